@@ -1,0 +1,533 @@
+/*
+ * decoders.c -- oracle restatement of Digiham::Decoder + the DMR and YSF phase
+ * state machines (TEST INFRASTRUCTURE ONLY).
+ *
+ * PARITY UNPINNED for the state machines (reference TUs need csdr headers, see
+ * dh_oracle.h); the FEC they call is the pinned fec.c.  Metadata bookkeeping
+ * (MetaCollector, talker alias, GPS, callsign strings) is out of scope: every
+ * call the reference makes into its MetaCollector is recorded as an orc_event
+ * carrying the raw FEC-corrected bytes instead.
+ */
+#include "dh_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+enum { PROTO_DMR = 1, PROTO_YSF = 2 };
+enum { PH_SYNC = 0, PH_FRAME = 1 };
+
+/* ---- DMR constants: src/dmr_decoder/dmr_phase.hpp:6-12,25-33 */
+#define DMR_SYNC_SIZE 24
+#define DMR_CACH_SIZE 12
+#define DMR_FRAME_SIZE 144
+#define DMR_SYNC_OFFSET (54 + DMR_CACH_SIZE)
+#define SYNCTYPE_DATA 1
+#define SYNCTYPE_VOICE 2
+static const uint8_t dmr_bs_data_sync[24]  = { 3,1,3,3,3,3,1,1,1,3,3,1,1,3,1,1,3,1,3,3,1,1,3,1 };
+static const uint8_t dmr_bs_voice_sync[24] = { 1,3,1,1,1,1,3,3,3,1,1,3,3,1,3,3,1,3,1,1,3,3,1,3 };
+static const uint8_t dmr_ms_data_sync[24]  = { 3,1,1,1,3,1,1,3,3,3,1,3,1,3,3,3,3,1,1,3,1,1,1,3 };
+static const uint8_t dmr_ms_voice_sync[24] = { 1,3,3,3,1,3,3,1,1,1,3,1,3,1,1,1,1,3,3,1,3,3,3,1 };
+/* emb.hpp:5-8, slottype.hpp:6-17 */
+enum { LCSS_SINGLE = 0, LCSS_START = 1, LCSS_STOP = 2, LCSS_CONTINUATION = 3 };
+enum { DT_VOICE_LC = 1, DT_TERMINATOR_LC = 2, DT_RATE_3_4_DATA = 8, DT_IDLE = 9 };
+
+/* ---- YSF constants: src/ysf_decoder/ysf_phase.hpp:7-12,21; fich.hpp:3-11 */
+#define YSF_SYNC_SIZE 20
+#define YSF_FICH_SIZE 100
+#define YSF_PAYLOAD_SIZE 360
+#define YSF_FRAME_SIZE 480
+static const uint8_t ysf_sync[20] = { 3,1,1,0,1,3,0,1,3,0,2,1,1,2,0,3,1,0,3,1 };
+enum { FT_HEADER = 0, FT_COMMUNICATION = 1, FT_TERMINATOR = 2 };
+enum { YDT_VD1 = 0, YDT_DATA_FR = 1, YDT_VD2 = 2, YDT_VOICE_FR = 3 };
+static const uint8_t tribit_majority_table[8] = { 0, 0, 0, 1, 0, 1, 1, 1 };
+/* AMBE bit order of the V/D type 2 voice channel (ysf_phase.hpp:46-51) */
+static const uint8_t v2_voice_mapping[49] = {
+    0, 3, 6,  9, 12, 15, 18, 21, 24, 27, 30, 33, 36, 39, 41, 43, 45, 47,
+    1, 4, 7, 10, 13, 16, 19, 22, 25, 28, 31, 34, 37, 40, 42, 44, 46, 48,
+    2, 5, 8, 11, 14, 17, 20, 23, 26, 29, 32, 35, 38,
+};
+
+typedef struct { uint8_t data[16]; uint8_t offset; } emb_collector;   /* embedded.hpp:7-19 */
+
+struct orc_decoder {
+    int proto, phase;
+    uint64_t consumed;       /* symbols consumed so far (for event stamps) */
+    /* sinks for the current process() call */
+    uint8_t* out; size_t out_cap, out_n;
+    orc_event* ev; size_t ev_cap, ev_n;
+    int overflow;
+    /* Dmr::Decoder (dmr_decoder.hpp:16) */
+    uint8_t slot_filter_decoder;
+    /* Dmr::FramePhase (dmr_phase.hpp:51-60) */
+    int sync_count, slot, slot_stability, sync_types[2], slot_sync_count[2], active_slot;
+    emb_collector emb[2];
+    uint8_t slot_filter, superframe_counter[2];
+    /* Ysf::FramePhase (ysf_phase.hpp:53-56) */
+    int has_running_fich; uint32_t running_fich; int expect_sub_frame;
+};
+
+static void emit(orc_decoder* d, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, uint8_t len) {
+    if (d->ev == NULL) return;
+    if (d->ev_n >= d->ev_cap) { d->overflow = 1; return; }
+    orc_event* e = &d->ev[d->ev_n++];
+    memset(e, 0, sizeof(*e));
+    e->sym_index = (uint32_t) d->consumed;
+    e->type = type; e->a = a; e->b = b; e->len = len;
+    if (len) memcpy(e->payload, payload, len);
+}
+
+static void enter_dmr_frame_phase(orc_decoder* d) {
+    /* FramePhase::FramePhase() (dmr_phase.cpp:49-52) + member initialisers (dmr_phase.hpp:51-60);
+     * Decoder::setPhase pushes the decoder's slot filter into the new phase (dmr_decoder.cpp:17-23) */
+    d->sync_count = 0; d->slot = -1; d->slot_stability = 0;
+    d->sync_types[0] = d->sync_types[1] = -1;
+    d->slot_sync_count[0] = d->slot_sync_count[1] = 0;
+    memset(d->emb, 0, sizeof(d->emb));
+    d->active_slot = -1;
+    d->superframe_counter[0] = d->superframe_counter[1] = 0;
+    d->slot_filter = d->slot_filter_decoder;
+    if (((d->active_slot + 1) & d->slot_filter) == 0) d->active_slot = -1;   /* dmr_phase.cpp:341-345 */
+}
+
+static void enter_ysf_frame_phase(orc_decoder* d) {
+    d->sync_count = 0; d->has_running_fich = 0; d->running_fich = 0; d->expect_sub_frame = 0;
+}
+
+orc_decoder* orc_dmr_new(void) {
+    orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
+    d->proto = PROTO_DMR; d->phase = PH_SYNC; d->slot_filter_decoder = 3;   /* dmr_decoder.hpp:16 */
+    return d;
+}
+
+orc_decoder* orc_ysf_new(void) {
+    orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
+    d->proto = PROTO_YSF; d->phase = PH_SYNC;
+    return d;
+}
+
+void orc_decoder_free(orc_decoder* d) { free(d); }
+
+/* dmr_decoder.cpp:9-15 + dmr_phase.cpp:341-345 */
+void orc_dmr_set_slot_filter(orc_decoder* d, uint8_t filter) {
+    d->slot_filter_decoder = filter;
+    if (d->phase == PH_FRAME) {
+        d->slot_filter = filter;
+        if (((d->active_slot + 1) & d->slot_filter) == 0) d->active_slot = -1;
+    }
+}
+
+/* ================================================================== DMR */
+
+/* dmr_phase.cpp:18-33 */
+static int dmr_get_sync_type(const uint8_t* s) {
+    if (orc_hamming_distance(s, dmr_bs_data_sync, DMR_SYNC_SIZE) <= 3) return SYNCTYPE_DATA;
+    if (orc_hamming_distance(s, dmr_bs_voice_sync, DMR_SYNC_SIZE) <= 3) return SYNCTYPE_VOICE;
+    if (orc_hamming_distance(s, dmr_ms_data_sync, DMR_SYNC_SIZE) <= 3) return SYNCTYPE_DATA;
+    if (orc_hamming_distance(s, dmr_ms_voice_sync, DMR_SYNC_SIZE) <= 3) return SYNCTYPE_VOICE;
+    return -1;
+}
+
+/* cach.cpp:11-31 (only the TACT is used downstream) + tact.cpp:9-12,20-22.
+ * returns -1 when Hamming(7,4) fails, else the TC (slot) bit */
+static int dmr_cach_tact_slot(const uint8_t* raw) {
+    static const uint8_t tact_positions[7] = { 0, 4, 8, 12, 14, 18, 22 };
+    uint8_t tact = 0;
+    for (int i = 0; i < 7; i++) {
+        uint8_t bit = tact_positions[i];
+        int pos = bit / 2, shift = 1 - (bit % 2);
+        tact = (uint8_t) ((tact << 1) | ((raw[pos] >> shift) & 1));
+    }
+    if (!orc_hamming_7_4(&tact)) return -1;
+    return (tact >> 5) & 1;
+}
+
+/* embedded.cpp:32-94; returns 1 and fills lc[9] on success */
+static int dmr_embedded_get_lc(emb_collector* c, uint8_t* lc) {
+    if (c->offset < 3) return 0;
+    uint16_t m[8] = { 0 };
+    for (int i = 0; i < 16; i++) {
+        uint8_t byte = c->data[i];
+        for (int k = 0; k < 8; k++) m[k] = (uint16_t) ((m[k] << 1) | ((byte >> (7 - k)) & 1));
+    }
+    for (int i = 0; i < 7; i++) if (!orc_hamming_16_11(&m[i])) return 0;
+    uint16_t parity = 0;
+    for (int i = 0; i < 8; i++) parity ^= m[i];
+    if (parity != 0) return 0;
+    lc[0] = (uint8_t) ((m[0] & 0xFF00) >> 8);
+    lc[1] = (uint8_t) ((m[0] & 0x00E0) | ((m[1] & 0xF800) >> 11));
+    lc[2] = (uint8_t) (((m[1] & 0x07E0) >> 3) | ((m[2] & 0xC000) >> 14));
+    lc[3] = (uint8_t) ((m[2] & 0x3FC0) >> 6);
+    lc[4] = (uint8_t) ((m[3] & 0xFF00) >> 8);
+    lc[5] = (uint8_t) ((m[3] & 0x00C0) | ((m[4] & 0xFC00) >> 10));
+    lc[6] = (uint8_t) (((m[4] & 0x03C0) >> 2) | ((m[5] & 0xF000) >> 12));
+    lc[7] = (uint8_t) (((m[5] & 0x0FC0) >> 4) | ((m[6] & 0xC000) >> 14));
+    lc[8] = (uint8_t) ((m[6] & 0x3FC0) >> 6);
+    uint16_t checksum = 0;
+    for (int i = 0; i < 9; i++) checksum = (uint16_t) (checksum + lc[i]);
+    uint8_t checksum_mod = (uint8_t) (checksum % 31);
+    uint8_t received = 0;
+    for (int i = 0; i < 5; i++) received |= (uint8_t) ((m[i + 2] & 0x0020) >> (i + 1));
+    return checksum_mod == received;
+}
+
+static void dmr_slot_sync_lost(orc_decoder* d) {
+    /* dmr_phase.cpp:175-182 == :194-200 */
+    if (--d->slot_sync_count[d->slot] < 0) {
+        d->slot_sync_count[d->slot] = 0;
+        d->sync_types[d->slot] = -1;
+        emit(d, ORC_EV_DMR_SLOT_RESET, (uint8_t) d->slot, 0, NULL, 0);
+        if (d->active_slot == d->slot) d->active_slot = -1;
+    }
+}
+
+/* dmr_phase.cpp:65-302.  returns 1 when the phase falls back to SyncPhase (no advance) */
+static int dmr_frame(orc_decoder* d, const uint8_t* p) {
+    int tact_slot = dmr_cach_tact_slot(p);
+    uint8_t next = (uint8_t) (d->slot ^ 1);              /* :69 (0xFE while slot == -1) */
+    if (tact_slot >= 0) {
+        if ((uint8_t) tact_slot != next) {
+            if (d->slot_stability < 5) {
+                d->slot_stability = 0;
+                d->slot = tact_slot;
+                uint8_t other = (uint8_t) (d->slot ^ 1);
+                d->sync_types[other] = -1;
+                emit(d, ORC_EV_DMR_SLOT_RESET, other, 0, NULL, 0);
+                if (d->active_slot == other) d->active_slot = -1;
+            } else {
+                d->slot_stability--;
+                if (d->slot != -1) d->slot = next;
+            }
+        } else {
+            if (++d->slot_stability > 100) d->slot_stability = 100;
+            d->slot = next;
+        }
+    } else if (d->slot != -1) {
+        if (d->slot_stability-- < -100) d->slot_stability = -100;
+        d->slot = next;
+    }
+
+    if (d->slot != -1) {
+        int slot = d->slot;
+        int sync_type = dmr_get_sync_type(p + DMR_SYNC_OFFSET);
+        if (sync_type > 0) {
+            if (++d->sync_count > 5) d->sync_count = 5;
+            if (++d->slot_sync_count[slot] > 5) d->slot_sync_count[slot] = 5;
+            uint8_t soft_reset = d->sync_types[slot] == SYNCTYPE_VOICE && sync_type != d->sync_types[slot];
+            d->sync_types[slot] = sync_type;
+            emit(d, ORC_EV_DMR_SYNC, (uint8_t) slot, (uint8_t) sync_type, &soft_reset, 1);
+            d->superframe_counter[slot] = 0;
+            d->emb[slot].offset = 0;
+        } else if (d->sync_types[slot] == SYNCTYPE_VOICE && d->superframe_counter[slot] < 5) {
+            d->superframe_counter[slot]++;
+            uint16_t emb_data = 0;
+            for (int i = 0; i < 2; i++) {
+                const uint8_t* raw = p + DMR_SYNC_OFFSET + i * 20;
+                for (int k = 0; k < 4; k++) emb_data = (uint16_t) ((emb_data << 2) | raw[k]);
+            }
+            if (orc_quadratic_residue(&emb_data)) {
+                if (++d->sync_count > 5) d->sync_count = 5;
+                if (++d->slot_sync_count[slot] > 5) d->slot_sync_count[slot] = 5;
+                uint8_t embedded_data[4] = { 0 };
+                const uint8_t* emb_raw = p + DMR_SYNC_OFFSET + 4;
+                for (int i = 0; i < 16; i++) embedded_data[i / 4] |= (uint8_t) (emb_raw[i] << (6 - (i % 4) * 2));
+                emb_collector* c = &d->emb[slot];
+                uint8_t lcss = (emb_data >> 9) & 3, cc = (emb_data >> 12) & 15;
+                emit(d, ORC_EV_DMR_EMB, (uint8_t) slot, lcss, &cc, 1);
+                switch (lcss) {
+                    case LCSS_SINGLE: break;
+                    case LCSS_START:
+                        c->offset = 0;
+                        /* fall through */
+                    case LCSS_CONTINUATION:
+                        if (c->offset <= 3) { memcpy(c->data + c->offset * 4, embedded_data, 4); c->offset++; }
+                        break;
+                    case LCSS_STOP: {
+                        if (c->offset <= 3) { memcpy(c->data + c->offset * 4, embedded_data, 4); c->offset++; }
+                        uint8_t lc[9];
+                        if (dmr_embedded_get_lc(c, lc)) emit(d, ORC_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
+                        c->offset = 0;
+                        break;
+                    }
+                }
+            } else {
+                dmr_slot_sync_lost(d);
+                if (--d->sync_count < 0) {
+                    emit(d, ORC_EV_DMR_META_RESET, 0, 0, NULL, 0);
+                    return 1;
+                }
+            }
+        } else {
+            d->superframe_counter[slot] = 0;
+            d->emb[slot].offset = 0;
+            dmr_slot_sync_lost(d);
+            if (--d->sync_count < 0) {
+                emit(d, ORC_EV_DMR_META_RESET, 0, 0, NULL, 0);
+                return 1;
+            }
+        }
+
+        if (d->sync_types[slot] == SYNCTYPE_VOICE) {
+            if (((slot + 1) & d->slot_filter) && (d->active_slot == -1 || d->active_slot == slot)) {
+                d->active_slot = slot;
+                if (d->out_cap - d->out_n < 27) { d->overflow = 1; }
+                else {
+                    uint8_t* payload = d->out + d->out_n;
+                    memset(payload, 0, 27);
+                    const uint8_t* raw = p + DMR_CACH_SIZE;
+                    for (int i = 0; i < 54; i++) payload[i / 4] |= (uint8_t) ((raw[i] & 3) << (6 - 2 * (i % 4)));
+                    raw += 54 + DMR_SYNC_SIZE;
+                    for (int i = 0; i < 54; i++) payload[(i + 54) / 4] |= (uint8_t) ((raw[i] & 3) << (6 - 2 * ((i + 54) % 4)));
+                    d->out_n += 27;
+                }
+            }
+        } else {
+            if (d->active_slot == slot) d->active_slot = -1;
+            if (d->sync_types[slot] == SYNCTYPE_DATA) {
+                uint32_t slot_type = 0;
+                const uint8_t* raw = p + DMR_SYNC_OFFSET - 5;
+                for (int i = 0; i < 5; i++) slot_type = (slot_type << 2) | (raw[i] & 3);
+                raw = p + DMR_SYNC_OFFSET + DMR_SYNC_SIZE;
+                for (int i = 0; i < 5; i++) slot_type = (slot_type << 2) | (raw[i] & 3);
+                if (orc_golay_20_8(&slot_type)) {
+                    uint8_t data_type = (slot_type >> 12) & 15, cc = (slot_type >> 16) & 15;
+                    emit(d, ORC_EV_DMR_SLOTTYPE, (uint8_t) slot, data_type, &cc, 1);
+                    if (data_type != DT_RATE_3_4_DATA) {
+                        uint8_t payload[25] = { 0 };
+                        const uint8_t* pr = p + DMR_CACH_SIZE;
+                        for (int k = 0; k < 49; k++) payload[k / 4] |= (uint8_t) ((pr[k] & 3) << (6 - 2 * (k % 4)));
+                        pr += 54 + DMR_SYNC_SIZE + 5;
+                        for (int k = 0; k < 49; k++) payload[(k + 49) / 4] |= (uint8_t) ((pr[k] & 3) << (6 - 2 * ((k + 49) % 4)));
+                        uint8_t lc_data[12] = { 0 };
+                        if (orc_bptc_196_96(payload, lc_data)) {
+                            emit(d, ORC_EV_DMR_BPTC, (uint8_t) slot, data_type, lc_data, 12);
+                            if (data_type == DT_VOICE_LC) {
+                                emit(d, ORC_EV_DMR_LC, (uint8_t) slot, 0, lc_data, 9);
+                            } else if (data_type == DT_TERMINATOR_LC || data_type == DT_IDLE) {
+                                emit(d, ORC_EV_DMR_SOFT_RESET, (uint8_t) slot, data_type, NULL, 0);
+                            }
+                        }
+                    }
+                }
+            } else {
+                emit(d, ORC_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, NULL, 0);
+            }
+        }
+    }
+    return 0;
+}
+
+/* ================================================================== YSF */
+
+/* fich.cpp:12-52 */
+static int ysf_fich_parse(const uint8_t* data, uint32_t* fich) {
+    uint8_t raw[25] = { 0 };
+    for (int i = 0; i < 100; i++) {
+        int offset = ((i * 20) % 100 + i * 20 / 100);
+        raw[i / 4] |= (uint8_t) ((data[offset] & 3) << (6 - 2 * (i % 4)));
+    }
+    uint8_t tr[13];
+    orc_decode_trellis(raw, 100, tr);
+    uint32_t g[4];
+    bool ok = true;
+    for (int i = 0; i < 4; i++) {
+        g[i] = (uint32_t) tr[i * 3] << 16 | (uint32_t) tr[i * 3 + 1] << 8 | tr[i * 3 + 2];
+        ok &= orc_golay_24_12(&g[i]);
+    }
+    if (!ok) return 0;
+    uint32_t fich_data = (g[0] & 0x00FFF000) << 8 | (g[1] & 0x00FFF000) >> 4 | (g[2] & 0x00FF0000) >> 16;
+    uint16_t fich_checksum = (uint16_t) ((g[2] & 0x0000F000) | (g[3] & 0x00FFF000) >> 12);
+    uint8_t be[4] = { (uint8_t) (fich_data >> 24), (uint8_t) (fich_data >> 16), (uint8_t) (fich_data >> 8), (uint8_t) fich_data };
+    if (orc_crc16_checksum(be, 4) != fich_checksum) return 0;
+    *fich = fich_data;
+    return 1;
+}
+
+/* ysf_phase.cpp:221-239 */
+static void ysf_decode_tribits(const uint8_t* input, uint8_t* output, uint8_t num) {
+    memset(output, 0, (size_t) (num + 7) / 8);
+    for (int i = 0; i < num; i++) {
+        int offset = i * 3;
+        uint8_t tribit = 0;
+        for (int k = 0; k < 3; k++) {
+            int pos = (offset + k) / 8, shift = 7 - ((offset + k) % 8);
+            tribit = (uint8_t) ((tribit << 1) | ((input[pos] >> shift) & 1));
+        }
+        output[i / 8] |= (uint8_t) (tribit_majority_table[tribit] << (7 - (i % 8)));
+    }
+}
+
+/* ysf_phase.cpp:180-219 + :241-256 */
+static void ysf_decode_v2_voice(const uint8_t* in, uint8_t* out) {
+    uint8_t inter[13] = { 0 };
+    for (int k = 0; k < 52; k++) inter[k / 4] |= (uint8_t) ((in[k] & 3) << (6 - 2 * (k % 4)));
+    uint8_t whitened[13] = { 0 };
+    for (int k = 0; k < 104; k++) {
+        int offset = (k * 4) % 104 + k * 4 / 104;
+        whitened[k / 8] |= (uint8_t) (((inter[offset / 8] >> (7 - offset % 8)) & 1) << (7 - k % 8));
+    }
+    uint8_t tribit[13] = { 0 };
+    orc_decode_whitening(whitened, tribit, 104);
+    uint8_t voice[7] = { 0 };
+    ysf_decode_tribits(tribit, voice, 27);
+    for (int k = 0; k < 22; k++) {
+        int ib = k + 81, ob = k + 27;
+        voice[ob / 8] |= (uint8_t) (((tribit[ib / 8] >> (7 - (ib % 8))) & 1) << (7 - (ob % 8)));
+    }
+    for (int i = 0; i < 7; i++) out[i] = 0;
+    for (int ib = 0; ib < 49; ib++) {
+        int ob = v2_voice_mapping[ib];
+        uint8_t x = (voice[ib / 8] >> (7 - (ib % 8))) & 1;
+        out[ob / 8] |= (uint8_t) (x << (7 - (ob % 8)));
+    }
+}
+
+/* ysf_phase.cpp:317-349; returns 1 and fills dch[20] on success */
+static int ysf_decode_header_dch(const uint8_t* in, uint8_t* dch) {
+    uint8_t raw[45] = { 0 };
+    for (int i = 0; i < 180; i++) {
+        int streampos = (i % 9) * 20 + i / 9;
+        int inpos = (streampos / 36) * 72 + streampos % 36;
+        raw[i / 4] |= (uint8_t) ((in[inpos] & 3) << (6 - 2 * (i % 4)));
+    }
+    uint8_t whitened[23] = { 0 };
+    orc_decode_trellis(raw, 180, whitened);
+    uint16_t checksum = (uint16_t) ((whitened[20] << 8) | whitened[21]);
+    if (orc_crc16_checksum(whitened, 20) != checksum) return 0;
+    orc_decode_whitening(whitened, dch, 160);
+    return 1;
+}
+
+/* ysf_phase.cpp:45-172.  returns 1 on fall-back to SyncPhase (nothing consumed) */
+static int ysf_frame(orc_decoder* d, const uint8_t* p) {
+    if (orc_hamming_distance(p, ysf_sync, YSF_SYNC_SIZE) <= 3) {
+        if (++d->sync_count > 12) d->sync_count = 12;
+    } else {
+        if (--d->sync_count < 0) {
+            emit(d, ORC_EV_YSF_META_RESET, 0, 0, NULL, 0);
+            return 1;
+        }
+    }
+    uint32_t fich = 0;
+    int fresh = ysf_fich_parse(p + YSF_SYNC_SIZE, &fich);
+    if (fresh) {
+        d->running_fich = fich; d->has_running_fich = 1;
+        uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };
+        emit(d, ORC_EV_YSF_FICH, 0, 0, be, 4);
+    }
+    const uint8_t* payload = p + YSF_SYNC_SIZE + YSF_FICH_SIZE;
+    if (d->has_running_fich) {
+        uint8_t frame_type = (d->running_fich >> 30) & 3;
+        uint8_t data_type = (d->running_fich >> 8) & 3;
+        switch (frame_type) {
+            case FT_COMMUNICATION:
+                emit(d, ORC_EV_YSF_MODE, 0, data_type, NULL, 0);
+                switch (data_type) {
+                    case YDT_VD1:
+                        for (int i = 0; i < 5; i++) {
+                            if (d->out_cap - d->out_n < 10) { d->overflow = 1; break; }
+                            uint8_t* o = d->out + d->out_n;
+                            o[0] = data_type;
+                            /* ysf_phase.cpp:174-178: `=` (not `|=`): only dibit k%4==3 of each byte survives */
+                            const uint8_t* in = payload + 36 + i * 72;
+                            for (int k = 0; k < 36; k++) o[1 + k / 4] = (uint8_t) ((in[k] & 3) << (6 - 2 * (k % 4)));
+                            d->out_n += 10;
+                        }
+                        break;
+                    case YDT_VD2:
+                        for (int i = 0; i < 5; i++) {
+                            if (d->out_cap - d->out_n < 8) { d->overflow = 1; break; }
+                            uint8_t* o = d->out + d->out_n;
+                            o[0] = data_type;
+                            ysf_decode_v2_voice(payload + 20 + i * 72, o + 1);
+                            d->out_n += 8;
+                        }
+                        if (fresh) {
+                            uint8_t dch_raw[25] = { 0 };
+                            for (int i = 0; i < 100; i++) {
+                                int inpos = ((i % 5) * 72 + (i * 2) / 10);
+                                dch_raw[i / 4] |= (uint8_t) ((payload[inpos] & 3) << (6 - 2 * (i % 4)));
+                            }
+                            /* decodeV2DataChannel, ysf_phase.cpp:258-269 (metadata tail :271-305 out of scope) */
+                            uint8_t whitened[13] = { 0 };
+                            orc_decode_trellis(dch_raw, 100, whitened);
+                            uint16_t checksum = (uint16_t) (whitened[10] << 8 | whitened[11]);
+                            if (orc_crc16_checksum(whitened, 10) == checksum) {
+                                uint8_t dch[13] = { 0 };
+                                orc_decode_whitening(whitened, dch, 100);
+                                emit(d, ORC_EV_YSF_DCH, (uint8_t) ((fich >> 19) & 7), 0, dch, 10);
+                            }
+                        }
+                        break;
+                    case YDT_VOICE_FR: {
+                        int start_frame = d->expect_sub_frame ? 3 : 0;
+                        d->expect_sub_frame = 0;
+                        for (int i = start_frame; i < 5; i++) {
+                            if (d->out_cap - d->out_n < 19) { d->overflow = 1; break; }
+                            uint8_t* o = d->out + d->out_n;
+                            o[0] = data_type;
+                            memset(o + 1, 0, 18);
+                            const uint8_t* in = payload + i * 72;
+                            for (int k = 0; k < 72; k++) o[1 + k / 4] |= (uint8_t) ((in[k] & 3) << (6 - 2 * (k % 4)));
+                            d->out_n += 19;
+                        }
+                        break;
+                    }
+                    case YDT_DATA_FR: break;
+                }
+                break;
+            case FT_HEADER: {
+                emit(d, ORC_EV_YSF_META_RESET, 0, 1, NULL, 0);
+                uint8_t dch[20];
+                if (ysf_decode_header_dch(payload, dch)) emit(d, ORC_EV_YSF_HEADER_DCH, 0, 0, dch, 20);
+                if (ysf_decode_header_dch(payload + 36, dch)) emit(d, ORC_EV_YSF_HEADER_DCH, 1, 0, dch, 20);
+                d->expect_sub_frame = 1;
+                break;
+            }
+            case FT_TERMINATOR:
+                emit(d, ORC_EV_YSF_META_RESET, 0, 2, NULL, 0);
+                break;
+        }
+    }
+    return 0;
+}
+
+/* ============================================ Digiham::Decoder main loop */
+/* `while (canProcess()) process()` with canProcess = available > required
+ * (src/lib/decoder.cpp:21-32; cli.cpp:29-33) */
+size_t orc_decoder_process(orc_decoder* d, const uint8_t* in, size_t n,
+                           uint8_t* out, size_t cap, size_t* n_out,
+                           orc_event* ev, size_t ev_cap, size_t* n_ev) {
+    d->out = out; d->out_cap = cap; d->out_n = 0;
+    d->ev = ev; d->ev_cap = ev_cap; d->ev_n = 0; d->overflow = 0;
+    size_t pos = 0;
+    for (;;) {
+        size_t avail = n - pos;
+        const uint8_t* p = in + pos;
+        if (d->proto == PROTO_DMR) {
+            if (d->phase == PH_SYNC) {
+                if (!(avail > DMR_SYNC_SIZE + DMR_SYNC_OFFSET)) break;      /* dmr_phase.cpp:35-37 */
+                if (dmr_get_sync_type(p + DMR_SYNC_OFFSET) > 0) {           /* :39-47 */
+                    d->phase = PH_FRAME; enter_dmr_frame_phase(d);
+                } else { pos++; d->consumed++; }
+            } else {
+                if (!(avail > DMR_FRAME_SIZE)) break;                        /* :61-63 */
+                if (dmr_frame(d, p)) d->phase = PH_SYNC;
+                else { pos += DMR_FRAME_SIZE; d->consumed += DMR_FRAME_SIZE; }
+            }
+        } else {
+            if (d->phase == PH_SYNC) {
+                if (!(avail > YSF_SYNC_SIZE)) break;                         /* ysf_phase.cpp:20-22 */
+                if (orc_hamming_distance(p, ysf_sync, YSF_SYNC_SIZE) <= 3) {   /* :25-34 */
+                    d->phase = PH_FRAME; enter_ysf_frame_phase(d);
+                } else { pos++; d->consumed++; }
+            } else {
+                if (!(avail > YSF_FRAME_SIZE)) break;                        /* :41-43 */
+                if (ysf_frame(d, p)) d->phase = PH_SYNC;
+                else { pos += YSF_FRAME_SIZE; d->consumed += YSF_FRAME_SIZE; }
+            }
+        }
+        if (d->overflow) break;
+    }
+    if (n_out) *n_out = d->out_n;
+    if (n_ev) *n_ev = d->ev_n;
+    return pos;
+}

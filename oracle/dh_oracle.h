@@ -1,0 +1,145 @@
+/*
+ * dh_oracle.h -- CPU oracle for the digiham hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * A plain-C restatement of the reference algorithms (jketterl/digiham v0.7.0-dev)
+ * for rrc_filter -> gfsk/fsk_demodulator -> dmr/ysf_decoder FEC and the
+ * digitalvoice_filter.  Every function cites the reference file:line it follows.
+ *
+ * This code is the *checker*: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product (digiham_amd/) never
+ * links, imports or falls back to anything in this directory.
+ *
+ * Pinning status (see oracle/README.md):
+ *   - FEC primitives (fec.c): PINNED against the reference's own C sources,
+ *     compiled unmodified into oracle/_ref/libdigiham_ref_fec.so by
+ *     oracle/Makefile and compared exhaustively (tests/test_oracle_vs_ref.py).
+ *   - DSP (dsp.c) and frame state machines (dmr.c, ysf.c): PARITY UNPINNED --
+ *     those reference TUs include <csdr/module.hpp> (csdr 0.18, third-party,
+ *     absent from this image), so they are unbuildable here without writing
+ *     stand-in headers, which the rules forbid.  They are restated line by
+ *     line from the cited sources instead.
+ */
+#ifndef DH_ORACLE_H
+#define DH_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ fec.c */
+unsigned int orc_hamming_distance(const uint8_t* a, const uint8_t* b, size_t size);
+bool orc_hamming_7_4(uint8_t* data);
+bool orc_hamming_13_9(uint16_t* data);
+bool orc_hamming_15_11(uint16_t* data);
+bool orc_hamming_16_11(uint16_t* data);
+bool orc_golay_20_8(uint32_t* data);
+bool orc_golay_24_12(uint32_t* data);
+bool orc_quadratic_residue(uint16_t* data);
+bool orc_bptc_196_96(const uint8_t* payload /*25*/, uint8_t* output /*12*/);
+uint8_t orc_decode_trellis(const uint8_t* input, uint8_t size, uint8_t* output);
+uint16_t orc_crc16_checksum(const uint8_t* data, int count);
+void orc_decode_whitening(const uint8_t* input, uint8_t* output, uint8_t num);
+
+/* encoders (not in the reference; used by the synthetic signal generator and
+ * by round-trip tests).  Systematic encoders from the same generator matrices. */
+uint8_t  orc_hamming_7_4_encode(uint8_t data4);
+uint16_t orc_hamming_13_9_encode(uint16_t data9);
+uint16_t orc_hamming_15_11_encode(uint16_t data11);
+uint16_t orc_hamming_16_11_encode(uint16_t data11);
+uint32_t orc_golay_20_8_encode(uint8_t data8);
+uint32_t orc_golay_24_12_encode(uint16_t data12);
+uint16_t orc_quadratic_residue_encode(uint8_t data7);
+void orc_bptc_196_96_encode(const uint8_t* info /*12*/, uint8_t* payload /*25*/);
+/* rate-1/2 K=5 convolutional encoder: nbits input bits (MSB first) -> nbits dibits packed 4/byte */
+void orc_trellis_encode(const uint8_t* bits, int nbits, uint8_t* out);
+
+/* ------------------------------------------------------------------ dsp.c */
+typedef struct orc_rrc orc_rrc;
+orc_rrc* orc_rrc_new(int narrow);
+void orc_rrc_free(orc_rrc*);
+void orc_rrc_process(orc_rrc*, const float* in, float* out, size_t n);
+const float* orc_rrc_taps(int narrow, unsigned* n_zeros, double* gain);
+
+typedef struct orc_demod orc_demod;
+/* levels = 4 -> GfskDemodulator(sps); levels = 2 -> FskDemodulator(sps, invert) */
+orc_demod* orc_demod_new(unsigned sps, int levels, int invert);
+void orc_demod_free(orc_demod*);
+/* streaming: consumes from in[0..n), returns number of samples consumed (the
+ * caller keeps the unread tail, exactly like a csdr ringbuffer reader) and
+ * appends symbols to out (capacity cap); *n_out receives the count. */
+size_t orc_demod_process(orc_demod*, const float* in, size_t n, uint8_t* out, size_t cap, size_t* n_out);
+
+typedef struct orc_dvfilter orc_dvfilter;
+orc_dvfilter* orc_dvfilter_new(void);
+void orc_dvfilter_free(orc_dvfilter*);
+void orc_dvfilter_process(orc_dvfilter*, const int16_t* in, int16_t* out, size_t n);
+
+/* --------------------------------------------------------- dmr.c / ysf.c */
+/* Decoder event record: what the reference hands to its MetaCollector (and a
+ * few FEC intermediates), as plain data so it can be compared bit-exactly.
+ * Layout is shared with the product's C-ABI (include/digiham_amd.h: dh_event). */
+typedef struct {
+    uint32_t sym_index;   /* absolute symbol index of the frame start (mod 2^32) */
+    uint8_t  type;        /* ORC_EV_* */
+    uint8_t  a;           /* slot (DMR) / frame number (YSF) */
+    uint8_t  b;           /* sub-type: sync type, data type, ... */
+    uint8_t  len;         /* valid payload bytes */
+    uint8_t  payload[24];
+} orc_event;
+
+enum {
+    ORC_EV_DMR_SYNC        = 1,  /* a=slot b=syncType payload[0]=softReset      dmr_phase.cpp:111-114 */
+    ORC_EV_DMR_SLOT_RESET  = 2,  /* a=slot                                       dmr_phase.cpp:81,178,197,285 */
+    ORC_EV_DMR_META_RESET  = 3,  /* MetaCollector::reset()                       dmr_phase.cpp:184,202 */
+    ORC_EV_DMR_LC          = 4,  /* a=slot b=0 voice header / 1 embedded; payload=9 LC bytes  dmr_phase.cpp:159,276 */
+    ORC_EV_DMR_SOFT_RESET  = 5,  /* a=slot b=data_type (terminator / idle)       dmr_phase.cpp:278-281 */
+    ORC_EV_DMR_BPTC        = 6,  /* a=slot b=data_type payload=12 bytes          dmr_phase.cpp:272 */
+    ORC_EV_DMR_SLOTTYPE    = 7,  /* a=slot b=data_type payload[0]=color code     dmr_phase.cpp:247-249 */
+    ORC_EV_DMR_EMB         = 8,  /* a=slot b=lcss payload[0]=color code          dmr_phase.cpp:134 */
+    ORC_EV_YSF_FICH        = 16, /* payload=fich u32 big endian                   fich.cpp:12-52 */
+    ORC_EV_YSF_MODE        = 17, /* b=data type (0 V1, 2 DN, 3 VW, 1 FR data)      ysf_phase.cpp:75,87,113,134 */
+    ORC_EV_YSF_DCH         = 18, /* a=frame number payload=10 bytes                ysf_phase.cpp:258-269 */
+    ORC_EV_YSF_HEADER_DCH  = 19, /* a=0 (CSD1) / 1 (CSD2) payload=20 bytes         ysf_phase.cpp:145,152 */
+    ORC_EV_YSF_META_RESET  = 20, /* b=0 sync loss, 1 header, 2 terminator          ysf_phase.cpp:50,141,163 */
+};
+
+typedef struct orc_decoder orc_decoder;
+orc_decoder* orc_dmr_new(void);
+orc_decoder* orc_ysf_new(void);
+void orc_decoder_free(orc_decoder*);
+void orc_dmr_set_slot_filter(orc_decoder*, uint8_t filter);
+/* streaming: consumes symbols from in[0..n); returns symbols consumed.  Output
+ * bytes appended to out (cap), events to ev (ev_cap). */
+size_t orc_decoder_process(orc_decoder*, const uint8_t* in, size_t n,
+                           uint8_t* out, size_t cap, size_t* n_out,
+                           orc_event* ev, size_t ev_cap, size_t* n_ev);
+
+/* ----------------------------------------------------------------- pipe.c */
+/* whole-chain helper used by bench.py's cpu_baseline leg and by tests:
+ * rrc(wide|narrow|none) -> demod(levels,sps) -> decoder(proto) for n_channels
+ * independent channels laid out [n_channels][stride] floats, on n_threads
+ * pthreads (one channel per thread at a time). Returns 0 on success. */
+typedef struct {
+    int rrc;        /* 0 none, 1 wide, 2 narrow */
+    int levels;     /* 4 gfsk, 2 fsk, 0 = no demod */
+    int invert;
+    unsigned sps;
+    int proto;      /* 0 none, 1 DMR, 2 YSF */
+    int slot_filter;
+} orc_chain_cfg;
+
+int orc_chain_run(const orc_chain_cfg* cfg, const float* in, size_t n_channels, size_t stride, size_t n,
+                  float* filtered /* [n_channels][stride] or NULL */,
+                  uint8_t* syms, size_t sym_stride, uint32_t* sym_count,
+                  uint8_t* out, size_t out_stride, uint32_t* out_count,
+                  orc_event* ev, size_t ev_stride, uint32_t* ev_count,
+                  int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
