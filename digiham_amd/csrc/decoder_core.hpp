@@ -1,0 +1,812 @@
+// decoder_core.hpp -- Digiham::Decoder shell + DMR / YSF frame state machines, one channel per
+// wavefront.
+//
+// The reference walks byte-per-dibit buffers with scalar loops.  Here a frame's dibits are
+// loaded once (one symbol per lane, three loads), turned into two 192-bit BITPLANES with
+// wave-wide votes (bit1 plane H, bit0 plane L), and every field the protocol needs is then a
+// shift/mask/bit-reverse/interleave of those planes: wave-uniform integer work that stays off
+// the vector memory path.  Sync correlation is XOR + popcount of the planes against the sync
+// pattern planes; while unsynchronised, each lane tests one candidate offset and a vote picks
+// the first hit (what the reference does one symbol per call: dmr_phase.cpp:39-47).
+// Lane-parallel parts: plane construction, sync search, BPTC column decode, payload packing,
+// Viterbi add-compare-select (16 states on 16 lanes), event / output stores.
+#pragma once
+
+#include "dh_portable.hpp"
+#include "fec_core.hpp"
+
+#include "../../include/digiham_amd.h"     // dh_event, DH_EV_*
+
+#define DH_SYM_CARRY_MAX 512          // symbols a decoder may leave unread between pushes (<= 480)
+#define DH_DEC_STATE_WORDS 32
+
+enum {
+    DS_PHASE = 0, DS_SYNC_COUNT = 1, DS_SLOT = 2, DS_SLOT_STABILITY = 3, DS_SYNC_TYPE0 = 4, DS_SYNC_TYPE1 = 5,
+    DS_SLOT_SYNC0 = 6, DS_SLOT_SYNC1 = 7, DS_ACTIVE_SLOT = 8, DS_SLOT_FILTER = 9, DS_SUPERFRAME0 = 10,
+    DS_SUPERFRAME1 = 11, DS_EMB_OFF0 = 12, DS_EMB_OFF1 = 13, DS_EMB_DATA0 = 14 /*4 words*/, DS_EMB_DATA1 = 18,
+    DS_CONSUMED = 22, DS_CARRY = 23, DS_SLOT_FILTER_DECODER = 24, DS_HAS_FICH = 25, DS_FICH = 26, DS_EXPECT_SUB = 27
+};
+
+struct DhDecParams {
+    const uint8_t* syms; size_t sym_stride;    // [B][sym_stride] this push's symbols (dibits, one per byte)
+    const uint32_t* sym_count;                 // [B] symbols in this push
+    uint8_t* carry; size_t carry_stride;       // [B][DH_SYM_CARRY_MAX] symbols left unread by the previous push
+    uint32_t* state; size_t state_stride;      // [B][DH_DEC_STATE_WORDS]
+    uint8_t* out; size_t out_stride; uint32_t out_cap; uint32_t* out_count;
+    dh_event* events; size_t ev_stride; uint32_t ev_cap; uint32_t* ev_count;   // events may be null
+    uint32_t* overflow;
+    const DhFecTables* T;
+    uint32_t n_channels;
+};
+
+#define DH_PLANE_WORDS 8            // 512 symbols: a YSF frame is 480, a DMR burst + search window 154
+struct DhPlanes { uint64_t h[DH_PLANE_WORDS], l[DH_PLANE_WORDS]; };
+
+// bits [start, start+cnt) of a plane, symbol `start` in bit 0 (cnt <= 32)
+DH_HD uint32_t dh_plane_range(const uint64_t* w, int start, int cnt) {
+    const int i = start >> 6, sh = start & 63;
+    uint64_t v = w[i] >> sh;
+    if (sh && i < DH_PLANE_WORDS - 1) v |= w[i + 1] << (64 - sh);
+    return (uint32_t) (v & ((cnt >= 32) ? 0xFFFFFFFFull : ((1ull << cnt) - 1)));
+}
+
+DH_HD uint32_t dh_spread16(uint32_t x) {      // abcd -> 0a0b0c0d
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// cnt (<= 16) symbols starting at `start`, packed MSB-first 2 bits per symbol -- what the
+// reference's `(v << 2) | raw[i]` loops build (e.g. dmr_phase.cpp:123-132, :236-245)
+DH_HD uint32_t dh_syms_msb(const DhPlanes& p, int start, int cnt) {
+    const uint32_t hr = dh_brev32(dh_plane_range(p.h, start, cnt)) >> (32 - cnt);
+    const uint32_t lr = dh_brev32(dh_plane_range(p.l, start, cnt)) >> (32 - cnt);
+    return (dh_spread16(hr) << 1) | dh_spread16(lr);
+}
+
+DH_HD uint32_t dh_sym_at(const DhPlanes& p, int j) {
+    return (uint32_t) ((((p.h[j >> 6] >> (j & 63)) & 1ull) << 1) | ((p.l[j >> 6] >> (j & 63)) & 1ull));
+}
+
+// Hamming distance between 24 (or 20) symbols at `start` and a pattern given as planes
+DH_HD int dh_sync_distance(const DhPlanes& p, int start, int cnt, uint32_t pat_h, uint32_t pat_l) {
+    return dh_popc32(dh_plane_range(p.h, start, cnt) ^ pat_h) + dh_popc32(dh_plane_range(p.l, start, cnt) ^ pat_l);
+}
+
+// sync words as planes (symbol i in bit i), derived from the ETSI TS 102 361-1 table 9.2 / YSF spec hex
+// words (the dibit arrays at dmr_phase.hpp:25-28 and ysf_phase.hpp:21 are the same words)
+constexpr uint32_t dh_sync_plane(uint64_t word, int ndibits, int bit) {
+    uint32_t r = 0;
+    for (int i = 0; i < ndibits; i++) {
+        const uint32_t dibit = (uint32_t) ((word >> (2 * (ndibits - 1 - i))) & 3u);
+        r |= ((dibit >> bit) & 1u) << i;
+    }
+    return r;
+}
+#define DH_DMR_BS_DATA_H  dh_sync_plane(0xDFF57D75DF5Dull, 24, 1)
+#define DH_DMR_BS_VOICE_H dh_sync_plane(0x755FD7DF75F7ull, 24, 1)
+#define DH_DMR_MS_DATA_H  dh_sync_plane(0xD5D7F77FD757ull, 24, 1)
+#define DH_DMR_MS_VOICE_H dh_sync_plane(0x7F7D5DD57DFDull, 24, 1)
+#define DH_DMR_SYNC_L     dh_sync_plane(0xDFF57D75DF5Dull, 24, 0)     /* every DMR sync dibit is 01 or 11: all ones */
+#define DH_YSF_SYNC_H     dh_sync_plane(0xD471C9634Dull, 20, 1)
+#define DH_YSF_SYNC_L     dh_sync_plane(0xD471C9634Dull, 20, 0)
+
+#define DH_SYNCTYPE_DATA 1
+#define DH_SYNCTYPE_VOICE 2
+
+// dmr_phase.cpp:18-33
+DH_HD int dh_dmr_sync_type(const DhPlanes& p, int start) {
+    const uint32_t h = dh_plane_range(p.h, start, 24), l = dh_plane_range(p.l, start, 24);
+    constexpr uint32_t SL = DH_DMR_SYNC_L, BD = DH_DMR_BS_DATA_H, BV = DH_DMR_BS_VOICE_H,
+                       MD = DH_DMR_MS_DATA_H, MV = DH_DMR_MS_VOICE_H;
+    static_assert(SL == 0xFFFFFFu, "DMR sync L plane");
+    const int dl = dh_popc32(l ^ SL);
+    if (dh_popc32(h ^ BD) + dl <= 3) return DH_SYNCTYPE_DATA;
+    if (dh_popc32(h ^ BV) + dl <= 3) return DH_SYNCTYPE_VOICE;
+    if (dh_popc32(h ^ MD) + dl <= 3) return DH_SYNCTYPE_DATA;
+    if (dh_popc32(h ^ MV) + dl <= 3) return DH_SYNCTYPE_VOICE;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct DhDecCtx {
+    const DhDecParams* P;
+    uint32_t* st;
+    uint8_t* out; dh_event* ev;
+    uint32_t nout, nev, consumed;
+    bool overflow;
+    bool writer;                       // this thread performs the (wave-uniform) global stores
+};
+
+DH_HD void dh_emit(DhDecCtx& c, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, int len) {
+    if (c.ev == nullptr) return;
+    if (c.nev >= c.P->ev_cap) { c.overflow = true; return; }
+    if (c.writer) {
+        dh_event e;
+        e.sym_index = c.consumed; e.type = type; e.a = a; e.b = b; e.len = (uint8_t) len;
+        for (int i = 0; i < 24; i++) e.payload[i] = i < len ? payload[i] : (uint8_t) 0;
+        c.ev[c.nev] = e;
+    }
+    c.nev++;
+}
+
+// FramePhase::FramePhase() + Decoder::setPhase (dmr_phase.cpp:49-52, dmr_phase.hpp:51-60, dmr_decoder.cpp:17-23)
+DH_HD void dh_dmr_enter_frame_phase(uint32_t* s) {
+    s[DS_SYNC_COUNT] = 0; s[DS_SLOT] = (uint32_t) -1; s[DS_SLOT_STABILITY] = 0;
+    s[DS_SYNC_TYPE0] = s[DS_SYNC_TYPE1] = (uint32_t) -1;
+    s[DS_SLOT_SYNC0] = s[DS_SLOT_SYNC1] = 0;
+    s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+    s[DS_SUPERFRAME0] = s[DS_SUPERFRAME1] = 0;
+    s[DS_EMB_OFF0] = s[DS_EMB_OFF1] = 0;
+    for (int i = 0; i < 8; i++) s[DS_EMB_DATA0 + i] = 0;
+    s[DS_SLOT_FILTER] = s[DS_SLOT_FILTER_DECODER];
+}
+
+// EmbeddedCollector::getLc (embedded.cpp:32-94) on the 16 collected bytes (4 big-endian words)
+DH_HD bool dh_dmr_embedded_lc(const DhFecTables& T, const uint32_t* data, uint32_t off, uint8_t* lc) {
+    if (off < 3) return false;
+    uint32_t m[8];
+    for (int k = 0; k < 8; k++) m[k] = 0;
+    for (int i = 0; i < 16; i++) {
+        const uint32_t byte = (data[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
+        for (int k = 0; k < 8; k++) m[k] = (m[k] << 1) | ((byte >> (7 - k)) & 1u);
+    }
+    for (int i = 0; i < 7; i++) if (!dh_block_decode(T.h1611, T.lut_h1611, m[i])) return false;
+    uint32_t parity = 0;
+    for (int i = 0; i < 8; i++) parity ^= m[i];
+    if (parity != 0) return false;
+    // 72 LC bits: 11 from rows 0,1 and 10 from rows 2..6 (ETSI B.2.1); 5 checksum bits = bit 5 of rows 2..6
+    uint64_t acc = 0; int nacc = 0, ob = 0; uint32_t received = 0, sum = 0;
+    for (int r = 0; r < 7; r++) {
+        const int nb = r < 2 ? 11 : 10;
+        acc = (acc << nb) | ((m[r] >> (16 - nb)) & ((1u << nb) - 1)); nacc += nb;
+        while (nacc >= 8) { lc[ob] = (uint8_t) (acc >> (nacc - 8)); sum += lc[ob]; ob++; nacc -= 8; }
+        if (r >= 2) received |= ((m[r] >> 5) & 1u) << (4 - (r - 2));
+    }
+    return (sum % 31u) == received;
+}
+
+DH_HD void dh_dmr_slot_sync_lost(DhDecCtx& c, int slot) {     // dmr_phase.cpp:175-182 == :194-200
+    uint32_t* s = c.st;
+    int v = (int) s[DS_SLOT_SYNC0 + slot] - 1;
+    if (v < 0) {
+        v = 0;
+        s[DS_SYNC_TYPE0 + slot] = (uint32_t) -1;
+        dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
+        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+    }
+    s[DS_SLOT_SYNC0 + slot] = (uint32_t) v;
+}
+
+struct DhDmrFrameResult { bool to_sync; bool voice_out; bool want_bptc; uint8_t data_type; };
+
+// FramePhase::process up to (not including) the payload stores and the BPTC, which the caller runs
+// lane-parallel (dmr_phase.cpp:65-254).
+DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhPlanes& p) {
+    const DhFecTables& T = *c.P->T;
+    uint32_t* s = c.st;
+    DhDmrFrameResult R; R.to_sync = false; R.voice_out = false; R.want_bptc = false; R.data_type = 0;
+
+    // CACH: the 7 TACT bits sit on the bit1 plane of dibits 0,2,4,6,7,9,11 (cach.cpp:7,11-19)
+    const uint32_t h12 = (uint32_t) (p.h[0] & 0xFFFu);
+    uint32_t tact = ((h12 >> 0) & 1u) << 6 | ((h12 >> 2) & 1u) << 5 | ((h12 >> 4) & 1u) << 4 | ((h12 >> 6) & 1u) << 3 |
+                    ((h12 >> 7) & 1u) << 2 | ((h12 >> 9) & 1u) << 1 | ((h12 >> 11) & 1u);
+    const bool has_tact = dh_block_decode(T.h74, T.lut_h74, tact);
+    const int tact_slot = (int) ((tact >> 5) & 1u);
+
+    int slot = (int) s[DS_SLOT], stab = (int) s[DS_SLOT_STABILITY];
+    const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
+    if (has_tact) {
+        if (tact_slot != next) {
+            if (stab < 5) {
+                stab = 0; slot = tact_slot;
+                const int other = slot ^ 1;
+                s[DS_SYNC_TYPE0 + other] = (uint32_t) -1;
+                dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) other, 0, nullptr, 0);
+                if ((int) s[DS_ACTIVE_SLOT] == other) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+            } else {
+                stab--;
+                if (slot != -1) slot = next;
+            }
+        } else {
+            if (++stab > 100) stab = 100;
+            slot = next;
+        }
+    } else if (slot != -1) {
+        if (stab-- < -100) stab = -100;
+        slot = next;
+    }
+    s[DS_SLOT] = (uint32_t) slot; s[DS_SLOT_STABILITY] = (uint32_t) stab;
+    if (slot == -1) return R;
+
+    int sync_count = (int) s[DS_SYNC_COUNT];
+    const int sync_type = dh_dmr_sync_type(p, 66);
+    if (sync_type > 0) {
+        if (++sync_count > 5) sync_count = 5;
+        int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
+        s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
+        uint8_t soft = ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) ? 1 : 0;
+        s[DS_SYNC_TYPE0 + slot] = (uint32_t) sync_type;
+        dh_emit(c, DH_EV_DMR_SYNC, (uint8_t) slot, (uint8_t) sync_type, &soft, 1);
+        s[DS_SUPERFRAME0 + slot] = 0;
+        s[DS_EMB_OFF0 + slot] = 0;
+    } else if ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && s[DS_SUPERFRAME0 + slot] < 5) {
+        s[DS_SUPERFRAME0 + slot]++;
+        // EMB: dibits 66..69 and 86..89 (:123-132), QR(16,7)
+        uint32_t emb = (dh_syms_msb(p, 66, 4) << 8) | dh_syms_msb(p, 86, 4);
+        if (dh_block_decode(T.qr, T.lut_qr, emb)) {
+            if (++sync_count > 5) sync_count = 5;
+            int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
+            s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
+            const uint32_t frag = dh_syms_msb(p, 70, 16);               // 32 embedded bits (:141-145)
+            const uint32_t lcss = (emb >> 9) & 3u; uint8_t cc = (uint8_t) ((emb >> 12) & 15u);
+            dh_emit(c, DH_EV_DMR_EMB, (uint8_t) slot, (uint8_t) lcss, &cc, 1);
+            uint32_t off = s[DS_EMB_OFF0 + slot];
+            uint32_t* data = s + (slot ? DS_EMB_DATA1 : DS_EMB_DATA0);
+            if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
+            if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
+                if (off <= 3) { data[off] = frag; off++; }
+            }
+            if (lcss == 2) {                                             // LCSS_STOP
+                uint8_t lc[9];
+                if (dh_dmr_embedded_lc(T, data, off, lc)) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
+                off = 0;
+            }
+            s[DS_EMB_OFF0 + slot] = off;
+        } else {
+            dh_dmr_slot_sync_lost(c, slot);
+            if (--sync_count < 0) {
+                dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
+                R.to_sync = true; return R;
+            }
+        }
+    } else {
+        s[DS_SUPERFRAME0 + slot] = 0;
+        s[DS_EMB_OFF0 + slot] = 0;
+        dh_dmr_slot_sync_lost(c, slot);
+        if (--sync_count < 0) {
+            dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
+            R.to_sync = true; return R;
+        }
+    }
+    s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+
+    const int st = (int) s[DS_SYNC_TYPE0 + slot];
+    if (st == DH_SYNCTYPE_VOICE) {
+        const int active = (int) s[DS_ACTIVE_SLOT];
+        if (((slot + 1) & (int) s[DS_SLOT_FILTER]) && (active == -1 || active == slot)) {
+            s[DS_ACTIVE_SLOT] = (uint32_t) slot;
+            if (c.P->out_cap - c.nout < 27) c.overflow = true; else R.voice_out = true;
+        }
+    } else {
+        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+        if (st == DH_SYNCTYPE_DATA) {
+            uint32_t slot_type = (dh_syms_msb(p, 61, 5) << 10) | dh_syms_msb(p, 90, 5);   // :236-245
+            if (dh_block_decode(T.g208, T.lut_g208, slot_type)) {
+                uint8_t cc = (uint8_t) ((slot_type >> 16) & 15u);
+                R.data_type = (uint8_t) ((slot_type >> 12) & 15u);
+                dh_emit(c, DH_EV_DMR_SLOTTYPE, (uint8_t) slot, R.data_type, &cc, 1);
+                if (R.data_type != 8) R.want_bptc = true;               // rate 3/4 data is not decoded (:251-253)
+            }
+        } else {
+            dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
+        }
+    }
+    return R;
+}
+
+// position (symbol index in the burst) of info dibit d (0..97) of a data burst (:256-269)
+DH_HD int dh_dmr_info_dibit_pos(int d) { return d < 49 ? 12 + d : 12 + 54 + 24 + 5 + (d - 49); }
+// position of voice payload dibit d (0..107) (:215-225)
+DH_HD int dh_dmr_voice_dibit_pos(int d) { return d < 54 ? 12 + d : 12 + 54 + 24 + (d - 54); }
+
+// ------------------------------------------------------------------------------------------
+struct DhDecShared {
+    uint8_t  carry[DH_SYM_CARRY_MAX];
+    uint32_t state[DH_DEC_STATE_WORDS];   // wave-uniform working copy of the channel state
+    DhPlanes planes;                      // bit planes of the current frame (wave-uniform; LDS broadcast reads)
+    uint32_t colword[16];
+    uint32_t vit_metric[2][64];
+    uint64_t vit_dec[192];
+    uint8_t  vit_in[4][48];           // up to 4 concurrent codewords, dibits packed 4/byte
+    uint8_t  vit_out[4][24];
+    uint8_t  vit_best_metric[4];
+};
+
+// virtual symbol stream of a channel for this push: carried symbols, then the fresh ones
+struct DhSymView { const uint8_t* carry; uint32_t nc; const uint8_t* fresh; };
+DH_HD uint32_t dh_view_at(const DhSymView& v, uint32_t j) { return j < v.nc ? v.carry[j] : v.fresh[j - v.nc]; }
+
+DH_HD void dh_load_planes(const DhSymView& syms, uint32_t pos, uint32_t total, DhPlanes& pl, int nwords) {
+    for (int w = 0; w < DH_PLANE_WORDS; w++) { pl.h[w] = 0; pl.l[w] = 0; }
+    for (int w = 0; w < nwords; w++) {
+        uint64_t mh = 0, ml = 0;
+        DH_FOR_LANES(lane) {
+            const uint32_t j = pos + (uint32_t) (w * 64 + lane);
+            const uint32_t v = j < total ? dh_view_at(syms, j) : 0u;
+            DH_BALLOT_ACC(mh, (v >> 1) & 1u, lane);
+            DH_BALLOT_ACC(ml, v & 1u, lane);
+        }
+        pl.h[w] = mh; pl.l[w] = ml;
+    }
+}
+
+// BPTC(196,96) of a data burst, columns on lanes (bptc_196_96.c:5-59 on the dibits of dmr_phase.cpp:256-269)
+DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared& S, uint8_t* out12) {
+    uint64_t okmask = 0;
+    DH_FOR_LANES(lane) {
+        bool ok = true;
+        uint32_t w = 0;
+        if (lane < 15) {
+            const int d_lane = (lane * 181) % 196;
+            for (int k = 0; k < 13; k++) {
+                int r = ((k * 15 + 1) * 181) % 196 + d_lane;        // ((k*15 + lane + 1) * 181) mod 196
+                if (r >= 196) r -= 196;
+                const int pos = dh_dmr_info_dibit_pos(r >> 1);
+                const uint64_t* plane = (r & 1) ? p.l : p.h;        // even bit of a dibit = its bit1
+                w |= (uint32_t) ((plane[pos >> 6] >> (pos & 63)) & 1ull) << (12 - k);
+            }
+            ok = dh_block_decode(T.h139, T.lut_h139, w);
+        }
+        DH_BALLOT_ACC(okmask, ok, lane);
+        if (lane < 15) S.colword[lane] = w;
+    }
+    DH_BARRIER();
+    if (okmask != ~0ull) return false;
+    bool ok = true;
+    uint32_t rows[9];
+    for (int i = 0; i < 9; i++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 15; k++) w |= ((S.colword[k] >> (12 - i)) & 1u) << (14 - k);
+        ok &= dh_block_decode(T.h1511, T.lut_h1511, w);
+        rows[i] = w;
+    }
+    DH_BARRIER();
+    if (!ok) return false;
+    uint64_t acc = 0; int nacc = 0, ob = 0;
+    for (int r = 0; r < 9; r++) {
+        const int nb = r == 0 ? 8 : 11;
+        acc = (acc << nb) | ((rows[r] >> 4) & ((1u << nb) - 1)); nacc += nb;
+        while (nacc >= 8) { out12[ob++] = (uint8_t) (acc >> (nacc - 8)); nacc -= 8; }
+    }
+    return true;
+}
+
+// One DMR channel, one push.
+DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+    DhDecCtx c;
+    c.P = &P;
+    c.st = P.state + (size_t) ch * P.state_stride;
+    c.out = P.out + (size_t) ch * P.out_stride;
+    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
+    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.consumed = c.st[DS_CONSUMED];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    c.writer = threadIdx.x == 0;
+#else
+    c.writer = true;
+#endif
+    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
+    DhSymView syms; syms.carry = carry_buf; syms.nc = c.st[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    const uint32_t total = syms.nc + P.sym_count[ch];
+    uint32_t pos = 0;
+    uint32_t phase = c.st[DS_PHASE];
+    // the state words are wave-uniform working copies; lane 0 stores them back at the end
+    uint32_t* const s = S.state;       // every lane stores the same values: no barrier needed for its own reads
+    for (int i = 0; i < DH_DEC_STATE_WORDS; i++) s[i] = c.st[i];
+    uint32_t* const st_global = c.st;
+    c.st = s;
+
+    for (;;) {
+        const uint32_t avail = total - pos;
+        DhPlanes& pl = S.planes;
+        if (phase == 0) {                                              // SyncPhase (dmr_phase.cpp:35-47)
+            if (!(avail > 90)) break;
+            dh_load_planes(syms, pos, total, pl, 3);
+            uint64_t hits = 0;
+            DH_FOR_LANES(lane) {
+                const bool valid = avail - (uint32_t) lane > 90 && avail > (uint32_t) lane;
+                const bool hit = valid && dh_dmr_sync_type(pl, 66 + lane) > 0;
+                DH_BALLOT_ACC(hits, hit, lane);
+            }
+            if (hits) {
+                const uint32_t l = (uint32_t) dh_ffs64(hits);
+                pos += l; c.consumed += l;
+                phase = 1; dh_dmr_enter_frame_phase(s);
+            } else {
+                const uint32_t adv = dh_min<uint32_t>(64u, avail - 90u);
+                pos += adv; c.consumed += adv;
+            }
+        } else {                                                       // FramePhase (dmr_phase.cpp:61-302)
+            if (!(avail > 144)) break;
+            dh_load_planes(syms, pos, total, pl, 3);
+            const DhDmrFrameResult R = dh_dmr_frame_head(c, pl);
+            if (R.to_sync) { phase = 0; continue; }
+            if (R.voice_out) {
+                uint8_t* o = c.out + c.nout;
+                DH_FOR_LANES(lane) {
+                    if (lane < 27) {
+                        uint32_t v = 0;
+                        for (int i = 0; i < 4; i++) v = (v << 2) | dh_sym_at(pl, dh_dmr_voice_dibit_pos(lane * 4 + i));
+                        o[lane] = (uint8_t) v;
+                    }
+                }
+                c.nout += 27;
+            }
+            if (R.want_bptc) {
+                uint8_t lc[12];
+                for (int i = 0; i < 12; i++) lc[i] = 0;
+                const int slot = (int) s[DS_SLOT];
+                if (dh_dmr_bptc_wave(*P.T, pl, S, lc)) {
+                    dh_emit(c, DH_EV_DMR_BPTC, (uint8_t) slot, R.data_type, lc, 12);
+                    if (R.data_type == 1) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 0, lc, 9);
+                    else if (R.data_type == 2 || R.data_type == 9) dh_emit(c, DH_EV_DMR_SOFT_RESET, (uint8_t) slot, R.data_type, nullptr, 0);
+                }
+            }
+            pos += 144; c.consumed += 144;
+        }
+        if (c.overflow) break;
+    }
+
+    // carry the unread symbols to the front of the buffer
+    const uint32_t rem = total - pos;
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) S.carry[j] = (uint8_t) dh_view_at(syms, pos + j);
+    }
+    DH_BARRIER();
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = S.carry[j];
+        if (DH_IS_LANE0(lane)) {
+            s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+            s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+            for (int i = 0; i < DH_DEC_STATE_WORDS; i++) st_global[i] = s[i];
+            P.out_count[ch] = c.nout;
+            if (P.ev_count) P.ev_count[ch] = c.nev;
+            if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
+        }
+    }
+    DH_BARRIER();
+}
+
+// =============================================================================================
+// YSF
+// =============================================================================================
+
+// rate-1/2 K=5 Viterbi for up to four codewords at once: codeword g on lanes 16g..16g+15, one
+// trellis state per lane.  Same decisions as the reference's register-exchange decoder
+// (src/ysf_decoder/trellis.c:32-109): uint8 path metrics starting at 0 in every state, the k = 0
+// predecessor wins ties, the best final state is the lowest index among the minimum metric;
+// survivors are recovered by trace-back over the stored decision votes instead of copying
+// sixteen bit strings per step.
+DH_HD void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4], multiples of 4 not required*/) {
+    int steps = 0;
+    for (int g = 0; g < 4; g++) steps = sizes[g] > steps ? sizes[g] : steps;
+    DH_FOR_LANES(lane) { S.vit_metric[0][lane] = 0; }
+    DH_BARRIER();
+    for (int pos = 0; pos < steps; pos++) {
+        const int cur = pos & 1;
+        uint64_t dec = 0;
+        DH_FOR_LANES(lane) {
+            const int g = lane >> 4, i = lane & 15;
+            bool sel = false;
+            uint32_t nm = S.vit_metric[cur][lane];
+            if (pos < sizes[g]) {
+                const uint32_t in = ((uint32_t) S.vit_in[g][pos >> 2] >> (2 * (3 - (pos & 3)))) & 3u;
+                const uint32_t outbit = (uint32_t) i >> 3;
+                const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
+                const uint32_t m0 = (S.vit_metric[cur][g * 16 + p0] + (uint32_t) dh_popc32(in ^ dh_trellis_out(p0, outbit))) & 0xFFu;
+                const uint32_t m1 = (S.vit_metric[cur][g * 16 + p1] + (uint32_t) dh_popc32(in ^ dh_trellis_out(p1, outbit))) & 0xFFu;
+                sel = m1 < m0;
+                nm = sel ? m1 : m0;
+            }
+            S.vit_metric[cur ^ 1][lane] = nm;
+            DH_BALLOT_ACC(dec, sel, lane);
+        }
+        S.vit_dec[pos] = dec;
+        DH_BARRIER();
+    }
+    const int fin = steps & 1;
+    DH_FOR_LANES(lane) {
+        if ((lane & 15) == 0) {
+            const int g = lane >> 4;
+            const int size = sizes[g];
+            if (size > 0) {
+                uint32_t best = 0, bm = S.vit_metric[fin][g * 16];
+                for (uint32_t i = 1; i < 16; i++) {
+                    const uint32_t m = S.vit_metric[fin][g * 16 + i];
+                    if (m < bm) { bm = m; best = i; }
+                }
+                S.vit_best_metric[g] = (uint8_t) bm;
+                for (int b = 0; b < 24; b++) S.vit_out[g][b] = 0;
+                uint32_t state = best;
+                for (int pos = size - 1; pos >= 0; pos--) {
+                    S.vit_out[g][pos >> 3] |= (uint8_t) ((state >> 3) << (7 - (pos & 7)));
+                    const uint32_t k = (uint32_t) ((S.vit_dec[pos] >> (g * 16 + state)) & 1ull);
+                    state = ((state << 1) & 0xEu) | k;
+                }
+            }
+        }
+    }
+    DH_BARRIER();
+}
+
+// note: when sizes differ, a shorter codeword's metrics simply stop updating (they are copied
+// forward), so `fin` indexes the right buffer for every group.
+
+// PN9 whitening sequence (whitening.c:6-22), packed: bits first..first+63, bit (first+j) in bit j
+constexpr uint64_t dh_pn9_word(int first) {      // bits first..first+63, bit (first+j) in bit j
+    uint32_t wsr = 0x1C9u;
+    uint64_t r = 0;
+    for (int k = 0; k < first + 64; k++) {
+        const uint32_t wb = wsr & 1u;
+        const uint32_t fb = ((wsr >> 4) & 1u) ^ wb;
+        wsr = ((wsr & 0x1FEu) >> 1) | (fb << 8);
+        if (k >= first) r |= (uint64_t) wb << (k - first);
+    }
+    return r;
+}
+
+// AMBE bit order of the V/D type 2 voice channel (ysf_phase.hpp:46-51): voice bit ib -> output bit.
+// The table is three arithmetic runs (step 3 up to 39/40/38, then step 2), stated here in closed form.
+constexpr int dh_v2_forward(int ib) {
+    return ib < 18 ? (ib < 14 ? 3 * ib : 39 + 2 * (ib - 13))
+         : ib < 36 ? ((ib - 18) < 14 ? 1 + 3 * (ib - 18) : 40 + 2 * (ib - 18 - 13))
+                   : 2 + 3 * (ib - 36);
+}
+// its inverse: output bit -> voice bit
+constexpr int dh_v2_inverse(int ob) {
+    return ob <= 40 ? (ob % 3 == 0 ? ob / 3 : ob % 3 == 1 ? 18 + ob / 3 : 36 + ob / 3)
+                    : ((ob & 1) ? 14 + (ob - 41) / 2 : 32 + (ob - 42) / 2);
+}
+constexpr bool dh_v2_check() {
+    for (int ib = 0; ib < 49; ib++) if (dh_v2_inverse(dh_v2_forward(ib)) != ib) return false;
+    return dh_v2_forward(13) == 39 && dh_v2_forward(17) == 47 && dh_v2_forward(18) == 1 && dh_v2_forward(35) == 48 &&
+           dh_v2_forward(36) == 2 && dh_v2_forward(48) == 38;
+}
+static_assert(dh_v2_check(), "v2 voice mapping closed form");
+
+// whitened/interleaved VCH bit k (0..103) of the 52-dibit voice block at symbol `base`
+DH_HD uint32_t dh_ysf_vch_bit(const DhPlanes& p, int base, int k) {
+    const int t = (k * 4) % 104 + (k * 4) / 104;           // 26 x 4 de-interleave (ysf_phase.cpp:188-197)
+    const int pos = base + (t >> 1);
+    const uint64_t* plane = (t & 1) ? p.l : p.h;
+    constexpr uint64_t PN0 = dh_pn9_word(0), PN1 = dh_pn9_word(64);
+    const uint64_t pn = k < 64 ? PN0 : PN1;
+    const uint32_t wb = (uint32_t) ((pn >> (k & 63)) & 1ull);
+    return (uint32_t) ((plane[pos >> 6] >> (pos & 63)) & 1ull) ^ wb;
+}
+
+// one output byte (0..6) of decodeV2VoicePayload (ysf_phase.cpp:180-256)
+DH_HD uint8_t dh_ysf_v2_voice_byte(const DhPlanes& p, int base, int byte) {
+    uint32_t v = 0;
+    for (int b = 0; b < 8; b++) {
+        const int ob = byte * 8 + b;
+        uint32_t bit = 0;
+        if (ob < 49) {
+            const int ib = dh_v2_inverse(ob);          // the voice bit the mapping sends to output bit `ob`
+            if (ib < 27) {
+                const uint32_t t = dh_ysf_vch_bit(p, base, 3 * ib) + dh_ysf_vch_bit(p, base, 3 * ib + 1) + dh_ysf_vch_bit(p, base, 3 * ib + 2);
+                bit = t >= 2 ? 1u : 0u;                     // tribit majority (ysf_phase.hpp:45)
+            } else {
+                bit = dh_ysf_vch_bit(p, base, 81 + (ib - 27));
+            }
+        }
+        v = (v << 1) | bit;
+    }
+    return (uint8_t) v;
+}
+
+DH_HD void dh_ysf_enter_frame_phase(uint32_t* s) {
+    s[DS_SYNC_COUNT] = 0; s[DS_HAS_FICH] = 0; s[DS_FICH] = 0; s[DS_EXPECT_SUB] = 0;
+}
+
+DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.cpp:16-18
+    constexpr uint32_t YH = DH_YSF_SYNC_H, YL = DH_YSF_SYNC_L;
+    return dh_popc32(dh_plane_range(p.h, start, 20) ^ YH) + dh_popc32(dh_plane_range(p.l, start, 20) ^ YL) <= 3;
+}
+
+// One YSF channel, one push.
+DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+    const DhFecTables& T = *P.T;
+    DhDecCtx c;
+    c.P = &P;
+    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
+    c.out = P.out + (size_t) ch * P.out_stride;
+    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
+    c.nout = 0; c.nev = 0; c.overflow = false;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    c.writer = threadIdx.x == 0;
+#else
+    c.writer = true;
+#endif
+    uint32_t* const s = S.state;
+    for (int i = 0; i < DH_DEC_STATE_WORDS; i++) s[i] = st_global[i];
+    c.st = s;
+    c.consumed = s[DS_CONSUMED];
+    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
+    DhSymView syms; syms.carry = carry_buf; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    const uint32_t total = syms.nc + P.sym_count[ch];
+    uint32_t pos = 0, phase = s[DS_PHASE];
+
+    for (;;) {
+        const uint32_t avail = total - pos;
+        DhPlanes& pl = S.planes;
+        if (phase == 0) {                                          // SyncPhase (ysf_phase.cpp:20-34)
+            if (!(avail > 20)) break;
+            dh_load_planes(syms, pos, total, pl, 2);
+            uint64_t hits = 0;
+            DH_FOR_LANES(lane) {
+                const bool valid = avail > (uint32_t) lane && avail - (uint32_t) lane > 20;
+                DH_BALLOT_ACC(hits, valid && dh_ysf_is_sync(pl, lane), lane);
+            }
+            if (hits) {
+                const uint32_t l = (uint32_t) dh_ffs64(hits);
+                pos += l; c.consumed += l; phase = 1; dh_ysf_enter_frame_phase(s);
+            } else {
+                const uint32_t adv = dh_min<uint32_t>(64u, avail - 20u);
+                pos += adv; c.consumed += adv;
+            }
+            continue;
+        }
+        // FramePhase (ysf_phase.cpp:41-172)
+        if (!(avail > 480)) break;
+        dh_load_planes(syms, pos, total, pl, 8);
+        int sync_count = (int) s[DS_SYNC_COUNT];
+        if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
+        else if (--sync_count < 0) {
+            dh_emit(c, DH_EV_YSF_META_RESET, 0, 0, nullptr, 0);
+            phase = 0; continue;
+        }
+        s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+
+        // gather the four convolutional codewords of this frame (FICH, V/D2 DCH, header CSD1/CSD2)
+        DH_FOR_LANES(lane) {
+            if (lane < 25) {
+                uint32_t f = 0, d = 0;
+                for (int q = 0; q < 4; q++) {
+                    const int i = lane * 4 + q;
+                    f = (f << 2) | dh_sym_at(pl, 20 + (i * 20) % 100 + (i * 20) / 100);      // fich.cpp:16-19
+                    d = (d << 2) | dh_sym_at(pl, 120 + (i % 5) * 72 + (i * 2) / 10);         // ysf_phase.cpp:103-106
+                }
+                S.vit_in[0][lane] = (uint8_t) f; S.vit_in[1][lane] = (uint8_t) d;
+            }
+            if (lane < 45) {
+                uint32_t a = 0, b = 0;
+                for (int q = 0; q < 4; q++) {
+                    const int i = lane * 4 + q;
+                    const int streampos = (i % 9) * 20 + i / 9;                               // ysf_phase.cpp:323-333
+                    const int inpos = 120 + (streampos / 36) * 72 + streampos % 36;
+                    a = (a << 2) | dh_sym_at(pl, inpos);
+                    b = (b << 2) | dh_sym_at(pl, inpos + 36);
+                }
+                S.vit_in[2][lane] = (uint8_t) a; S.vit_in[3][lane] = (uint8_t) b;
+            }
+        }
+        DH_BARRIER();
+        // which codewords can matter: the header pair only if the (possibly stale) running FICH or the
+        // fresh one says "header"; we do not know the fresh FICH yet, so decode speculatively.
+        const int sizes[4] = { 100, 100, 180, 180 };
+        dh_viterbi_wave(S, sizes);
+
+        // FICH: 4 x Golay(24,12) + CRC16 (fich.cpp:24-49)
+        uint32_t fich = 0; bool fresh = true;
+        {
+            uint32_t g[4];
+            for (int i = 0; i < 4; i++) {
+                g[i] = (uint32_t) S.vit_out[0][i * 3] << 16 | (uint32_t) S.vit_out[0][i * 3 + 1] << 8 | S.vit_out[0][i * 3 + 2];
+                fresh &= dh_block_decode(T.g2412, T.lut_g2412, g[i]);
+            }
+            if (fresh) {
+                fich = (g[0] & 0x00FFF000u) << 8 | (g[1] & 0x00FFF000u) >> 4 | (g[2] & 0x00FF0000u) >> 16;
+                const uint32_t checksum = (g[2] & 0x0000F000u) | (g[3] & 0x00FFF000u) >> 12;
+                const uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };
+                fresh = dh_crc16(be, 4) == checksum;
+                if (fresh) {
+                    s[DS_FICH] = fich; s[DS_HAS_FICH] = 1;
+                    dh_emit(c, DH_EV_YSF_FICH, 0, 0, be, 4);
+                }
+            }
+        }
+
+        if (s[DS_HAS_FICH]) {
+            const uint32_t rf = s[DS_FICH];
+            const uint32_t frame_type = (rf >> 30) & 3u, data_type = (rf >> 8) & 3u;
+            if (frame_type == 1) {                                                  // communication channel
+                dh_emit(c, DH_EV_YSF_MODE, 0, (uint8_t) data_type, nullptr, 0);
+                if (data_type == 0) {                                               // V/D mode 1 (:73-84)
+                    if (P.out_cap - c.nout < 50) c.overflow = true;
+                    else {
+                        uint8_t* o = c.out + c.nout;
+                        DH_FOR_LANES(lane) {
+                            if (lane < 50) {
+                                const int blk = lane / 10, j = lane % 10;
+                                // `=` instead of `|=` at ysf_phase.cpp:176: only dibit 4j+3 survives, unshifted
+                                o[lane] = j == 0 ? (uint8_t) data_type : (uint8_t) dh_sym_at(pl, 120 + 36 + blk * 72 + 4 * (j - 1) + 3);
+                            }
+                        }
+                        c.nout += 50;
+                    }
+                } else if (data_type == 2) {                                        // V/D mode 2 (:85-110)
+                    if (P.out_cap - c.nout < 40) c.overflow = true;
+                    else {
+                        uint8_t* o = c.out + c.nout;
+                        DH_FOR_LANES(lane) {
+                            if (lane < 40) {
+                                const int blk = lane >> 3, j = lane & 7;
+                                o[lane] = j == 0 ? (uint8_t) data_type : dh_ysf_v2_voice_byte(pl, 120 + 20 + blk * 72, j - 1);
+                            }
+                        }
+                        c.nout += 40;
+                    }
+                    if (fresh) {                                                    // decodeV2DataChannel (:258-269)
+                        const uint8_t* w = S.vit_out[1];
+                        const uint32_t checksum = (uint32_t) w[10] << 8 | w[11];
+                        if (dh_crc16(w, 10) == checksum) {
+                            uint8_t dch[13];
+                            dh_whiten(w, dch, 100);
+                            dh_emit(c, DH_EV_YSF_DCH, (uint8_t) ((fich >> 19) & 7u), 0, dch, 10);
+                        }
+                    }
+                } else if (data_type == 3) {                                        // voice full rate (:111-130)
+                    const int start_frame = s[DS_EXPECT_SUB] ? 3 : 0;
+                    s[DS_EXPECT_SUB] = 0;
+                    const uint32_t nbytes = (uint32_t) (5 - start_frame) * 19u;
+                    if (P.out_cap - c.nout < nbytes) c.overflow = true;
+                    else {
+                        uint8_t* o = c.out + c.nout;
+                        DH_FOR_LANES(lane) {
+                            for (uint32_t e = lane; e < nbytes; e += DH_WAVE) {
+                                const int blk = start_frame + (int) (e / 19u), j = (int) (e % 19u);
+                                uint32_t v = data_type;
+                                if (j > 0) {
+                                    v = 0;
+                                    for (int q = 0; q < 4; q++) v = (v << 2) | dh_sym_at(pl, 120 + blk * 72 + (j - 1) * 4 + q);
+                                }
+                                o[e] = (uint8_t) v;
+                            }
+                        }
+                        c.nout += nbytes;
+                    }
+                }
+            } else if (frame_type == 0) {                                           // header (:139-161)
+                dh_emit(c, DH_EV_YSF_META_RESET, 0, 1, nullptr, 0);
+                for (int half = 0; half < 2; half++) {
+                    const uint8_t* w = S.vit_out[2 + half];
+                    const uint32_t checksum = (uint32_t) w[20] << 8 | w[21];
+                    if (dh_crc16(w, 20) == checksum) {
+                        uint8_t dch[20];
+                        dh_whiten(w, dch, 160);
+                        dh_emit(c, DH_EV_YSF_HEADER_DCH, (uint8_t) half, 0, dch, 20);
+                    }
+                }
+                s[DS_EXPECT_SUB] = 1;
+            } else if (frame_type == 2) {                                           // terminator (:162-164)
+                dh_emit(c, DH_EV_YSF_META_RESET, 0, 2, nullptr, 0);
+            }
+        }
+        DH_BARRIER();
+        pos += 480; c.consumed += 480;
+        if (c.overflow) break;
+    }
+
+    const uint32_t rem = total - pos;
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) S.carry[j] = (uint8_t) dh_view_at(syms, pos + j);
+    }
+    DH_BARRIER();
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = S.carry[j];
+        if (DH_IS_LANE0(lane)) {
+            s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+            s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+            for (int i = 0; i < DH_DEC_STATE_WORDS; i++) st_global[i] = s[i];
+            P.out_count[ch] = c.nout;
+            if (P.ev_count) P.ev_count[ch] = c.nev;
+            if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
+        }
+    }
+    DH_BARRIER();
+}

@@ -1,0 +1,83 @@
+// dh_portable.hpp -- how the kernel bodies are written.
+//
+// Every kernel in this library is "one channel (or one small group of codewords) per
+// 64-lane wavefront", one wavefront per workgroup.  The bodies are written as a sequence of
+// PHASES: inside a phase each lane works independently (DH_FOR_LANES), between phases the
+// lanes exchange data through the workgroup's LDS block and meet at DH_BARRIER().  Wave-wide
+// votes use DH_BALLOT_ACC.  Loop control between phases only uses wave-uniform values.
+//
+// When hipcc compiles this for gfx950, DH_FOR_LANES binds `lane` to threadIdx.x, DH_BARRIER is
+// s_barrier (free for a single-wave workgroup apart from the LDS wait) and DH_BALLOT_ACC is
+// v_cmp + s_mov of the EXEC-wide vote.  When a plain C++ compiler builds the *test harness*
+// (tests/host_harness), the same phases run as `for (lane = 0..63)` loops, which lets the
+// CPU-only test tier execute the exact wave algorithm (index maths, carries, block-parallel
+// timing recovery) against the oracle without a GPU.  The shipped library contains only the
+// gfx950 build; there is no CPU fallback in the product.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define DH_DEVICE_BUILD 1
+#define DH_HD __host__ __device__ __forceinline__
+#define DH_D __device__ __forceinline__
+#else
+#define DH_DEVICE_BUILD 0
+#define DH_HD inline
+#define DH_D inline
+#endif
+
+#define DH_WAVE 64
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_FOR_LANES(lane) for (int lane = (int) threadIdx.x, dh_once_ = 1; dh_once_; dh_once_ = 0)
+#define DH_BARRIER() __syncthreads()
+#define DH_BALLOT_ACC(mask, pred, lane) (mask) = __ballot((pred) ? 1 : 0)
+#define DH_IS_LANE0(lane) ((lane) == 0)
+#else
+#define DH_FOR_LANES(lane) for (int lane = 0; lane < DH_WAVE; ++lane)
+#define DH_BARRIER() ((void) 0)
+#define DH_BALLOT_ACC(mask, pred, lane) (mask) |= ((uint64_t) ((pred) ? 1 : 0) << (lane))
+#define DH_IS_LANE0(lane) ((lane) == 0)
+#endif
+
+DH_HD int dh_popc32(uint32_t x) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+
+DH_HD int dh_popc64(uint64_t x) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+
+DH_HD uint32_t dh_brev32(uint32_t x) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+
+DH_HD int dh_ffs64(uint64_t x) {   // index of lowest set bit, x != 0
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((unsigned long long) x) - 1;
+#else
+    return __builtin_ctzll(x);
+#endif
+}
+
+template <typename T> DH_HD T dh_min(T a, T b) { return a < b ? a : b; }
+template <typename T> DH_HD T dh_max(T a, T b) { return a > b ? a : b; }

@@ -1,0 +1,321 @@
+// engine.hip -- gfx950 kernels + HIP backend of the engine; builds libdigiham_amd.so.
+//
+// Launch geometry: every streaming kernel is ONE 64-lane wavefront per workgroup, one channel per
+// wavefront (grid = n_channels, or channels x tiles for the stand-alone RRC).  Channels share no
+// data, so the workgroup -> XCD round-robin of the dispatcher needs no remapping: each XCD's L2
+// only ever holds its own channels' rows, and 16 384-channel grids give 64 workgroups per CU.
+// Batch FEC kernels are one item per lane, 256-lane workgroups, grid-stride.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+// (no FMA contraction anywhere: products and sums of the exact paths round separately, as the
+// reference's x86-64 SSE2 build does; the FAST FIR asks for fmaf explicitly).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/digiham_amd.h"
+#include "kernels_core.hpp"
+#include "fec_tables.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return -1;
+}
+#define HIP_TRY(expr) do { if (hip_fail((expr), #expr)) return DH_EDEVICE; } while (0)
+
+// ---------------------------------------------------------------------------------- kernels
+template <int NZ, bool FAST>
+__global__ __launch_bounds__(DH_WAVE) void k_rrc_demod(const DhDspParams P) {
+    extern __shared__ __attribute__((aligned(16))) char dh_smem[];
+    DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
+    dh_rrc_demod_channel<NZ, FAST>(P, blockIdx.x, S);
+}
+
+template <int NZ, bool FAST>
+__global__ __launch_bounds__(DH_WAVE) void k_rrc_tile(const DhRrcParams R) {
+    extern __shared__ __attribute__((aligned(16))) char dh_smem[];
+    DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
+    dh_rrc_tile<NZ, FAST>(R, blockIdx.y, blockIdx.x, S);
+}
+
+__global__ __launch_bounds__(DH_WAVE) void k_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz) {
+    __shared__ float sh[DH_MAX_NZ];
+    dh_rrc_hist_channel(hist, in, in_stride, n, nz, blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(DH_WAVE) void k_dmr(const DhDecParams P) {
+    __shared__ DhDecShared S;
+    dh_dmr_channel(P, blockIdx.x, S);
+}
+
+__global__ __launch_bounds__(DH_WAVE) void k_ysf(const DhDecParams P) {
+    __shared__ DhDecShared S;
+    dh_ysf_channel(P, blockIdx.x, S);
+}
+
+__global__ void k_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < B) dh_init_state_channel(dsp_state, state_words, tail0, dec_state, slot_filter, ch);
+}
+
+__global__ void k_set_slot_filter(uint32_t* dec_state, uint32_t filter, uint32_t B) {
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < B) dh_set_slot_filter_channel(dec_state, filter, ch);
+}
+
+__global__ void k_fec_block(const DhFecTables* T, int code, void* words, uint8_t* ok, size_t n) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        dh_fec_block_item(*T, code, words, ok, i);
+}
+
+// Golay: syndrome LUT (16 KiB) staged in LDS once per workgroup, then grid-stride over the words
+__global__ __launch_bounds__(256) void k_golay(const DhFecTables* T, int which, uint32_t* words, uint8_t* ok, size_t n) {
+    __shared__ uint32_t lut[4096];
+    __shared__ DhCode code;
+    const uint32_t* src = which ? T->lut_g2412 : T->lut_g208;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lut[i] = src[i];
+    if (threadIdx.x == 0) code = which ? T->g2412 : T->g208;
+    __syncthreads();
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        uint32_t w = words[i];
+        const bool r = dh_block_decode(code, lut, w);
+        words[i] = w;
+        ok[i] = r ? 1 : 0;
+    }
+}
+
+__global__ void k_bptc(const DhFecTables* T, const uint8_t* in, uint8_t* out, uint8_t* ok, size_t n) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        dh_bptc_item(*T, in, out, ok, i);
+}
+
+__global__ __launch_bounds__(DH_WAVE) void k_trellis(const uint8_t* in, size_t in_stride, int n_dibits, uint8_t* out, size_t out_stride,
+                                                     uint8_t* metric, size_t n) {
+    __shared__ DhDecShared S;
+    dh_trellis_wave(in, in_stride, n_dibits, out, out_stride, metric, n, blockIdx.x, S);
+}
+
+__global__ void k_crc16(const uint8_t* in, size_t stride, int count, uint16_t* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        dh_crc16_item(in, stride, count, out, i);
+}
+
+__global__ void k_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n_bits, size_t n) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        dh_whitening_item(in, out, stride, n_bits, i);
+}
+
+__global__ void k_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n) {
+    const size_t ch = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (ch < B) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
+}
+
+inline unsigned grid_for(size_t n, unsigned block) {
+    const size_t g = (n + block - 1) / block;
+    return (unsigned) (g < 1 ? 1 : (g > 8192 ? 8192 : g));      // 256 CUs x 32 resident workgroups, grid-stride beyond
+}
+
+// ---------------------------------------------------------------------------------- FEC tables
+std::mutex g_tables_mutex;
+DhFecTables* g_tables[64] = { nullptr };
+
+int tables_for_current_device(const DhFecTables** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return DH_EINVAL;
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    if (!g_tables[dev]) {
+        DhFecTables* host = new (std::nothrow) DhFecTables;
+        if (!host) return DH_ENOMEM;
+        dh::build_fec_tables(*host);
+        DhFecTables* d = nullptr;
+        if (hip_fail(hipMalloc((void**) &d, sizeof(DhFecTables)), "hipMalloc(tables)")) { delete host; return DH_ENOMEM; }
+        const hipError_t e = hipMemcpy(d, host, sizeof(DhFecTables), hipMemcpyHostToDevice);
+        delete host;
+        if (hip_fail(e, "hipMemcpy(tables)")) { (void) hipFree(d); return DH_EDEVICE; }
+        g_tables[dev] = d;
+    }
+    *out = g_tables[dev];
+    return DH_OK;
+}
+
+// ---------------------------------------------------------------------------------- backend
+struct HipBackend {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    int open(int dev, void* s) {
+        int count = 0;
+        if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) return DH_ENODEV;
+        if (dev < 0 || dev >= count) return DH_EINVAL;
+        device = dev; stream = (hipStream_t) s;
+        HIP_TRY(hipSetDevice(device));
+        return DH_OK;
+    }
+    void* alloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipSetDevice(device) != hipSuccess) return nullptr;
+        if (hip_fail(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc")) return nullptr;
+        return p;
+    }
+    void free(void* p) { (void) hipFree(p); }
+    int zero(void* p, size_t bytes) { return hip_fail(hipMemsetAsync(p, 0, bytes, stream), "hipMemsetAsync"); }
+    int upload(void* dst, const void* src, size_t bytes) {
+        // pageable source: hipMemcpyAsync stages it before returning, so the caller may free `src`
+        return hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)");
+    }
+    int download(void* dst, const void* src, size_t bytes) {
+        if (hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)")) return -1;
+        return hip_fail(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    }
+    int sync() { return hip_fail(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    int launched(const char* what) { return hip_fail(hipGetLastError(), what); }
+
+    // per-push stage timestamps: 4 events per recorded push
+    std::vector<hipEvent_t> ev;
+    uint32_t ev_cap = 0, ev_n = 0;
+    int timing_enable(uint32_t max_pushes) {
+        for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+        ev.clear(); ev_cap = max_pushes; ev_n = 0;
+        ev.resize((size_t) max_pushes * 4);
+        for (auto& e : ev) if (hip_fail(hipEventCreate(&e), "hipEventCreate")) return DH_EDEVICE;
+        return DH_OK;
+    }
+    void timing_mark(int k) { if (ev_n < ev_cap) (void) hipEventRecord(ev[(size_t) ev_n * 4 + k], stream); }
+    void timing_next() { if (ev_n < ev_cap) ev_n++; }
+    int timing_read(float* rrc, float* slicer, float* decoder, uint32_t* n) {
+        if (sync()) return DH_EDEVICE;
+        const uint32_t cnt = ev_n < *n ? ev_n : *n;
+        for (uint32_t i = 0; i < cnt; i++) {
+            float a = 0, b = 0, c = 0;
+            HIP_TRY(hipEventElapsedTime(&a, ev[i * 4 + 0], ev[i * 4 + 1]));
+            HIP_TRY(hipEventElapsedTime(&b, ev[i * 4 + 1], ev[i * 4 + 2]));
+            HIP_TRY(hipEventElapsedTime(&c, ev[i * 4 + 2], ev[i * 4 + 3]));
+            if (rrc) rrc[i] = a;
+            if (slicer) slicer[i] = b;
+            if (decoder) decoder[i] = c;
+        }
+        *n = cnt; ev_n = 0;
+        return DH_OK;
+    }
+
+    template <int NZ, bool FAST> int go_rrc_demod(const DhDspParams& P) {
+        const size_t lds = dh_dsp_shared_bytes(P.sps);
+        if (lds > 48 * 1024) {
+            if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
+                         "hipFuncSetAttribute")) return -1;
+        }
+        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P);
+        return launched("k_rrc_demod");
+    }
+    int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
+        if (nz == 0) return go_rrc_demod<0, false>(P);
+        if (nz == 80) return fast ? go_rrc_demod<80, true>(P) : go_rrc_demod<80, false>(P);
+        if (nz == 160) return fast ? go_rrc_demod<160, true>(P) : go_rrc_demod<160, false>(P);
+        return -1;
+    }
+    template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {
+        const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
+        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3(tiles, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(1), stream, R);
+        return launched("k_rrc_tile");
+    }
+    int launch_rrc_tiles(const DhRrcParams& R, uint32_t nz, bool fast) {
+        if (nz == 80) return fast ? go_rrc_tiles<80, true>(R) : go_rrc_tiles<80, false>(R);
+        if (nz == 160) return fast ? go_rrc_tiles<160, true>(R) : go_rrc_tiles<160, false>(R);
+        return -1;
+    }
+    int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {
+        hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, stream, hist, in, in_stride, n, nz);
+        return launched("k_rrc_hist");
+    }
+    int launch_decoder(const DhDecParams& P, int proto) {
+        if (proto == DH_PROTO_DMR) hipLaunchKernelGGL(k_dmr, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
+        else hipLaunchKernelGGL(k_ysf, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
+        return launched("k_decoder");
+    }
+    int launch_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
+        hipLaunchKernelGGL(k_init_state, dim3((B + 255) / 256), dim3(256), 0, stream, dsp_state, state_words, tail0, dec_state, slot_filter, B);
+        return launched("k_init_state");
+    }
+    int launch_set_slot_filter(uint32_t* dec_state, uint32_t filter, uint32_t B) {
+        hipLaunchKernelGGL(k_set_slot_filter, dim3((B + 255) / 256), dim3(256), 0, stream, dec_state, filter, B);
+        return launched("k_set_slot_filter");
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- ABI hooks
+static int dh_be_device_count() {
+    int count = 0;
+    if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount")) return DH_ENODEV;
+    return count;
+}
+static const char* dh_be_last_error() { return g_last_error.c_str(); }
+static int dh_be_alloc(int device, size_t bytes, void** out) {
+    HIP_TRY(hipSetDevice(device));
+    if (hip_fail(hipMalloc(out, bytes ? bytes : 1), "hipMalloc")) return DH_ENOMEM;
+    return DH_OK;
+}
+static int dh_be_free(void* p) { HIP_TRY(hipFree(p)); return DH_OK; }
+static int dh_be_copy(void* dst, const void* src, size_t bytes, int to_host) {
+    if (!bytes) return DH_OK;
+    HIP_TRY(hipMemcpy(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
+    return DH_OK;
+}
+static int dh_be_fec_block(int code, void* words, uint8_t* ok, size_t n, void* stream) {
+    if (!n) return DH_OK;
+    if (!words || !ok) return DH_EINVAL;
+    const DhFecTables* T = nullptr;
+    int rc = tables_for_current_device(&T);
+    if (rc) return rc;
+    if (code == 5 || code == 6)
+        hipLaunchKernelGGL(k_golay, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t) stream, T, code == 6 ? 1 : 0, (uint32_t*) words, ok, n);
+    else
+        hipLaunchKernelGGL(k_fec_block, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, T, code, words, ok, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+static int dh_be_bptc(const uint8_t* in, uint8_t* out, uint8_t* ok, size_t n, void* stream) {
+    if (!n) return DH_OK;
+    const DhFecTables* T = nullptr;
+    int rc = tables_for_current_device(&T);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bptc, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, T, in, out, ok, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+static int dh_be_trellis(const uint8_t* in, size_t in_stride, int n_dibits, uint8_t* out, size_t out_stride, uint8_t* metric, size_t n, void* stream) {
+    if (!n) return DH_OK;
+    hipLaunchKernelGGL(k_trellis, dim3((unsigned) ((n + 3) / 4)), dim3(DH_WAVE), 0, (hipStream_t) stream, in, in_stride, n_dibits, out, out_stride, metric, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+static int dh_be_crc16(const uint8_t* in, size_t stride, int count, uint16_t* out, size_t n, void* stream) {
+    if (!n) return DH_OK;
+    hipLaunchKernelGGL(k_crc16, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, in, stride, count, out, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+static int dh_be_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n_bits, size_t n, void* stream) {
+    if (!n) return DH_OK;
+    hipLaunchKernelGGL(k_whitening, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, in, out, stride, n_bits, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n, void* stream) {
+    if (!B) return DH_OK;
+    hipLaunchKernelGGL(k_dvfilter, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, out, state, B, stride, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+
+#define DH_BACKEND HipBackend
+#include "abi_impl.hpp"

@@ -1,0 +1,253 @@
+// engine_impl.hpp -- the streaming engine behind the C ABI: buffer layout in HBM, per-push kernel
+// sequence, output views.  Written against a small backend interface so that the same
+// orchestration is exercised by the gfx950 build (engine.hip: HIP allocations + kernel launches)
+// and by the CPU-only test harness (tests/host_harness: malloc + lane loops).
+//
+// HBM layout per engine (B = n_channels, all channel-major, one contiguous row per channel):
+//   in            [B][stride] f32      caller's buffer (device-resident), read once per push
+//   dsp_state     [B][state_words] u32 slicer rings + timing state + raw tail (dsp_core.hpp)
+//   syms          [B][sym_stride] u8   this push's symbols (dibits)
+//   sym_carry     [B][512] u8          symbols the decoder left unread (< one frame)
+//   dec_state     [B][32] u32          decoder phase state (decoder_core.hpp)
+//   frames        [B][out_cap] u8      decoder output bytes of this push
+//   events        [B][ev_cap] dh_event decoder events of this push
+//   filtered      [B][max_samples] f32 only with DH_FLAG_KEEP_FILTERED (unfused path)
+//   rrc_hist      [B][nz] f32          only with DH_FLAG_KEEP_FILTERED
+#pragma once
+
+#include <string.h>
+#include <new>
+
+#include "../../include/digiham_amd.h"
+#include "dsp_core.hpp"
+#include "decoder_core.hpp"
+#include "fec_tables.hpp"
+#include "rrc_taps.h"
+
+namespace dh {
+
+struct Layout {
+    uint32_t B, max_samples, sps, nz, lo, hi;
+    int rrc, demod, proto;
+    uint32_t flags;
+    uint32_t sym_cap, out_cap, ev_cap;
+    size_t sym_stride, state_words;
+    bool fused;          // RRC folded into the slicer kernel (no filtered signal in HBM)
+};
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+inline int make_layout(const dh_engine_config& c, Layout& L) {
+    if (c.struct_size != sizeof(dh_engine_config)) return DH_EINVAL;
+    if (c.n_channels == 0 || c.max_samples == 0) return DH_EINVAL;
+    if (c.rrc < DH_RRC_NONE || c.rrc > DH_RRC_NARROW) return DH_EINVAL;
+    if (c.demod != DH_DEMOD_NONE && c.demod != DH_DEMOD_FSK2 && c.demod != DH_DEMOD_GFSK4) return DH_EINVAL;
+    if (c.proto < DH_PROTO_NONE || c.proto > DH_PROTO_YSF) return DH_EINVAL;
+    if (c.demod != DH_DEMOD_NONE && (c.sps < 3 || c.sps > DH_MAX_SPS)) return DH_EINVAL;
+    if (c.demod == DH_DEMOD_NONE && c.rrc == DH_RRC_NONE && c.proto == DH_PROTO_NONE) return DH_EINVAL;
+    L.B = c.n_channels; L.max_samples = c.max_samples; L.sps = c.demod ? c.sps : 1;
+    L.rrc = c.rrc; L.demod = c.demod; L.proto = c.proto; L.flags = c.flags;
+    L.nz = c.rrc == DH_RRC_WIDE ? DH_RRC_WIDE_NZEROS : c.rrc == DH_RRC_NARROW ? DH_RRC_NARROW_NZEROS : 0;
+    // GfskDemodulator ctor: lowestEval = round(sps/3), highestEval = round(2*sps/3)  (gfsk_demodulator.cpp:8-9)
+    L.lo = (uint32_t) (int) __builtin_roundf((float) L.sps / 3);
+    L.hi = (uint32_t) (int) __builtin_roundf((float) L.sps * 2 / 3);
+    L.fused = L.rrc != DH_RRC_NONE && L.demod != DH_DEMOD_NONE && !(L.flags & DH_FLAG_KEEP_FILTERED);
+    // a symbol consumes at least sps-1 samples
+    L.sym_cap = L.demod ? (L.max_samples + DH_TAIL_MAX) / (L.sps - 1) + 4 : L.max_samples;
+    L.sym_stride = round_up(L.sym_cap, 64);
+    L.state_words = round_up(dh_state_words(L.sps), 16);
+    const uint32_t max_syms = DH_SYM_CARRY_MAX + L.sym_cap;
+    if (L.proto == DH_PROTO_DMR) { L.out_cap = (max_syms / 144 + 1) * 27; L.ev_cap = (max_syms / 144 + 1) * 4 + 8; }
+    else if (L.proto == DH_PROTO_YSF) { L.out_cap = (max_syms / 480 + 1) * 95; L.ev_cap = (max_syms / 480 + 1) * 5 + 8; }
+    else { L.out_cap = 0; L.ev_cap = 0; }
+    L.out_cap = round_up(L.out_cap, 64);
+    return DH_OK;
+}
+
+inline void fill_taps(int rrc, float* half, double* gain) {
+    float full[DH_RRC_MAX_TAPS];
+    const int narrow = rrc == DH_RRC_NARROW;
+    dh_rrc_expand_taps(narrow, full);
+    const int nz = narrow ? DH_RRC_NARROW_NZEROS : DH_RRC_WIDE_NZEROS;
+    for (int i = 0; i <= nz / 2; i++) half[i] = full[i];
+    *gain = narrow ? DH_RRC_NARROW_GAIN : DH_RRC_WIDE_GAIN;
+}
+
+// Backend interface (duck-typed):
+//   void* alloc(size_t bytes); void free(void*);
+//   int zero(void* p, size_t bytes);                       // async on the engine stream
+//   int upload(void* dst, const void* src, size_t bytes);  // host -> device, async
+//   int download(void* dst, const void* src, size_t bytes);// device -> host, synchronous
+//   int sync();
+//   int launch_rrc_demod(const DhDspParams&, uint32_t nz, bool fast);
+//   int launch_rrc_tiles(const DhRrcParams&, uint32_t nz, bool fast);
+//   int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B);
+//   int launch_decoder(const DhDecParams&, int proto);
+//   int launch_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B);
+//   int launch_set_slot_filter(uint32_t* dec_state, uint32_t filter, uint32_t B);
+//   void timing_mark(int k); void timing_next();            // optional per-push stage timestamps (k = 0..3)
+//   int timing_enable(uint32_t max_pushes); int timing_read(float* rrc, float* slicer, float* decoder, uint32_t* n);
+template <class BE>
+struct Engine {
+    BE be;
+    Layout L;
+    uint32_t slot_filter;
+    // device buffers
+    uint32_t* dsp_state = nullptr;
+    uint8_t* syms = nullptr;
+    uint32_t* sym_count = nullptr;
+    uint8_t* sym_carry = nullptr;        // [B][DH_SYM_CARRY_MAX] symbols the decoder has not consumed yet
+    uint32_t* dec_state = nullptr;
+    uint8_t* frames = nullptr; uint32_t* frame_count = nullptr;
+    dh_event* events = nullptr; uint32_t* ev_count = nullptr;
+    uint32_t* overflow = nullptr;
+    float* filtered = nullptr; float* rrc_hist = nullptr;
+    float* staging = nullptr;            // push_host staging [B][max_samples]
+    DhFecTables* tables = nullptr;
+    uint32_t* zero_counts = nullptr;
+    uint32_t last_n = 0;
+    DhDspParams dsp{}; DhRrcParams rrcp{}; DhDecParams dec{};
+
+    int init(const dh_engine_config& c) {
+        int rc = make_layout(c, L);
+        if (rc) return rc;
+        slot_filter = c.slot_filter;
+        const size_t B = L.B;
+#define DH_ALLOC(ptr, type, count) do { ptr = (type*) be.alloc(sizeof(type) * (size_t) (count)); if (!ptr) return DH_ENOMEM; } while (0)
+        DH_ALLOC(overflow, uint32_t, 16);
+        DH_ALLOC(sym_count, uint32_t, B);
+        if (L.demod) DH_ALLOC(dsp_state, uint32_t, B * L.state_words);
+        if (L.demod) DH_ALLOC(syms, uint8_t, B * L.sym_stride);
+        if (L.proto) {
+            DH_ALLOC(dec_state, uint32_t, B * DH_DEC_STATE_WORDS);
+            DH_ALLOC(sym_carry, uint8_t, B * DH_SYM_CARRY_MAX);
+            DH_ALLOC(frames, uint8_t, B * (size_t) L.out_cap);
+            DH_ALLOC(frame_count, uint32_t, B);
+            DH_ALLOC(ev_count, uint32_t, B);
+            if (!(L.flags & DH_FLAG_NO_EVENTS)) DH_ALLOC(events, dh_event, B * (size_t) L.ev_cap);
+            DH_ALLOC(tables, DhFecTables, 1);
+            DhFecTables* host = new (std::nothrow) DhFecTables;
+            if (!host) return DH_ENOMEM;
+            build_fec_tables(*host);
+            rc = be.upload(tables, host, sizeof(DhFecTables));
+            be.sync();
+            delete host;
+            if (rc) return rc;
+        }
+        if (L.rrc && !L.fused) {
+            DH_ALLOC(filtered, float, B * (size_t) L.max_samples);
+            DH_ALLOC(rrc_hist, float, B * (size_t) L.nz);
+        }
+#undef DH_ALLOC
+        return reset();
+    }
+
+    void destroy() {
+        void* ptrs[] = { dsp_state, syms, sym_count, sym_carry, dec_state, frames, frame_count, events, ev_count,
+                         overflow, filtered, rrc_hist, staging, tables };
+        for (void* p : ptrs) if (p) be.free(p);
+    }
+
+    int reset() {
+        int rc = be.zero(overflow, sizeof(uint32_t) * 16);
+        rc |= be.zero(sym_count, sizeof(uint32_t) * L.B);
+        if (sym_carry) rc |= be.zero(sym_carry, (size_t) L.B * DH_SYM_CARRY_MAX);
+        if (dsp_state) rc |= be.zero(dsp_state, sizeof(uint32_t) * L.B * L.state_words);
+        if (syms) rc |= be.zero(syms, L.B * L.sym_stride);
+        if (dec_state) rc |= be.zero(dec_state, sizeof(uint32_t) * L.B * DH_DEC_STATE_WORDS);
+        if (frame_count) rc |= be.zero(frame_count, sizeof(uint32_t) * L.B);
+        if (ev_count) rc |= be.zero(ev_count, sizeof(uint32_t) * L.B);
+        if (rrc_hist) rc |= be.zero(rrc_hist, sizeof(float) * L.B * L.nz);
+        // the fused slicer starts with nz zero samples of history in its tail (RrcFilter's delay line)
+        rc |= be.launch_init_state(dsp_state, L.state_words, L.fused ? L.nz : 0u, dec_state, slot_filter, L.B);
+        last_n = 0;
+        return rc ? DH_EDEVICE : DH_OK;
+    }
+
+    int set_slot_filter(uint32_t f) {
+        if (L.proto != DH_PROTO_DMR) return DH_EINVAL;
+        slot_filter = f;
+        return be.launch_set_slot_filter(dec_state, f, L.B) ? DH_EDEVICE : DH_OK;
+    }
+
+    void fill_dec_params(const uint8_t* d_syms, size_t stride, const uint32_t* d_count) {
+        dec.syms = d_syms; dec.sym_stride = stride; dec.sym_count = d_count;
+        dec.carry = sym_carry; dec.carry_stride = DH_SYM_CARRY_MAX;
+        dec.state = dec_state; dec.state_stride = DH_DEC_STATE_WORDS;
+        dec.out = frames; dec.out_stride = L.out_cap; dec.out_cap = L.out_cap; dec.out_count = frame_count;
+        dec.events = events; dec.ev_stride = L.ev_cap; dec.ev_cap = L.ev_cap; dec.ev_count = ev_count;
+        dec.overflow = overflow; dec.T = tables; dec.n_channels = L.B;
+    }
+
+    int push(const float* d_in, size_t stride, size_t n) {
+        if (!d_in || n > L.max_samples || stride < n) return DH_EINVAL;
+        if (!L.rrc && !L.demod) return DH_EINVAL;
+        last_n = (uint32_t) n;
+        int rc = 0;
+        const float* demod_in = d_in; size_t demod_stride = stride;
+        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;
+        be.timing_mark(0);
+        if (L.rrc && !L.fused) {
+            rrcp.in = d_in; rrcp.in_stride = stride; rrcp.out = filtered; rrcp.out_stride = L.max_samples;
+            rrcp.hist = rrc_hist; rrcp.n = (uint32_t) n; rrcp.n_channels = L.B; rrcp.nz = L.nz; rrcp.fast = fast;
+            fill_taps(L.rrc, rrcp.taps, &rrcp.gain); rrcp.inv_gain = (float) (1.0 / rrcp.gain);
+            if (n) rc |= be.launch_rrc_tiles(rrcp, L.nz, fast);
+            if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, L.nz, L.B);
+            demod_in = filtered; demod_stride = L.max_samples;
+        }
+        be.timing_mark(1);
+        if (L.demod) {
+            dsp.in = demod_in; dsp.in_stride = demod_stride; dsp.n = (uint32_t) n;
+            dsp.state = (float*) dsp_state; dsp.state_stride = L.state_words;
+            dsp.syms = syms; dsp.sym_stride = L.sym_stride;
+            dsp.sym_count = sym_count; dsp.sym_cap = L.sym_cap; dsp.overflow = overflow; dsp.n_channels = L.B;
+            dsp.sps = L.sps; dsp.lo = L.lo; dsp.hi = L.hi;
+            dsp.levels = L.demod; dsp.invert = (L.flags & DH_FLAG_FSK_INVERT) ? 1 : 0;
+            dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast;
+            if (L.fused) { fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.inv_gain = (float) (1.0 / dsp.gain); }
+            rc |= be.launch_rrc_demod(dsp, dsp.nz, fast);
+        }
+        be.timing_mark(2);
+        if (L.proto && L.demod) {
+            fill_dec_params(syms, L.sym_stride, sym_count);
+            rc |= be.launch_decoder(dec, L.proto);
+        }
+        be.timing_mark(3);
+        be.timing_next();
+        return rc ? DH_EDEVICE : DH_OK;
+    }
+
+    int push_host(const float* h_in, size_t stride, size_t n) {
+        if (!h_in || n > L.max_samples || stride < n) return DH_EINVAL;
+        if (!staging) { staging = (float*) be.alloc(sizeof(float) * (size_t) L.B * L.max_samples); if (!staging) return DH_ENOMEM; }
+        for (uint32_t ch = 0; ch < L.B; ch++)
+            if (be.upload(staging + (size_t) ch * L.max_samples, h_in + (size_t) ch * stride, sizeof(float) * n)) return DH_EDEVICE;
+        return push(staging, L.max_samples, n);
+    }
+
+    // decoder-only engines: the caller's symbol rows are read in place
+    int push_symbols(const uint8_t* d_syms, size_t stride, const uint32_t* d_count) {
+        if (!L.proto || L.demod || !d_syms || !d_count) return DH_EINVAL;
+        fill_dec_params(d_syms, stride, d_count);
+        return be.launch_decoder(dec, L.proto) ? DH_EDEVICE : DH_OK;
+    }
+
+    int check_overflow() {
+        uint32_t flag = 0;
+        if (be.download(&flag, overflow, sizeof(flag))) return DH_EDEVICE;
+        return flag ? DH_ECAPACITY : DH_OK;
+    }
+
+    int read_row(const void* base, size_t row_bytes, uint32_t channel, const uint32_t* counts, size_t elem, void* h_out, size_t* n) {
+        if (channel >= L.B || !n || !base) return DH_EINVAL;
+        uint32_t cnt = 0; const uint32_t off = 0;
+        if (be.download(&cnt, counts + channel, sizeof(cnt))) return DH_EDEVICE;
+        const size_t cap = *n;
+        *n = cnt;
+        if (cnt > cap) return DH_ECAPACITY;
+        if (cnt && h_out && be.download(h_out, (const char*) base + row_bytes * channel + (size_t) off * elem, cnt * elem)) return DH_EDEVICE;
+        return DH_OK;
+    }
+};
+
+}  // namespace dh

@@ -1,0 +1,128 @@
+// fec_core.hpp -- block codes, BPTC(196,96), CRC-16, PN9 as lane-local functions.
+//
+// What the reference does with a bit-serial syndrome loop plus a linear scan of a generated
+// {syndrome, pattern} list (e.g. src/dmr_decoder/golay_20_8.c:1403-1435) is done here with
+//   syndrome = for each parity-check row: parity(popcount(word & row))      (v_bcnt / s_bcnt1)
+//   pattern  = dense LUT[syndrome]                                          (LDS / L2 resident)
+// The dense LUT is equivalent to the reference's first-match scan because no two correctable
+// error patterns of these codes share a syndrome (d_min >= 2t+1); the tables are regenerated
+// at library start-up from the generator matrices (fec_tables.cpp), not copied.
+#pragma once
+
+#include "dh_portable.hpp"
+
+struct DhCode {
+    // parity-check rows as masks over the n-bit word (bit n-1 = first transmitted column)
+    uint32_t h[12];
+    int n, k;
+};
+
+struct DhFecTables {
+    DhCode h74, h139, h1511, h1611, qr, g208, g2412;
+    uint8_t  lut_h74[8];
+    uint16_t lut_h139[16];
+    uint16_t lut_h1511[16];
+    uint16_t lut_h1611[32];
+    uint16_t lut_qr[512];
+    uint32_t lut_g208[4096];
+    uint32_t lut_g2412[4096];
+};
+
+// syndrome in the reference's bit order: first parity-check row ends up in the MSB
+// (hamming_13_9.c:52-68 and siblings)
+DH_HD uint32_t dh_syndrome(const DhCode& c, uint32_t word) {
+    uint32_t s = 0;
+    const int r = c.n - c.k;
+    for (int i = 0; i < r; i++) s = (s << 1) | (uint32_t) (dh_popc32(word & c.h[i]) & 1);
+    return s;
+}
+
+template <typename LutT>
+DH_HD bool dh_block_decode(const DhCode& c, const LutT* lut, uint32_t& word) {
+    const uint32_t s = dh_syndrome(c, word);
+    if (s == 0) return true;
+    const uint32_t p = lut[s];
+    if (p == 0) return false;          // syndrome of no pattern of weight <= t: uncorrectable
+    word ^= p;
+    return true;
+}
+
+// ------------------------------------------------------------------ BPTC(196,96)
+// reference: src/dmr_decoder/bptc_196_96.c:5-59.  `raw` holds the 196 received bits MSB-first
+// in 25 bytes.  The de-interleave (i*181 mod 196) and the 13x15 pivot are folded into one gather.
+DH_HD int dh_bptc_bit(const uint8_t* raw, int i) { return (raw[i >> 3] >> (7 - (i & 7))) & 1; }
+
+DH_HD bool dh_bptc_196_96(const DhFecTables& T, const uint8_t* raw, uint8_t* out12) {
+    uint32_t cols[15];
+    bool ok = true;
+    for (int i = 0; i < 15; i++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 13; k++) {
+            const int di = k * 15 + i + 1;                 // skip R(3)
+            w |= (uint32_t) dh_bptc_bit(raw, (di * 181) % 196) << (12 - k);
+        }
+        ok &= dh_block_decode(T.h139, T.lut_h139, w);      // all 15 columns are always decoded (:27)
+        cols[i] = w;
+    }
+    if (!ok) return false;
+    uint32_t rows[9];
+    for (int i = 0; i < 9; i++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 15; k++) w |= ((cols[k] >> (12 - i)) & 1u) << (14 - k);
+        ok &= dh_block_decode(T.h1511, T.lut_h1511, w);
+        rows[i] = w;
+    }
+    if (!ok) return false;
+    // 96 information bits: row 0 carries 3 reserved + 8, rows 1..8 carry 11 each (:45-56)
+    uint64_t acc = 0; int nacc = 0, ob = 0;
+    for (int r = 0; r < 9; r++) {
+        const int nb = r == 0 ? 8 : 11;
+        const uint32_t bits = (rows[r] >> 4) & ((1u << nb) - 1);
+        acc = (acc << nb) | bits; nacc += nb;
+        while (nacc >= 8) { out12[ob++] = (uint8_t) (acc >> (nacc - 8)); nacc -= 8; }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ CRC-16 / PN9
+// reference: src/ysf_decoder/crc16.c:3-18
+DH_HD uint16_t dh_crc16(const uint8_t* data, int count) {
+    uint32_t crc = 0;
+    for (int k = 0; k < count; k++) {
+        crc ^= (uint32_t) data[k] << 8;
+        for (int i = 0; i < 8; i++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) : (crc << 1);
+    }
+    return (uint16_t) (~crc & 0xFFFFu);
+}
+
+// reference: src/ysf_decoder/whitening.c:6-22; one PN9 step returns the whitening bit
+DH_HD uint32_t dh_pn9_step(uint32_t& wsr) {
+    const uint32_t wb = wsr & 1u;
+    const uint32_t fb = ((wsr >> 4) & 1u) ^ wb;
+    wsr = ((wsr & 0x1FEu) >> 1) | (fb << 8);
+    return wb;
+}
+
+DH_HD void dh_whiten(const uint8_t* in, uint8_t* out, int n_bits) {
+    uint32_t wsr = 0x1C9u;
+    const int nbytes = (n_bits + 7) / 8;
+    for (int b = 0; b < nbytes; b++) {
+        uint32_t m = 0;
+        for (int i = 0; i < 8; i++) {
+            const int bit = b * 8 + i;
+            uint32_t wb = 0;
+            if (bit < n_bits) wb = dh_pn9_step(wsr);
+            m = (m << 1) | wb;
+        }
+        // bits past n_bits in the last byte come out as 0, as in the reference (only the first n are copied)
+        const uint32_t keep = (b * 8 + 8 <= n_bits) ? 0xFFu : (0xFFu << (8 - (n_bits - b * 8))) & 0xFFu;
+        out[b] = (uint8_t) ((in[b] ^ m) & keep);
+    }
+}
+
+// rate-1/2 K=5 encoder output of the transition leaving `state` with input `bit`
+// (G1 = 1+D^3+D^4, G2 = 1+D+D^2+D^4; equals the table at src/ysf_decoder/trellis.c:8-25)
+DH_HD uint32_t dh_trellis_out(uint32_t state, uint32_t bit) {
+    const uint32_t s0 = state & 1u, s1 = (state >> 1) & 1u, s2 = (state >> 2) & 1u, s3 = (state >> 3) & 1u;
+    return ((bit ^ s1 ^ s0) << 1) | (bit ^ s3 ^ s2 ^ s0);
+}

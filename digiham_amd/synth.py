@@ -1,0 +1,337 @@
+"""Deterministic synthetic DMR / YSF signal generator (host-side plumbing).
+
+Builds what digiham's ``rrc_filter`` sees in ``examples/dmr-decoder.sh:13-19``:
+48 kS/s float32 FM-discriminator audio of a 4800 Bd 4-level FSK signal, i.e.
+dibit symbols mapped to levels {1:+3, 0:+1, 2:-1, 3:-3} (the inverse of the
+slicer at gfsk_demodulator.cpp:90-104), 10 samples per symbol, TX pulse-shaped
+with the same 81-tap root-raised-cosine the receiver uses.
+
+Frame builders follow the layouts the reference decoders parse (file:line of
+the *decoding* side is cited at each builder); FEC encoders are systematic
+encoders for the ETSI TS 102 361-1 Annex B / YSF generator matrices.
+
+Nothing here touches the GPU; bench.py lifts the symbol streams to the device
+and does the pulse shaping there with torch (plumbing, not the product).
+"""
+import numpy as np
+
+# ----------------------------------------------------------------------------- FEC encoders
+# P parts of the systematic generator matrices G = [I | P]
+_P = {
+    "hamming_7_4": (7, 4, [0x5, 0x7, 0x6, 0x3]),
+    "hamming_13_9": (13, 9, [0xF, 0xE, 0x7, 0xA, 0x5, 0xB, 0xC, 0x6, 0x3]),
+    "hamming_15_11": (15, 11, [0x9, 0xD, 0xF, 0xE, 0x7, 0xA, 0x5, 0xB, 0xC, 0x6, 0x3]),
+    "hamming_16_11": (16, 11, [0x13, 0x1A, 0x1F, 0x1C, 0x0E, 0x15, 0x0B, 0x16, 0x19, 0x0D, 0x07]),
+    "golay_24_12": (24, 12, [0xC75, 0x63B, 0xF68, 0x7B4, 0x3DA, 0xD99, 0x6CD, 0x367, 0xDC6, 0xA97, 0x93E, 0x8EB]),
+    "golay_20_8": (20, 8, [0x3DA, 0xD99, 0x6CD, 0x367, 0xDC6, 0xA97, 0x93E, 0x8EB]),
+    "quadratic_residue": (16, 7, [0x04F, 0x11E, 0x1B7, 0x1E2, 0x1C9, 0x0E5, 0x073]),
+}
+
+
+def block_encode(code, info):
+    n, k, p = _P[code]
+    info = int(info) & ((1 << k) - 1)
+    par = 0
+    for j in range(k):
+        if (info >> (k - 1 - j)) & 1:
+            par ^= p[j]
+    return (info << (n - k)) | par
+
+
+def _bits_of(value, nbits):
+    return [(value >> (nbits - 1 - i)) & 1 for i in range(nbits)]
+
+
+def bytes_to_bits(b):
+    return [(int(x) >> (7 - i)) & 1 for x in b for i in range(8)]
+
+
+def bits_to_bytes(bits):
+    bits = list(bits) + [0] * (-len(bits) % 8)
+    return bytes(sum(bits[i + j] << (7 - j) for j in range(8)) for i in range(0, len(bits), 8))
+
+
+def bits_to_dibits(bits):
+    assert len(bits) % 2 == 0
+    return [bits[i] * 2 + bits[i + 1] for i in range(0, len(bits), 2)]
+
+
+def bptc_196_96_encode_bits(info_bits):
+    """96 info bits -> 196 transmit bits (decoder: bptc_196_96.c:5-59)."""
+    assert len(info_bits) == 96
+    rows = []
+    it = iter(info_bits)
+    for r in range(9):
+        d = [0, 0, 0] + [next(it) for _ in range(8)] if r == 0 else [next(it) for _ in range(11)]
+        rows.append(_bits_of(block_encode("hamming_15_11", int("".join(map(str, d)), 2)), 15))
+    rows += [[0] * 15 for _ in range(4)]
+    for c in range(15):
+        d = int("".join(str(rows[r][c]) for r in range(9)), 2)
+        cw = _bits_of(block_encode("hamming_13_9", d), 13)
+        for r in range(9, 13):
+            rows[r][c] = cw[r]
+    deint = [0] + [b for row in rows for b in row]
+    tx = [0] * 196
+    for i in range(196):
+        tx[(i * 181) % 196] = deint[i]
+    return tx
+
+
+def trellis_encode_bits(bits):
+    """rate-1/2 K=5, G1 = 1+D^3+D^4, G2 = 1+D+D^2+D^4 (decoder: trellis.c:8-25) -> dibits."""
+    state = 0
+    out = []
+    for b in bits:
+        s0, s1, s2, s3 = state & 1, (state >> 1) & 1, (state >> 2) & 1, (state >> 3) & 1
+        out.append(((b ^ s1 ^ s0) << 1) | (b ^ s3 ^ s2 ^ s0))
+        state = (b << 3) | (state >> 1)
+    return out
+
+
+def crc16_ccitt(data):
+    """decoder: crc16.c:3-18 (init 0, poly 0x1021, inverted)."""
+    crc = 0
+    for byte in data:
+        for i in range(8):
+            fb = ((byte >> (7 - i)) & 1) ^ ((crc >> 15) & 1)
+            crc = (crc << 1) & 0xFFFF
+            if fb:
+                crc ^= 0x1021
+    return crc ^ 0xFFFF
+
+
+def pn9_bits(n):
+    """decoder: whitening.c:6-22."""
+    wsr = 0x1C9
+    out = []
+    for _ in range(n):
+        wb = wsr & 1
+        out.append(wb)
+        fb = ((wsr >> 4) & 1) ^ wb
+        wsr = ((wsr & 0x1FE) >> 1) | (fb << 8)
+    return out
+
+
+# ----------------------------------------------------------------------------- DMR
+def _hex_to_dibits(h):
+    bits = _bits_of(int(h, 16), 4 * len(h))
+    return bits_to_dibits(bits)
+
+
+DMR_SYNC = {  # ETSI TS 102 361-1 table 9.2 (decoder: dmr_phase.hpp:25-28)
+    "bs_data": _hex_to_dibits("DFF57D75DF5D"), "bs_voice": _hex_to_dibits("755FD7DF75F7"),
+    "ms_data": _hex_to_dibits("D5D7F77FD757"), "ms_voice": _hex_to_dibits("7F7D5DD57DFD"),
+}
+_TACT_POS = [0, 4, 8, 12, 14, 18, 22]           # decoder: cach.cpp:7
+
+
+def dmr_cach(slot, lcss=0, at=1, rng=None):
+    """12 dibits; TACT = Hamming(7,4) of [AT, TC, LCSS1, LCSS0] (decoder: cach.cpp:11-31, tact.cpp:14-24)."""
+    tact = _bits_of(block_encode("hamming_7_4", (at << 3) | (slot << 2) | lcss), 7)
+    bits = list(rng.integers(0, 2, 24)) if rng is not None else [0] * 24
+    for b, pos in zip(tact, _TACT_POS):
+        bits[pos] = b
+    return bits_to_dibits([int(b) for b in bits])
+
+
+def dmr_embedded_lc_fragments(lc9):
+    """9 LC bytes -> four 32-bit fragments as 16 dibits each (decoder: embedded.cpp:32-94)."""
+    bits = bytes_to_bits(lc9)
+    cs = sum(lc9) % 31
+    csb = _bits_of(cs, 5)
+    rows = [bits[0:11], bits[11:22], bits[22:32] + [csb[0]], bits[32:42] + [csb[1]], bits[42:52] + [csb[2]],
+            bits[52:62] + [csb[3]], bits[62:72] + [csb[4]]]
+    rows = [_bits_of(block_encode("hamming_16_11", int("".join(map(str, r)), 2)), 16) for r in rows]
+    rows.append([sum(r[c] for r in rows) & 1 for c in range(16)])
+    stream = [rows[r][c] for c in range(16) for r in range(8)]          # column by column
+    return [bits_to_dibits(stream[i * 32:(i + 1) * 32]) for i in range(4)]
+
+
+def dmr_voice_burst(slot, payload_dibits, mid, rng=None):
+    """144 dibits: CACH 12 | 54 | 24 (sync or EMB+embedded) | 54 (decoder: dmr_phase.cpp:207-227)."""
+    assert len(payload_dibits) == 108 and len(mid) == 24
+    return dmr_cach(slot, rng=rng) + list(payload_dibits[:54]) + list(mid) + list(payload_dibits[54:])
+
+
+def dmr_emb_mid(cc, lcss, frag16, pi=0):
+    """EMB (QR(16,7) of CC|PI|LCSS) split around 16 embedded dibits (decoder: dmr_phase.cpp:117-145, emb.cpp:18-24)."""
+    emb = _bits_of(block_encode("quadratic_residue", (cc << 3) | (pi << 2) | lcss), 16)
+    return bits_to_dibits(emb[:8]) + list(frag16) + bits_to_dibits(emb[8:])
+
+
+def dmr_data_burst(slot, cc, data_type, info12, sync="bs_data", rng=None):
+    """Data burst: 98 info dibits + slot type Golay(20,8) around the sync (decoder: dmr_phase.cpp:235-284)."""
+    tx = bits_to_dibits(bptc_196_96_encode_bits(bytes_to_bits(info12)))
+    st = bits_to_dibits(_bits_of(block_encode("golay_20_8", (cc << 4) | data_type), 20))
+    return dmr_cach(slot, rng=rng) + tx[:49] + st[:5] + DMR_SYNC[sync] + st[5:] + tx[49:]
+
+
+def dmr_lc(flco, fid, opts, dst, src):
+    """9-byte full LC + 3 parity bytes (parity not checked: lc.cpp:8-11)."""
+    return bytes([flco & 0x3F, fid, opts, (dst >> 16) & 255, (dst >> 8) & 255, dst & 255,
+                  (src >> 16) & 255, (src >> 8) & 255, src & 255])
+
+
+def dmr_call(rng, slot, cc=1, dst=1234, src=5678901, n_superframes=4, sync_kind="bs"):
+    """One voice call on one slot as a list of 144-dibit bursts: LC header, superframes, terminator."""
+    lc = dmr_lc(0, 0, 0, dst, src)
+    bursts = [dmr_data_burst(slot, cc, 1, lc + bytes(3), sync_kind + "_data", rng)]
+    frags = dmr_embedded_lc_fragments(lc)
+    for _ in range(n_superframes):
+        for f in range(6):
+            payload = list(rng.integers(0, 4, 108))
+            if f == 0:
+                mid = DMR_SYNC[sync_kind + "_voice"]
+            elif f <= 4:
+                mid = dmr_emb_mid(cc, [1, 3, 3, 2][f - 1], frags[f - 1])
+            else:
+                mid = dmr_emb_mid(cc, 0, [0] * 16)
+            bursts.append(dmr_voice_burst(slot, payload, mid, rng))
+    bursts.append(dmr_data_burst(slot, cc, 2, lc + bytes(3), sync_kind + "_data", rng))
+    return bursts
+
+
+def dmr_idle_burst(slot, cc, rng):
+    return dmr_data_burst(slot, cc, 9, bytes(rng.integers(0, 256, 12).tolist()), "bs_data", rng)
+
+
+def dmr_stream(seed, n_bursts, two_slots=True, cc=1, lead_in=37):
+    """A BS-style TDMA dibit stream: bursts alternate slot 0 / slot 1.  Slot 0 carries
+    back-to-back voice calls; slot 1 carries idle data bursts or (two_slots) its own calls."""
+    rng = np.random.default_rng(seed)
+    q = [[], []]
+    while len(q[0]) < n_bursts:
+        q[0] += dmr_call(rng, 0, cc, dst=int(rng.integers(1, 1 << 24)), src=int(rng.integers(1, 1 << 24)),
+                         n_superframes=int(rng.integers(2, 6)))
+        q[0] += [dmr_idle_burst(0, cc, rng) for _ in range(int(rng.integers(0, 3)))]
+    while len(q[1]) < n_bursts:
+        if two_slots:
+            q[1] += [dmr_idle_burst(1, cc, rng) for _ in range(int(rng.integers(1, 4)))]
+            q[1] += dmr_call(rng, 1, cc, dst=int(rng.integers(1, 1 << 24)), src=int(rng.integers(1, 1 << 24)),
+                             n_superframes=int(rng.integers(1, 4)))
+        else:
+            q[1].append(dmr_idle_burst(1, cc, rng))
+    out = list(rng.integers(0, 4, lead_in))
+    for i in range(n_bursts):
+        out += q[i & 1][i >> 1]
+    return np.array(out, np.uint8)
+
+
+# ----------------------------------------------------------------------------- YSF
+YSF_SYNC = _hex_to_dibits("D471C9634D")           # decoder: ysf_phase.hpp:21
+
+
+def ysf_fich_dibits(frame_type, data_type, frame_number, frame_total=7):
+    """FICH word -> CRC16 -> 4x Golay(24,12) -> conv. code -> 5x20 interleave (decoder: fich.cpp:12-66)."""
+    word = (frame_type << 30) | (frame_number << 19) | (frame_total << 16) | (data_type << 8)
+    be = word.to_bytes(4, "big")
+    bits = bytes_to_bits(be) + _bits_of(crc16_ccitt(be), 16)
+    coded = []
+    for i in range(4):
+        coded += _bits_of(block_encode("golay_24_12", int("".join(map(str, bits[i * 12:(i + 1) * 12])), 2)), 24)
+    code = trellis_encode_bits(coded + [0, 0, 0, 0])
+    tx = [0] * 100
+    for i in range(100):
+        tx[(i * 20) % 100 + (i * 20) // 100] = code[i]
+    return tx
+
+
+def _ysf_dch_code(data, nbytes):
+    """whiten -> CRC16 -> 4 tail bits -> conv. code (decoder: ysf_phase.cpp:258-269 / :332-346)."""
+    bits = bytes_to_bits(data[:nbytes])
+    pn = pn9_bits(len(bits))
+    wh = bits_to_bytes([b ^ p for b, p in zip(bits, pn)])
+    bits = bytes_to_bits(wh) + _bits_of(crc16_ccitt(wh), 16) + [0, 0, 0, 0]
+    return trellis_encode_bits(bits)
+
+
+_V2_MAP = [0, 3, 6, 9, 12, 15, 18, 21, 24, 27, 30, 33, 36, 39, 41, 43, 45, 47,
+           1, 4, 7, 10, 13, 16, 19, 22, 25, 28, 31, 34, 37, 40, 42, 44, 46, 48,
+           2, 5, 8, 11, 14, 17, 20, 23, 26, 29, 32, 35, 38]   # decoder: ysf_phase.hpp:46-51
+
+
+def ysf_v2_voice_dibits(ambe49):
+    """49 AMBE bits -> 52 dibits (decoder: ysf_phase.cpp:180-256)."""
+    voice = [ambe49[_V2_MAP[i]] for i in range(49)]
+    tri = [b for b in voice[:27] for _ in range(3)] + voice[27:] + [0]
+    pn = pn9_bits(104)
+    wh = [a ^ b for a, b in zip(tri, pn)]
+    inter = [0] * 104
+    for k in range(104):
+        inter[(k * 4) % 104 + (k * 4) // 104] = wh[k]
+    return bits_to_dibits(inter)
+
+
+def ysf_frame(rng, frame_type, data_type=2, frame_number=0, dch=None, csd=None, corrupt_fich=False):
+    """One 480-dibit frame: sync 20 | FICH 100 | payload 360 (decoder: ysf_phase.cpp:45-172)."""
+    payload = list(rng.integers(0, 4, 360))
+    if frame_type == 1 and data_type == 2:                      # V/D mode type 2
+        code = _ysf_dch_code(dch if dch is not None else bytes(rng.integers(32, 127, 10).tolist()), 10)
+        for i in range(100):
+            payload[(i % 5) * 72 + i // 5] = code[i]
+        for blk in range(5):
+            payload[blk * 72 + 20: blk * 72 + 72] = ysf_v2_voice_dibits(list(rng.integers(0, 2, 49)))
+    elif frame_type in (0, 2):                                  # header / terminator: CSD1 + CSD2
+        csd = csd if csd is not None else [bytes(rng.integers(32, 127, 20).tolist()) for _ in range(2)]
+        for half in range(2):
+            code = _ysf_dch_code(csd[half], 20)
+            for i in range(180):
+                streampos = (i % 9) * 20 + i // 9
+                payload[half * 36 + (streampos // 36) * 72 + streampos % 36] = code[i]
+    fich = ysf_fich_dibits(frame_type, data_type, frame_number)
+    if corrupt_fich:
+        fich = list(rng.integers(0, 4, 100))
+    return YSF_SYNC + fich + payload
+
+
+def ysf_stream(seed, n_frames, mode="vd2", lead_in=53):
+    """Header, communication frames (FN cycling 0..7), terminator, repeated."""
+    rng = np.random.default_rng(seed)
+    dt = {"vd1": 0, "vd2": 2, "fr": 3, "datafr": 1}[mode]
+    out = list(rng.integers(0, 4, lead_in))
+    n = 0
+    while n < n_frames:
+        out += ysf_frame(rng, 0, dt); n += 1
+        for i in range(int(rng.integers(6, 14))):
+            if n >= n_frames:
+                break
+            out += ysf_frame(rng, 1, dt, i & 7); n += 1
+        if n < n_frames:
+            out += ysf_frame(rng, 2, dt); n += 1
+    return np.array(out, np.uint8)
+
+
+# ----------------------------------------------------------------------------- waveform
+LEVELS = np.array([1.0, 3.0, -1.0, -3.0], np.float32) / 3.0      # dibit 0,1,2,3 (gfsk_demodulator.cpp:90-104)
+
+
+def wide_rrc_taps():
+    from . import _taps
+    return _taps.wide()
+
+
+def shape(symbols, sps=10, taps=None, amplitude=0.5, circular=False, levels=LEVELS):
+    """Dibits -> pulse-shaped float32 audio (TX RRC), `sps` samples per symbol."""
+    taps = wide_rrc_taps() if taps is None else taps
+    imp = np.zeros(len(symbols) * sps, np.float64)
+    imp[::sps] = levels[np.asarray(symbols)]
+    g = taps.astype(np.float64)
+    g = g / g.sum() * sps                                          # unity gain for a constant symbol run
+    if circular:
+        n = len(imp)
+        y = np.real(np.fft.ifft(np.fft.fft(imp) * np.fft.fft(g, n)))
+        y = np.roll(y, -(len(g) // 2))
+    else:
+        y = np.convolve(imp, g)[len(g) // 2:][:len(imp)]
+    return (amplitude * y).astype(np.float32)
+
+
+def impair(x, seed, snr_db=None, dc=0.0, gain=1.0, delay=0):
+    """Per-channel impairments: sample delay, gain, DC offset, additive white noise."""
+    rng = np.random.default_rng(seed)
+    y = np.roll(x, delay).astype(np.float32) * np.float32(gain) + np.float32(dc)
+    if snr_db is not None:
+        p = float(np.mean(x.astype(np.float64) ** 2))
+        sigma = np.sqrt(p / (10 ** (snr_db / 10)))
+        y = y + rng.normal(0, sigma, len(y)).astype(np.float32)
+    return y.astype(np.float32)

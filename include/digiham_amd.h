@@ -1,0 +1,189 @@
+/*
+ * digiham_amd.h -- C ABI of the MI355X-native many-channel digital-voice
+ * demodulation / FEC engine (libdigiham_amd.so).
+ *
+ * This is the drop-in boundary for digiham's hot path
+ *     rrc_filter -> gfsk_demodulator / fsk_demodulator -> dmr_decoder / ysf_decoder
+ * (+ digitalvoice_filter).  Plain C types, caller-owned buffers, `int` return
+ * (0 = ok, negative = DH_E*), no exceptions across the ABI.  The host-side
+ * C++ classes in include/digiham/ (same names and constructor signatures as
+ * the reference's include/ headers) and the Python binding in digiham_amd/ sit on
+ * top of exactly these entry points.
+ *
+ * Pointer conventions
+ *   d_*   device pointers (HBM; hipMalloc / torch CUDA tensors)
+ *   h_*   host pointers
+ *   stream: a hipStream_t passed as void* (NULL = the HIP default stream)
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the reference root, jketterl/digiham v0.7.0-dev).
+ */
+#ifndef DIGIHAM_AMD_H
+#define DIGIHAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_OK        0
+#define DH_EINVAL   -1   /* bad argument */
+#define DH_ENOMEM   -2   /* device allocation failed */
+#define DH_EDEVICE  -3   /* HIP runtime error (see dh_last_error) */
+#define DH_ENODEV   -4   /* no gfx950 device visible */
+#define DH_ECAPACITY -5  /* an output buffer overflowed; results truncated */
+
+const char* dh_version(void);
+/* last HIP error string recorded on this thread ("" if none) */
+const char* dh_last_error(void);
+/* number of visible HIP devices, or a negative DH_E* code */
+int dh_device_count(void);
+
+/* small memory helpers so that C / C++ hosts need no HIP headers (synchronous) */
+int dh_device_alloc(int device, size_t bytes, void** d_out);
+int dh_device_free(void* d_ptr);
+int dh_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
+int dh_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
+
+/* ------------------------------------------------------------------------
+ * Stateless batch FEC kernels (one codeword / block per lane).
+ * Replace the C functions under src/dmr_decoder and src/ysf_decoder.
+ * All arrays are device pointers; `ok` receives 1/0 per item.
+ * ---------------------------------------------------------------------- */
+/* bool hamming_7_4(uint8_t*)      src/dmr_decoder/hamming_7_4.c:56-72  */
+int dh_hamming_7_4(uint8_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool hamming_13_9(uint16_t*)    src/dmr_decoder/hamming_13_9.c:70-84 */
+int dh_hamming_13_9(uint16_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool hamming_15_11(uint16_t*)   src/dmr_decoder/hamming_15_11.c:74-88 */
+int dh_hamming_15_11(uint16_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool hamming_16_11(uint16_t*)   src/dmr_decoder/hamming_16_11.c:79-93 */
+int dh_hamming_16_11(uint16_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool quadratic_residue(uint16_t*) src/dmr_decoder/quadratic_residue.c:321-335 */
+int dh_quadratic_residue(uint16_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool golay_20_8(uint32_t*)      src/dmr_decoder/golay_20_8.c:1421-1435 */
+int dh_golay_20_8(uint32_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool golay_24_12(uint32_t*)     src/ysf_decoder/golay_24_12.c:2401-2415 */
+int dh_golay_24_12(uint32_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool bptc_196_96(uint8_t payload[25], uint8_t output[12])  src/dmr_decoder/bptc_196_96.c:5-59
+ * d_in [n][25] -> d_out [n][12] (zero-filled when ok == 0) */
+int dh_bptc_196_96(const uint8_t* d_in, uint8_t* d_out, uint8_t* d_ok, size_t n, void* stream);
+/* uint8_t decode_trellis(uint8_t* input, uint8_t size, uint8_t* output)  src/ysf_decoder/trellis.c:32-109
+ * d_in [n][in_stride] dibits packed 4 per byte MSB first; n_dibits <= 192;
+ * d_out [n][out_stride] decoded bits (ceil(n_dibits/8) bytes used); d_metric [n] */
+int dh_trellis(const uint8_t* d_in, size_t in_stride, int n_dibits,
+               uint8_t* d_out, size_t out_stride, uint8_t* d_metric, size_t n, void* stream);
+/* uint16_t crc16_checksum(uint8_t* data, int count)  src/ysf_decoder/crc16.c:3-18 */
+int dh_crc16(const uint8_t* d_in, size_t stride, int count, uint16_t* d_out, size_t n, void* stream);
+/* void decode_whitening(uint8_t* in, uint8_t* out, uint8_t num)  src/ysf_decoder/whitening.c:6-22
+ * in/out [n][stride]; ceil(n_bits/8) bytes per row are written */
+int dh_whitening(const uint8_t* d_in, uint8_t* d_out, size_t stride, int n_bits, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Streaming engine: B independent channels, per-channel state resident in HBM.
+ * Replaces one `rrc_filter | gfsk_demodulator | dmr_decoder` process chain
+ * per channel (examples/dmr-decoder.sh:19-23, examples/ysf-decoder.sh:19-23):
+ *   Digiham::RrcFilter::{Wide,Narrow}RrcFilter::process   src/rrc_filter/rrc_filter.cpp:16-34
+ *   Digiham::Fsk::GfskDemodulator::process                src/gfsk_demodulator/gfsk_demodulator.cpp:24-122
+ *   Digiham::Fsk::FskDemodulator::process                 src/fsk_demodulator/fsk_demodulator.cpp:25-112
+ *   Digiham::Decoder::process + Dmr/Ysf phases            src/lib/decoder.cpp:21-47,
+ *                                                         src/dmr_decoder/dmr_phase.cpp:18-302,
+ *                                                         src/ysf_decoder/ysf_phase.cpp:16-349
+ * ---------------------------------------------------------------------- */
+typedef struct dh_engine dh_engine;
+
+enum { DH_RRC_NONE = 0, DH_RRC_WIDE = 1, DH_RRC_NARROW = 2 };
+enum { DH_DEMOD_NONE = 0, DH_DEMOD_FSK2 = 2, DH_DEMOD_GFSK4 = 4 };
+enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2 };
+
+/* flags */
+#define DH_FLAG_FAST_FIR        0x1   /* FMA FIR: float outputs within 1e-6 of the reference, dibits NOT guaranteed bit-exact */
+#define DH_FLAG_KEEP_FILTERED   0x2   /* also materialise the RRC output [B][n] (unfused path; BASELINE config 2) */
+#define DH_FLAG_FSK_INVERT      0x4   /* FskDemodulator(sps, invert = true) */
+#define DH_FLAG_NO_EVENTS       0x8   /* do not record decoder events */
+
+typedef struct {
+    uint32_t struct_size;     /* = sizeof(dh_engine_config) */
+    int32_t  device;          /* HIP device ordinal */
+    uint32_t n_channels;      /* B */
+    uint32_t max_samples;     /* largest n a single push may carry (per channel) */
+    int32_t  rrc;             /* DH_RRC_* */
+    int32_t  demod;           /* DH_DEMOD_* */
+    uint32_t sps;             /* samples per symbol (GfskDemodulator / FskDemodulator ctor argument) */
+    int32_t  proto;           /* DH_PROTO_* */
+    uint32_t flags;
+    uint32_t slot_filter;     /* Dmr::Decoder::setSlotFilter initial value (3 = both slots) */
+    void*    stream;          /* hipStream_t all work is enqueued on (NULL: default stream) */
+} dh_engine_config;
+
+/* Decoder event: one record per call the reference makes into its MetaCollector,
+ * plus the FEC-corrected words feeding it (BPTC LC, slot type, EMB, FICH, DCH). */
+typedef struct {
+    uint32_t sym_index;       /* absolute symbol index of the frame start (mod 2^32) */
+    uint8_t  type;            /* DH_EV_* */
+    uint8_t  a;               /* DMR slot / YSF frame number or CSD index */
+    uint8_t  b;               /* sub-type (sync type, data type, lcss, reset cause) */
+    uint8_t  len;             /* valid payload bytes */
+    uint8_t  payload[24];
+} dh_event;
+
+enum {
+    DH_EV_DMR_SYNC = 1, DH_EV_DMR_SLOT_RESET = 2, DH_EV_DMR_META_RESET = 3, DH_EV_DMR_LC = 4,
+    DH_EV_DMR_SOFT_RESET = 5, DH_EV_DMR_BPTC = 6, DH_EV_DMR_SLOTTYPE = 7, DH_EV_DMR_EMB = 8,
+    DH_EV_YSF_FICH = 16, DH_EV_YSF_MODE = 17, DH_EV_YSF_DCH = 18, DH_EV_YSF_HEADER_DCH = 19,
+    DH_EV_YSF_META_RESET = 20
+};
+
+int  dh_engine_create(const dh_engine_config* cfg, dh_engine** out);
+void dh_engine_destroy(dh_engine* e);
+/* back to the freshly-constructed state of every module (zeroed delay lines, SyncPhase) */
+int  dh_engine_reset(dh_engine* e);
+/* Dmr::Decoder::setSlotFilter (src/dmr_decoder/dmr_decoder.cpp:9-15) for every channel */
+int  dh_engine_set_slot_filter(dh_engine* e, uint32_t filter);
+
+/* Feed n new samples per channel (n <= max_samples).  d_samples is [B][stride]
+ * float32, channel-major, resident in HBM.  Asynchronous on the engine stream.
+ * Outputs of this push replace those of the previous push. */
+int  dh_engine_push(dh_engine* e, const float* d_samples, size_t stride, size_t n);
+/* same, from host memory (staged through an engine-owned device buffer) */
+int  dh_engine_push_host(dh_engine* e, const float* h_samples, size_t stride, size_t n);
+
+/* Device views of the current push's outputs (valid until the next push).
+ * Any out-pointer may be NULL. counts are uint32 [B]. */
+int  dh_engine_filtered(dh_engine* e, const float** d_filtered, size_t* stride);           /* needs DH_FLAG_KEEP_FILTERED */
+int  dh_engine_symbols(dh_engine* e, const uint8_t** d_syms, size_t* stride, const uint32_t** d_count);
+int  dh_engine_frames(dh_engine* e, const uint8_t** d_bytes, size_t* stride, const uint32_t** d_count);
+int  dh_engine_events(dh_engine* e, const dh_event** d_events, size_t* stride, const uint32_t** d_count);
+/* Host copies for one channel (synchronises the engine stream). *n in: capacity, out: count */
+int  dh_engine_read_symbols(dh_engine* e, uint32_t channel, uint8_t* h_out, size_t* n);
+int  dh_engine_read_frames(dh_engine* e, uint32_t channel, uint8_t* h_out, size_t* n);
+int  dh_engine_read_events(dh_engine* e, uint32_t channel, dh_event* h_out, size_t* n);
+int  dh_engine_read_filtered(dh_engine* e, uint32_t channel, float* h_out, size_t* n);
+/* Per-stage device timing (HIP events recorded on the engine stream around each stage of a push):
+ * enable once with the number of pushes to keep; read returns, for each recorded push, the
+ * milliseconds spent in the stand-alone RRC stage (0 when fused), the slicer (fused RRC+GFSK)
+ * kernel and the decoder kernel.  *n in: capacity of the arrays, out: pushes recorded. */
+int  dh_engine_timing_enable(dh_engine* e, uint32_t max_pushes);
+int  dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float* decoder_ms, uint32_t* n);
+/* wait for all enqueued work; returns DH_ECAPACITY if any channel overflowed an output buffer */
+int  dh_engine_sync(dh_engine* e);
+
+/* Standalone decoder stage over symbols (for pipes that already have dibits):
+ * d_syms [B][stride] uint8 dibits (values 0..3), d_count[B] valid symbols per channel. Requires
+ * proto != NONE and an engine created with rrc = NONE, demod = DH_DEMOD_NONE (max_samples then
+ * bounds the symbols per push). */
+int  dh_engine_push_symbols(dh_engine* e, const uint8_t* d_syms, size_t stride, const uint32_t* d_count);
+
+/* ------------------------------------------------------------------------
+ * Digital voice post-filter, B independent int16 streams, state carried.
+ * Replaces Digiham::DigitalVoice::DigitalVoiceFilter::process
+ * (src/digitalvoice_filter/digitalvoice_filter.cpp:6-10,34-45).
+ * d_state: [B][22] floats (xv[11], yv[11]) zero-initialised by the caller.
+ * ---------------------------------------------------------------------- */
+int dh_dvfilter_s16(const int16_t* d_in, int16_t* d_out, float* d_state, size_t n_channels, size_t stride, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

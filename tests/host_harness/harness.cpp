@@ -1,0 +1,120 @@
+// harness.cpp -- CPU wave-emulation build of the kernel bodies (TEST INFRASTRUCTURE ONLY).
+//
+// Compiles digiham_amd/csrc/*_core.hpp with a plain C++ compiler: DH_FOR_LANES becomes a
+// 64-iteration loop, DH_BARRIER a no-op, "device memory" is the host heap and a "kernel launch"
+// is a loop over workgroups.  It exports the same C ABI as libdigiham_amd.so so the CPU-only test
+// tier can run the engine's orchestration and the exact wave algorithms against the oracle.
+// It is built into tests/host_harness/libdh_hostemu.so, is never installed, and the digiham_amd
+// package has no code path that loads it: the product fails loudly without the gfx950 library.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/digiham_amd.h"
+#include "../../digiham_amd/csrc/kernels_core.hpp"
+#include "../../digiham_amd/csrc/fec_tables.hpp"
+
+namespace {
+
+const DhFecTables& host_tables() {
+    static DhFecTables* T = [] { auto* t = new DhFecTables; dh::build_fec_tables(*t); return t; }();
+    return *T;
+}
+
+struct HostBackend {
+    int open(int, void*) { return 0; }
+    void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
+    void free(void* p) { ::free(p); }
+    int zero(void* p, size_t bytes) { memset(p, 0, bytes); return 0; }
+    int upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+    int download(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+    int sync() { return 0; }
+    void timing_mark(int) {}
+    void timing_next() {}
+    int timing_enable(uint32_t) { return 0; }
+    int timing_read(float*, float*, float*, uint32_t* n) { *n = 0; return 0; }
+
+    template <int NZ, bool FAST> static void run_rrc_demod(const DhDspParams& P) {
+        std::vector<char> lds(dh_dsp_shared_bytes(P.sps) + 64);
+        DhDspShared& S = *reinterpret_cast<DhDspShared*>(lds.data());
+        for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST>(P, ch, S);
+    }
+    int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
+        if (nz == 0) run_rrc_demod<0, false>(P);
+        else if (nz == 80) { if (fast) run_rrc_demod<80, true>(P); else run_rrc_demod<80, false>(P); }
+        else if (nz == 160) { if (fast) run_rrc_demod<160, true>(P); else run_rrc_demod<160, false>(P); }
+        else return -1;
+        return 0;
+    }
+    template <int NZ, bool FAST> static void run_rrc_tiles(const DhRrcParams& R) {
+        std::vector<char> lds(dh_dsp_shared_bytes(1) + 64);
+        DhDspShared& S = *reinterpret_cast<DhDspShared*>(lds.data());
+        const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
+        for (uint32_t ch = 0; ch < R.n_channels; ch++)
+            for (uint32_t t = 0; t < tiles; t++) dh_rrc_tile<NZ, FAST>(R, ch, t, S);
+    }
+    int launch_rrc_tiles(const DhRrcParams& R, uint32_t nz, bool fast) {
+        if (nz == 80) { if (fast) run_rrc_tiles<80, true>(R); else run_rrc_tiles<80, false>(R); }
+        else if (nz == 160) { if (fast) run_rrc_tiles<160, true>(R); else run_rrc_tiles<160, false>(R); }
+        else return -1;
+        return 0;
+    }
+    int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {
+        float sh[DH_MAX_NZ];
+        for (uint32_t ch = 0; ch < B; ch++) dh_rrc_hist_channel(hist, in, in_stride, n, nz, ch, sh);
+        return 0;
+    }
+    int launch_decoder(const DhDecParams& P, int proto) {
+        DhDecShared* S = new DhDecShared;
+        for (uint32_t ch = 0; ch < P.n_channels; ch++) {
+            if (proto == DH_PROTO_DMR) dh_dmr_channel(P, ch, *S); else dh_ysf_channel(P, ch, *S);
+        }
+        delete S;
+        return 0;
+    }
+    int launch_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
+        for (uint32_t ch = 0; ch < B; ch++) dh_init_state_channel(dsp_state, state_words, tail0, dec_state, slot_filter, ch);
+        return 0;
+    }
+    int launch_set_slot_filter(uint32_t* dec_state, uint32_t filter, uint32_t B) {
+        for (uint32_t ch = 0; ch < B; ch++) dh_set_slot_filter_channel(dec_state, filter, ch);
+        return 0;
+    }
+};
+
+}  // namespace
+
+static int dh_be_device_count() { return 0; }
+static const char* dh_be_last_error() { return "host emulation"; }
+static int dh_be_alloc(int, size_t bytes, void** out) { *out = calloc(1, bytes ? bytes : 1); return *out ? 0 : DH_ENOMEM; }
+static int dh_be_free(void* p) { free(p); return 0; }
+static int dh_be_copy(void* dst, const void* src, size_t bytes, int) { if (bytes) memcpy(dst, src, bytes); return 0; }
+static int dh_be_fec_block(int code, void* words, uint8_t* ok, size_t n, void*) {
+    for (size_t i = 0; i < n; i++) dh_fec_block_item(host_tables(), code, words, ok, i);
+    return 0;
+}
+static int dh_be_bptc(const uint8_t* in, uint8_t* out, uint8_t* ok, size_t n, void*) {
+    for (size_t i = 0; i < n; i++) dh_bptc_item(host_tables(), in, out, ok, i);
+    return 0;
+}
+static int dh_be_trellis(const uint8_t* in, size_t in_stride, int n_dibits, uint8_t* out, size_t out_stride, uint8_t* metric, size_t n, void*) {
+    DhDecShared* S = new DhDecShared;
+    for (size_t w = 0; w < (n + 3) / 4; w++) dh_trellis_wave(in, in_stride, n_dibits, out, out_stride, metric, n, w, *S);
+    delete S;
+    return 0;
+}
+static int dh_be_crc16(const uint8_t* in, size_t stride, int count, uint16_t* out, size_t n, void*) {
+    for (size_t i = 0; i < n; i++) dh_crc16_item(in, stride, count, out, i);
+    return 0;
+}
+static int dh_be_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n_bits, size_t n, void*) {
+    for (size_t i = 0; i < n; i++) dh_whitening_item(in, out, stride, n_bits, i);
+    return 0;
+}
+static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n, void*) {
+    for (size_t ch = 0; ch < B; ch++) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
+    return 0;
+}
+
+#define DH_BACKEND HostBackend
+#include "../../digiham_amd/csrc/abi_impl.hpp"

@@ -1,0 +1,143 @@
+"""rrc_filter -> gfsk/fsk_demodulator -> dmr/ysf_decoder through the engine ABI vs the oracle.
+
+Runs on the CPU wave emulation (CPU tier) and on the MI355X (-m gpu).  Dibits, decoder bytes and
+decoder events must be bit-exact; float filter outputs must be bit-exact in the default (exact)
+mode and within 1e-6 in FAST_FIR mode.
+"""
+import numpy as np
+import pytest
+
+from common import assert_matches_oracle, make_channels, rel_err, run_engine, sha
+from digiham_amd import synth
+
+
+@pytest.mark.parametrize("proto", ["dmr", "ysf"])
+@pytest.mark.parametrize("chunks", [[10 ** 9], [4800], [1000, 37, 12345, 5, 999]])
+def test_full_chain_bit_exact(ctx, oracle, proto, chunks):
+    x = make_channels(proto, [1, 2, 3, 4, 5], 30 if proto == "dmr" else 10)
+    ref = oracle.chain(x, proto=1 if proto == "dmr" else 2)
+    chunks = [min(c, x.shape[1]) for c in chunks]
+    res = run_engine(ctx, x, proto, chunks)
+    assert_matches_oracle(res, ref, x.shape[0], "%s %s" % (proto, chunks[:2]))
+    assert sum(len(f) for f in res["frames"]) > 0
+
+
+def test_chain_golden_vectors(ctx, golden):
+    g = golden["chain"]
+    for name, proto in (("dmr_a", "dmr"), ("dmr_b", "dmr"), ("ysf_a", "ysf")):
+        x = g[name + "_x"][None, :]
+        res = run_engine(ctx, x, proto, [x.shape[1]])
+        assert (res["syms"][0] == g[name + "_syms"]).all(), name
+        assert (res["frames"][0] == g[name + "_out"]).all(), name
+        assert res["events"][0].tobytes() == g[name + "_events"].tobytes(), name
+
+
+def test_unfused_rrc_output_is_bit_exact(ctx, oracle):
+    """BASELINE config 2 path: RRC output materialised, then the slicer (exact FIR => identical floats)."""
+    x = make_channels("dmr", [7, 8, 9], 12)
+    ref = oracle.chain(x, proto=0, keep_filtered=True)
+    for chunks in ([x.shape[1]], [3000, 50, 2049]):
+        res = run_engine(ctx, x, "none", chunks, keep_filtered=True)
+        assert (res["filtered"] == ref["filtered"]).all()
+        assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, x.shape[0])
+
+
+def test_fast_fir_within_1e6(ctx, oracle):
+    """FAST_FIR (FMA) is the float-path variant: 1e-6 relative to max(|ref|, rms(ref))."""
+    x = make_channels("dmr", [7, 8], 12)
+    ref = oracle.chain(x, proto=0, keep_filtered=True)
+    res = run_engine(ctx, x, "none", [x.shape[1]], keep_filtered=True, fast_fir=True)
+    assert rel_err(res["filtered"], ref["filtered"]).max() <= 1e-6
+    # dibits agree except (rarely) at threshold ties; on this input they agree exactly
+    agree = np.mean([np.mean(res["syms"][b][:1000] == ref["syms"][b, :1000]) for b in range(2)])
+    assert agree > 0.999
+
+
+@pytest.mark.parametrize("rrc,sps,levels", [("narrow", 20, "gfsk"), ("none", 10, "fsk"), ("none", 40, "fsk"), ("wide", 10, "fsk"), ("none", 5, "gfsk")])
+def test_demod_variants(ctx, oracle, rrc, sps, levels):
+    """NXDN-style narrow RRC + sps 20, and the 2-level slicer at sps 10 / 40 (D-Star / POCSAG settings), +invert."""
+    rng = np.random.default_rng(sps)
+    n = 30000
+    if levels == "fsk":
+        b = rng.integers(0, 2, n // sps + 1)
+        x = (np.repeat(b * 2.0 - 1, sps)[:n] * 0.4 + rng.normal(0, 0.08, n)).astype(np.float32)
+    else:
+        s = rng.integers(0, 4, n // sps + 1)
+        x = synth.shape(s, sps=sps)[:n] + rng.normal(0, 0.02, n).astype(np.float32)
+    x = np.stack([x, np.roll(x, 3) * 0.5 + 0.1]).astype(np.float32)
+    for invert in ([False, True] if levels == "fsk" else [False]):
+        ref = oracle.chain(x, rrc={"none": 0, "wide": 1, "narrow": 2}[rrc], levels=2 if levels == "fsk" else 4,
+                           invert=invert, sps=sps, proto=0)
+        for chunks in ([n], [777, 4096]):
+            res = run_engine(ctx, x, "none", chunks, rrc=rrc, demod=levels, sps=sps, invert=invert)
+            assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, 2, "%s sps%d" % (rrc, sps))
+
+
+def test_timing_steps_and_flt_min_quirk(ctx, oracle):
+    """Sampling-clock offset forces +-1 timing steps; an all-negative signal keeps max at FLT_MIN (gfsk:111)."""
+    rng = np.random.default_rng(1)
+    s = rng.integers(0, 4, 3000)
+    base = synth.shape(s)
+    t = np.arange(len(base))
+    fast = np.interp(t * 1.0004, t, base).astype(np.float32)       # +400 ppm
+    slow = np.interp(t * 0.9996, t, base).astype(np.float32)
+    neg = (base - 1.0).astype(np.float32)
+    x = np.stack([fast, slow, neg])
+    ref = oracle.chain(x, proto=0)
+    res = run_engine(ctx, x, "none", [x.shape[1]])
+    assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, 3)
+    res = run_engine(ctx, x, "none", [997])
+    assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, 3)
+    # the drifting channels really did step: symbol counts differ from n/10
+    assert int(ref["sym_count"][0]) != int(ref["sym_count"][1])
+
+
+def test_tiny_and_empty_pushes(ctx, oracle):
+    x = make_channels("dmr", [21], 8)
+    ref = oracle.chain(x, proto=1)
+    res = run_engine(ctx, x, "dmr", [1, 2, 3, 11, 12, 13, 0 + 80, 81, 5000])
+    assert_matches_oracle(res, ref, 1)
+
+
+def test_sync_loss_and_reacquire(ctx, oracle):
+    """Noise burst in the middle: FramePhase falls back to SyncPhase and re-acquires (dmr_phase.cpp:183-186)."""
+    for proto in ("dmr", "ysf"):
+        x = make_channels(proto, [31, 32], 70 if proto == "dmr" else 20, impair=False)
+        rng = np.random.default_rng(0)
+        n = x.shape[1]
+        x[:, n // 4: n // 4 + n // 2] = rng.normal(0, 0.3, (2, n // 2)).astype(np.float32)
+        ref = oracle.chain(x, proto=1 if proto == "dmr" else 2)
+        res = run_engine(ctx, x, proto, [6000])
+        assert_matches_oracle(res, ref, 2, proto)
+        types = set(res["events"][0]["type"].tolist())
+        assert (3 in types) or (20 in types)          # a META_RESET happened
+
+
+def test_dmr_slot_filter(ctx, oracle):
+    x = make_channels("dmr", [41, 43], 40)
+    for filt in (1, 2, 3, 0):
+        ref = oracle.chain(x, proto=1, slot_filter=filt)
+        res = run_engine(ctx, x, "dmr", [x.shape[1]], slot_filter=filt)
+        assert_matches_oracle(res, ref, 2, "filter %d" % filt)
+
+
+def test_decoder_only_engine(ctx, oracle):
+    """push_symbols: the decoder stage alone, fed dibits (what dmr_decoder sees on its stdin)."""
+    from digiham_amd import api
+    for proto in ("dmr", "ysf"):
+        s = [synth.dmr_stream(51, 20), synth.dmr_stream(52, 20)] if proto == "dmr" else [synth.ysf_stream(53, 6), synth.ysf_stream(54, 6)]
+        n = min(len(a) for a in s)
+        syms = np.stack([a[:n] for a in s])
+        eng = api.Engine(2, n, rrc="none", demod="none", proto=proto, ctx=ctx)
+        got_f, got_e = [[], []], [[], []]
+        for lo in range(0, n, 1000):
+            part = np.ascontiguousarray(syms[:, lo:lo + 1000])
+            eng.push_symbols(part, np.full(2, part.shape[1], np.uint32))
+            f, fc = eng.frames(); e, ec = eng.events()
+            for b in range(2):
+                got_f[b].append(f[b, :fc[b]].copy()); got_e[b].append(e[b, :ec[b]].copy())
+        for b in range(2):
+            d = oracle.Decoder(proto)
+            o, ev = d.process(syms[b])
+            assert (np.concatenate(got_f[b]) == o).all()
+            assert np.concatenate(got_e[b]).tobytes() == ev.tobytes()

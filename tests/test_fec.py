@@ -1,0 +1,106 @@
+"""FEC kernels (C ABI) against the reference-generated golden vectors and the oracle.
+
+Each test runs twice: on the CPU wave emulation of the kernel bodies (CPU tier) and, with -m gpu,
+through libdigiham_amd.so on the MI355X.  Bit-exact is the bar.
+"""
+import numpy as np
+import pytest
+
+from common import CODES, sha
+
+
+@pytest.mark.parametrize("code,bits", [c for c in CODES if c[1] <= 20])
+def test_block_codes_exhaustive(ctx, golden, code, bits):
+    h = golden["hashes"]["codes"][code]
+    cw, ok = ctx.block_decode(code, np.arange(1 << bits, dtype=np.uint32))
+    assert int(ok.sum()) == h["n_ok"]
+    assert sha(cw.astype(np.uint32), ok) == h["sha256_all"]
+
+
+def test_golay_24_12_strided(ctx, golden):
+    h = golden["hashes"]["codes"]["golay_24_12"]
+    cw, ok = ctx.block_decode("golay_24_12", np.arange(0, 1 << 24, 16, dtype=np.uint32))
+    assert sha(cw.astype(np.uint32), ok) == h["stride16_sha256"]
+
+
+@pytest.mark.gpu
+def test_golay_24_12_exhaustive_gpu(gpu_ctx, golden):
+    """All 2^24 words: maximum size of the domain, hash of (corrected words, ok flags) from the reference."""
+    h = golden["hashes"]["codes"]["golay_24_12"]
+    cw, ok = gpu_ctx.block_decode("golay_24_12", np.arange(1 << 24, dtype=np.uint32))
+    assert int(ok.sum()) == h["n_ok"]
+    assert sha(cw.astype(np.uint32), ok) == h["sha256_all"]
+
+
+def test_bptc_golden(ctx, golden):
+    g = golden["fec"]
+    out, ok = ctx.bptc_196_96(g["bptc_in"])
+    assert (ok == g["bptc_ok"]).all()
+    assert (out == g["bptc_out"]).all()
+
+
+@pytest.mark.parametrize("nd", [100, 180])
+def test_trellis_golden(ctx, golden, nd):
+    g = golden["fec"]
+    out, metric = ctx.trellis(g["trellis%d_in" % nd], nd)
+    assert (metric == g["trellis%d_metric" % nd]).all()
+    assert (out == g["trellis%d_out" % nd]).all()
+
+
+def test_trellis_ragged_sizes_vs_oracle(ctx, oracle):
+    """sizes that are not multiples of 4/8 dibits and batch sizes that do not fill a wavefront."""
+    rng = np.random.default_rng(11)
+    for nd, n in ((1, 3), (7, 5), (37, 9), (99, 1), (192, 6)):
+        x = rng.integers(0, 256, (n, (nd + 3) // 4), dtype=np.uint8)
+        if nd % 4:
+            x[:, -1] &= (0xFF << (2 * (4 - nd % 4))) & 0xFF
+        o1, m1 = ctx.trellis(x, nd)
+        o2, m2 = oracle.trellis(x, nd)
+        assert (o1 == o2).all() and (m1 == m2).all(), nd
+
+
+def test_trellis_encode_noise_decode(ctx, oracle):
+    """Property: a valid codeword with <= 2 well-separated channel errors decodes to the message, metric = #errors."""
+    rng = np.random.default_rng(5)
+    nd = 100
+    bits = rng.integers(0, 256, (64, 13), dtype=np.uint8)
+    bits[:, -1] &= 0xF0
+    bits[:, 12] = 0          # 4 tail zeros + padding
+    enc = np.stack([oracle.trellis_encode(b, nd) for b in bits])
+    noisy = enc.copy()
+    for r in range(len(noisy)):
+        for bp in (17, 120)[: r % 3]:
+            noisy[r, bp // 8] ^= 0x80 >> (bp % 8)
+    out, metric = ctx.trellis(noisy, nd)
+    assert (out[:, :12] == bits[:, :12]).all()
+    assert (metric == np.array([r % 3 for r in range(len(noisy))])).all()
+
+
+def test_crc_whitening_golden(ctx, golden):
+    g = golden["fec"]
+    for cnt in (4, 10, 20):
+        assert (ctx.crc16(g["crc_in"], cnt) == g["crc%d" % cnt]).all()
+    for nb in (100, 104, 160):
+        k = (nb + 7) // 8
+        assert (ctx.whitening(g["crc_in"], nb)[:, :k] == g["whiten%d" % nb]).all()
+
+
+def test_empty_batches(ctx):
+    cw, ok = ctx.block_decode("golay_20_8", np.zeros(0, np.uint32))
+    assert cw.size == 0 and ok.size == 0
+    out, ok = ctx.bptc_196_96(np.zeros((0, 25), np.uint8))
+    assert out.shape == (0, 12)
+
+
+def test_dvfilter_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(9)
+    x = np.stack([rng.normal(0, 9000, 4000).clip(-32768, 32767),
+                  20000 * np.sin(np.arange(4000) * 0.3),
+                  np.full(4000, 32767.0), rng.integers(-32768, 32768, 4000)]).astype(np.int16)
+    ref = np.stack([oracle.DvFilter().process(r) for r in x])
+    y, st = ctx.dvfilter(x)
+    assert (y == ref).all()
+    # state carry: two halves == one run
+    y1, st = ctx.dvfilter(x[:, :1500])
+    y2, st = ctx.dvfilter(x[:, 1500:], st)
+    assert (np.concatenate([y1, y2], axis=1) == ref).all()
