@@ -93,6 +93,13 @@ def load(path=None):
     if not os.path.exists(p):
         raise RuntimeError("digiham_amd: %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime of the process, so it has to
+    # be loaded before this library's NEEDED entry is resolved (two HIP runtimes in one process cannot see
+    # each other's devices, streams or allocations).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = declare(C.CDLL(p))
     if path is None:
         _LIB = L

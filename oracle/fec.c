@@ -127,6 +127,13 @@ static blockcode C_G208  = { 20, 8, 3, P_G2412 + 4 };
 static blockcode C_G2412 = { 24, 12, 3, P_G2412 };
 static blockcode C_QR    = { 16, 7, 2, P_QR };
 
+/* The correction lists are built once when the library is loaded, so the decoders are safe to call
+ * from the worker threads of pipe.c (bc_init itself is not re-entrant). */
+__attribute__((constructor)) static void orc_fec_init(void) {
+    bc_init(&C_H74); bc_init(&C_H139); bc_init(&C_H1511); bc_init(&C_H1611);
+    bc_init(&C_G208); bc_init(&C_G2412); bc_init(&C_QR);
+}
+
 /* hamming_7_4.c:56-72 */
 bool orc_hamming_7_4(uint8_t* data) { uint32_t d = *data; bool r = bc_decode(&C_H74, &d); *data = (uint8_t) d; return r; }
 /* hamming_13_9.c:70-84 */
