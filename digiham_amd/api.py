@@ -111,6 +111,13 @@ class Context:
         _check(self.lib.dh_whitening(self.mem.ptr(d), self.mem.ptr(out), stride, n_bits, n, self.mem.stream()), "dh_whitening", self.lib)
         return self.mem.to_numpy(out)
 
+    def debug_div_gain(self, x, narrow=False):
+        d = self.mem.from_numpy(np.ascontiguousarray(x, np.float32).ravel())
+        out = self.mem.zeros((d.shape[0],), np.float32)
+        _check(self.lib.dh_debug_div_gain(self.mem.ptr(d), self.mem.ptr(out), d.shape[0], int(narrow), self.mem.stream()),
+               "dh_debug_div_gain", self.lib)
+        return self.mem.to_numpy(out)
+
     def dvfilter(self, x, state=None):
         """x: int16 [B][n] numpy; returns (y, state) with state a device array [B][22] to carry on."""
         a = np.ascontiguousarray(x, np.int16)

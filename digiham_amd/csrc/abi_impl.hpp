@@ -64,6 +64,11 @@ int dh_dvfilter_s16(const int16_t* in, int16_t* out, float* state, size_t B, siz
     return dh_be_dvfilter(in, out, state, B, stride, n, s);
 }
 
+int dh_debug_div_gain(const float* in, float* out, size_t n, int narrow, void* s) {
+    if ((!in || !out) && n) return DH_EINVAL;
+    return dh_be_div_gain(in, out, n, narrow, s);
+}
+
 int dh_engine_create(const dh_engine_config* cfg, dh_engine** out) {
     if (!cfg || !out) return DH_EINVAL;
     *out = nullptr;

@@ -14,8 +14,9 @@
 // the next block, so inside one block every symbol window position is known up front:
 //   start[k] = p + (k - k0)*sps + (k0 == 0 && k > 0 ? pending_offset : 0)
 // Lanes take symbols; the 100-entry sliding AGC min/max becomes
-//   min_k = min( old ring entries outside [k0..k], new entries k0..k )
-// and the per-phase variance runs on `sps` lanes at the end of the block.
+//   min_k = min( prefix-min over {old[0..k0), new[k0..k]}, suffix-min over old(k..99] )
+// (two wave scans: min/max are exact in any order), and the per-phase variance runs on `sps`
+// lanes at the end of the block.
 #pragma once
 
 #include "dh_portable.hpp"
@@ -50,22 +51,22 @@ struct DhDspParams {
     int32_t levels, invert;                            // 4 = GFSK, 2 = FSK
     uint32_t nz;                                       // FIR order (0 = no RRC stage)
     int32_t fast;                                      // 1 = FMA FIR
-    double gain; float inv_gain;
+    double gain, rgain; float inv_gain;                // rgain = 1/gain rounded to double
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
 };
 
 DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + DH_TAIL_MAX; }
 
-// LDS block of one wavefront.  xbuf is padded one word per 16 so that the FIR's per-lane
-// sliding windows (stride 16 words between lanes) hit 32 different banks.
+// LDS block of one wavefront.  `xf` holds the raw-sample window during the FIR (padded one word
+// per 16 so that the per-lane sliding windows, 16 words apart, hit 32 different banks) and is then
+// overwritten in place by the filtered samples of the run.
 #define DH_XPAD(i) ((i) + ((i) >> 4))
+#define DH_SCAN_N 128
 struct DhDspShared {
-    float xbuf[DH_XPAD(DH_FTILE + DH_MAX_NZ) + 1];
-    float fbuf[DH_FTILE + 8];
-    float vol_old[DH_VOLUME_RB_SIZE];                  // ring content before the current run
-    float vol_new[DH_VOLUME_RB_SIZE];                  // entries written by the current run
-    float mn_pre[DH_VOLUME_RB_SIZE], mx_pre[DH_VOLUME_RB_SIZE];   // running min/max over new[k0..k]
-    float mn_suf[DH_VOLUME_RB_SIZE + 1], mx_suf[DH_VOLUME_RB_SIZE + 1];   // min/max over old(k..99]
+    float xf[DH_XPAD(DH_FTILE + DH_MAX_NZ) + 1];
+    float vol_old[DH_SCAN_N];                          // ring content before the current run (+ identity padding)
+    float vol_new[DH_SCAN_N];                          // entries written by the current run
+    float mn[DH_SCAN_N], mx[DH_SCAN_N];                // AGC window min / max per symbol of the block
     float sum[DH_VOLUME_RB_SIZE];                      // mid-symbol window sums of the current run
     double variance[DH_MAX_SPS];
     // variance ring follows (100 * sps floats), sized at launch
@@ -76,32 +77,118 @@ DH_HD size_t dh_dsp_shared_bytes(uint32_t sps) {
     return sizeof(DhDspShared) + sizeof(float) * (size_t) (DH_VARIANCE_SYMBOLS * sps);
 }
 
+// per-lane values that must survive a barrier: registers on the GPU, [lane] arrays in the harness
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_LANE_ARRAY(type, name, n) type name[n]
+#define DH_LA(name, lane) name
+#else
+#define DH_LANE_ARRAY(type, name, n) type name[DH_WAVE][n]
+#define DH_LA(name, lane) name[lane]
+#endif
+
 // ---------------------------------------------------------------------------------------------
-// FIR pass: lane computes outputs [lane*16, lane*16+16) of the tile from the padded LDS window.
-//   x[e] = S.xbuf[DH_XPAD(e)] holds input sample (tile_start - NZ + e);  out[j] = sum_i c[i]*x[j+i]
+// (float)((double)acc / gain), the reference's `sum / gain` with a double gain, without paying an
+// IEEE double division per sample: q' = fl64(acc * fl64(1/gain)) is within 3 ulp of fl64(acc / gain);
+// both round to the same float unless a float rounding boundary (mantissa bits 28..0 = 0x10000000)
+// lies within that distance, or the result is a float subnormal.  Only then (p ~ 2e-8) the real
+// division runs.  dh_div_gain_exact() is what the fast path must always equal (tested over 2^31
+// operands in tests/test_numerics.py).
+DH_HD float dh_div_gain_exact(float acc, double gain) { return (float) ((double) acc / gain); }
+
+// fast part: returns (float) q' and sets `suspect` when the exact division has to decide
+DH_HD float dh_div_gain_fast(float acc, double rgain, bool& suspect) {
+    const double q = (double) acc * rgain;
+    union { double d; uint64_t u; } b; b.d = q;
+    const uint32_t m = (uint32_t) b.u & 0x1FFFFFFFu;
+    const uint32_t e = (uint32_t) (b.u >> 52) & 0x7FFu;
+    const bool near_tie = (m - 0x0FFFFFFCu) <= 8u;                  // within 4 ulp(double) of a float midpoint
+    const bool odd_range = (e < 1023u - 125u && (b.u << 1) != 0) || e > 1023u + 126u;   // float subnormal / overflow / nan
+    suspect = near_tie || odd_range;
+    return (float) q;
+}
+
+DH_HD float dh_div_gain(float acc, double gain, double rgain) {
+    bool suspect;
+    const float y = dh_div_gain_fast(acc, rgain, suspect);
+    return suspect ? dh_div_gain_exact(acc, gain) : y;
+}
+
+// loop-invariant wave-uniform values that should live in VGPRs rather than compete for the 102 SGPRs
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_TO_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define DH_TO_VGPR(x) ((void) 0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// FIR pass: lane computes outputs [base, base+16) of the tile from the padded LDS window.
+//   x[e] = xs[DH_XPAD(e)] holds input sample (tile_start - NZ + e);  out[j] = sum_i c[i]*x[base+j+i]
+//
+// Register layout chosen for packed fp32 (v_pk_mul_f32 / v_pk_add_f32 work on aligned VGPR pairs):
+// the 16 outputs are two groups of 8, and output j of group A shares a register pair with output j
+// of group B.  The sliding window then holds pairs (x[t], x[t+8]); sliding by one tap renames
+// pairs instead of re-aligning them, and one ds_read2_b32 fills a pair.  Straight-line after
+// unrolling: 8 window pairs + 8 accumulator pairs + the taps (one VGPR each).
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+typedef float dh_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dh_f2 dh_f2_make(float a, float b) { dh_f2 v; v.x = a; v.y = b; return v; }
+template <bool FAST> __device__ __forceinline__ dh_f2 dh_f2_mac(float c, dh_f2 w, dh_f2 acc) {
+    if (FAST) return dh_f2_make(__builtin_fmaf(c, w.x, acc.x), __builtin_fmaf(c, w.y, acc.y));
+    const dh_f2 p = c * w;                                 // v_pk_mul_f32, rounded
+    return acc + p;                                        // v_pk_add_f32, rounded (-ffp-contract=off)
+}
+#else
+struct dh_f2 { float x, y; };
+inline dh_f2 dh_f2_make(float a, float b) { dh_f2 v; v.x = a; v.y = b; return v; }
+template <bool FAST> inline dh_f2 dh_f2_mac(float c, dh_f2 w, dh_f2 acc) {
+    if (FAST) return dh_f2_make(__builtin_fmaf(c, w.x, acc.x), __builtin_fmaf(c, w.y, acc.y));
+    const float px = c * w.x, py = c * w.y;
+    return dh_f2_make(acc.x + px, acc.y + py);
+}
+#endif
+#define DH_FIR_H (DH_FIR_L / 2)
+
 template <int NZ, bool FAST>
-DH_HD void dh_fir_lane(const DhDspParams& P, const DhDspShared& S, int lane, float* out16) {
-    float acc[DH_FIR_L];
+DH_HD void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
+    // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
+    const float* xs = xs_all + (DH_FIR_L + 1) * lane;
+#define DH_XL(e) xs[(e) + ((e) >> 4)]
+    dh_f2 accp[DH_FIR_H], w[DH_FIR_H];
 #pragma unroll
-    for (int j = 0; j < DH_FIR_L; j++) acc[j] = 0.0f;
-    const int base = lane * DH_FIR_L;
-#pragma unroll
-    for (int t = 0; t < NZ + DH_FIR_L; t++) {
-        const float x = S.xbuf[DH_XPAD(base + t)];
-#pragma unroll
-        for (int j = 0; j < DH_FIR_L; j++) {
-            const int i = t - j;                       // tap index
-            if (i >= 0 && i <= NZ) {
-                const float c = P.taps[i <= NZ / 2 ? i : NZ - i];
-                if (FAST) acc[j] = __builtin_fmaf(c, x, acc[j]);
-                else acc[j] = acc[j] + c * x;          // separately rounded (-ffp-contract=off)
-            }
-        }
+    for (int j = 0; j < DH_FIR_H; j++) {
+        accp[j] = dh_f2_make(0.0f, 0.0f);
+        w[j] = dh_f2_make(DH_XL(j), DH_XL(j + DH_FIR_H));
     }
 #pragma unroll
-    for (int j = 0; j < DH_FIR_L; j++) {
-        if (FAST) out16[j] = acc[j] * P.inv_gain;
-        else out16[j] = (float) ((double) acc[j] / P.gain);
+    for (int i = 0; i <= NZ; i++) {
+        const float c = taps[i <= NZ / 2 ? i : NZ - i];
+#pragma unroll
+        for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac<FAST>(c, w[j], accp[j]);
+        if (i < NZ) {
+#pragma unroll
+            for (int j = 0; j < DH_FIR_H - 1; j++) w[j] = w[j + 1];
+            w[DH_FIR_H - 1] = dh_f2_make(DH_XL(DH_FIR_H + i), DH_XL(2 * DH_FIR_H + i));
+        }
+    }
+    float acc[DH_FIR_L];
+#pragma unroll
+    for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < DH_FIR_L; j++) out16[j] = acc[j] * inv_gain;
+    } else {
+        uint32_t suspects = 0;
+#pragma unroll
+        for (int j = 0; j < DH_FIR_L; j++) {
+            bool s;
+            out16[j] = dh_div_gain_fast(acc[j], rgain, s);
+            suspects |= (s ? 1u : 0u) << j;
+        }
+        if (suspects) {                                   // ~2e-8 per sample: one copy of the IEEE division, not sixteen
+#pragma unroll 1
+            for (int j = 0; j < DH_FIR_L; j++)
+                if ((suspects >> j) & 1u) out16[j] = dh_div_gain_exact(acc[j], gain);
+        }
     }
 }
 
@@ -109,6 +196,68 @@ DH_HD void dh_fir_lane(const DhDspParams& P, const DhDspShared& S, int lane, flo
 DH_HD float dh_virtual_sample(const float* tail, uint32_t tc, const float* in, uint32_t idx) {
     return idx < tc ? tail[idx] : in[idx - tc];
 }
+
+// ---------------------------------------------------------------------------------------------
+// AGC window extremes for the symbols k0..k1-1 of the current block (calibrateAudio,
+// gfsk_demodulator.cpp:109-116): S.mn[k] / S.mx[k] = min / max over the volume ring as it stands
+// right after symbol k was written.  The reference seeds min with FLT_MAX and max with FLT_MIN
+// (sic: the smallest positive float), which are exactly the identities used for padding here.
+#define DH_FLT_MAX 3.402823466e+38f
+#define DH_FLT_MIN 1.175494351e-38f
+DH_HD float dh_fmin_(float a, float b) { return b < a ? b : a; }
+DH_HD float dh_fmax_(float a, float b) { return b > a ? b : a; }
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// lane l owns ring slots 2l and 2l+1; inclusive prefix scan with __shfl_up, exclusive suffix scan with
+// __shfl_down (ds_bpermute: no LDS traffic, no barriers)
+__device__ __forceinline__ void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
+    const int lane = (int) threadIdx.x;
+    const uint32_t e0 = 2u * (uint32_t) lane, e1 = e0 + 1u;
+    // prefix source: old below k0, new in [k0, k1), identity above
+    const float c0 = e0 < k0 ? S.vol_old[e0] : S.vol_new[e0];
+    const float c1 = e1 < k0 ? S.vol_old[e1] : S.vol_new[e1];
+    const bool v0 = e0 < k1, v1 = e1 < k1;
+    const float pmn0 = v0 ? c0 : DH_FLT_MAX, pmn1 = v1 ? c1 : DH_FLT_MAX;
+    const float pmx0 = v0 ? c0 : DH_FLT_MIN, pmx1 = v1 ? c1 : DH_FLT_MIN;
+    float pmn = dh_fmin_(pmn0, pmn1), pmx = dh_fmax_(pmx0, pmx1);
+    // suffix source: the old ring (slots >= 100 hold the identity, see the staging code)
+    const float o0 = S.vol_old[e0], o1 = S.vol_old[e1];
+    const float omn0 = e0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MAX, omn1 = e1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MAX;
+    const float omx0 = e0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MIN, omx1 = e1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MIN;
+    float smn = dh_fmin_(omn0, omn1), smx = dh_fmax_(omx0, omx1);
+#pragma unroll
+    for (int d = 1; d < DH_WAVE; d <<= 1) {
+        const float a = __shfl_up(pmn, d), b = __shfl_up(pmx, d);
+        const float c = __shfl_down(smn, d), e = __shfl_down(smx, d);
+        if (lane >= d) { pmn = dh_fmin_(pmn, a); pmx = dh_fmax_(pmx, b); }
+        if (lane + d < DH_WAVE) { smn = dh_fmin_(smn, c); smx = dh_fmax_(smx, e); }
+    }
+    // exclusive parts from the neighbours
+    float epmn = __shfl_up(pmn, 1), epmx = __shfl_up(pmx, 1);
+    float esmn = __shfl_down(smn, 1), esmx = __shfl_down(smx, 1);
+    if (lane == 0) { epmn = DH_FLT_MAX; epmx = DH_FLT_MIN; }
+    if (lane == DH_WAVE - 1) { esmn = DH_FLT_MAX; esmx = DH_FLT_MIN; }
+    // slot e0: prefix = excl + own e0; suffix (exclusive of e0) = own e1 + later lanes
+    const float mn0 = dh_fmin_(dh_fmin_(epmn, pmn0), dh_fmin_(omn1, esmn));
+    const float mx0 = dh_fmax_(dh_fmax_(epmx, pmx0), dh_fmax_(omx1, esmx));
+    // slot e1: prefix = inclusive through e1; suffix = later lanes only
+    const float mn1 = dh_fmin_(pmn, esmn);
+    const float mx1 = dh_fmax_(pmx, esmx);
+    S.mn[e0] = mn0; S.mx[e0] = mx0; S.mn[e1] = mn1; S.mx[e1] = mx1;
+}
+#else
+inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
+    // plain sequential statement of the same thing (harness only)
+    float pmn = DH_FLT_MAX, pmx = DH_FLT_MIN;
+    for (uint32_t j = 0; j < k0; j++) { pmn = dh_fmin_(pmn, S.vol_old[j]); pmx = dh_fmax_(pmx, S.vol_old[j]); }
+    for (uint32_t k = k0; k < k1; k++) {
+        pmn = dh_fmin_(pmn, S.vol_new[k]); pmx = dh_fmax_(pmx, S.vol_new[k]);
+        float smn = DH_FLT_MAX, smx = DH_FLT_MIN;
+        for (uint32_t j = k + 1; j < DH_VOLUME_RB_SIZE; j++) { smn = dh_fmin_(smn, S.vol_old[j]); smx = dh_fmax_(smx, S.vol_old[j]); }
+        S.mn[k] = dh_fmin_(pmn, smn); S.mx[k] = dh_fmax_(pmx, smx);
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
@@ -129,10 +278,18 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const uint32_t nv = tc + P.n;                       // length of the virtual input stream
     const uint32_t nf = nv >= NZ ? nv - NZ : 0u;        // filtered samples available this push
     DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < DH_VOLUME_RB_SIZE; j += DH_WAVE) S.vol_old[j] = st[DH_ST_VOL + j];
+        for (uint32_t j = lane; j < DH_SCAN_N; j += DH_WAVE) {
+            S.vol_old[j] = j < DH_VOLUME_RB_SIZE ? st[DH_ST_VOL + j] : 0.0f;
+            S.vol_new[j] = 0.0f;
+        }
         for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) S.var_rb[j] = st[DH_ST_VAR + j];
     }
     DH_BARRIER();
+
+    // FIR taps: wave-uniform, loop-invariant, one VGPR each (41 for the wide filter)
+    float tv[NZ / 2 + 1];
+#pragma unroll
+    for (int i = 0; i <= NZ / 2; i++) { tv[i] = P.taps[i]; DH_TO_VGPR(tv[i]); }
 
     uint32_t p = 0;                                     // read position in the filtered stream
     uint32_t nsym = 0;
@@ -141,49 +298,61 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 
     for (;;) {
         // ---- run planning (wave-uniform): symbols k0 .. k0+m-1 of the current variance block.
-        // A symbol is produced iff available > sps + 1 (gfsk_demodulator.cpp:18-22).
+        // A symbol at filtered position s is produced iff nf - s > sps + 1 (gfsk_demodulator.cpp:18-22);
+        // s_0 = p, s_q = p + q*sps + step_off for q >= 1.
         const int32_t step_off = (k0 == 0) ? off : 0;   // applied after the first symbol of a block
         uint32_t m = 0;
         {
             uint32_t lim = dh_min<uint32_t>(DH_VARIANCE_SYMBOLS - k0, max_run);
-            if (lim > P.sym_cap - nsym) { lim = P.sym_cap - nsym; }
-            for (uint32_t q = 0; q < lim; q++) {
-                const uint32_t s = p + q * sps + (q > 0 ? (uint32_t) step_off : 0u);
-                if (nf > s && nf - s > sps + 1) m = q + 1; else break;
+            lim = dh_min<uint32_t>(lim, P.sym_cap - nsym);
+            const int64_t room = (int64_t) nf - (int64_t) p - (int64_t) sps - 2;     // >= 0  <=>  symbol 0 fits
+            if (room >= 0 && lim > 0) {
+                const int64_t r1 = room - step_off;                                   // q*sps <= r1 for q >= 1
+                const uint32_t qmax = r1 >= (int64_t) sps ? (uint32_t) (r1 / sps) : 0u;
+                m = dh_min<uint32_t>(lim, qmax + 1u);
             }
             if (m == 0) {
-                if (lim == 0 && nf > p && nf - p > sps + 1) overflow = true;
+                if (lim == 0 && room >= 0) overflow = true;
                 break;
             }
         }
         const uint32_t last_start = p + (m - 1) * sps + (m > 1 ? (uint32_t) step_off : 0u);
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
 
-        // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window
+        // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window (zeros beyond)
         DH_FOR_LANES(lane) {
-            for (uint32_t e = lane; e < need + NZ; e += DH_WAVE)
-                S.xbuf[DH_XPAD(e)] = dh_virtual_sample(tail, tc, in, p + e);
-            if (NZ > 0) {
-                // lanes past the end of the run still read their whole window: keep it defined
-                for (uint32_t e = need + NZ + lane; e < DH_FTILE + NZ; e += DH_WAVE) S.xbuf[DH_XPAD(e)] = 0.0f;
-            }
+            for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
+                S.xf[DH_XPAD(e)] = e < need + NZ ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
         }
         DH_BARRIER();
 
-        // ---- P2: FIR (or pass-through when there is no RRC stage)
-        DH_FOR_LANES(lane) {
-            if (NZ > 0) {
+        // ---- P2: FIR into registers, then (after every lane has read its window) back into S.xf[0..need)
+        if (NZ > 0) {
+            DH_LANE_ARRAY(float, fo, DH_FIR_L);
+            DH_FOR_LANES(lane) {
+                if ((uint32_t) (lane * DH_FIR_L) < need)
+                    dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
+            }
+            DH_BARRIER();
+            DH_FOR_LANES(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need) {
-                    float o[DH_FIR_L];
-                    dh_fir_lane<NZ, FAST>(P, S, lane, o);
 #pragma unroll
-                    for (int j = 0; j < DH_FIR_L; j++) S.fbuf[lane * DH_FIR_L + j] = o[j];
+                    for (int j = 0; j < DH_FIR_L; j++) S.xf[lane * DH_FIR_L + j] = DH_LA(fo, lane)[j];
                 }
-            } else {
-                for (uint32_t e = lane; e < need; e += DH_WAVE) S.fbuf[e] = S.xbuf[DH_XPAD(e)];
+            }
+        } else {
+            // no RRC stage: un-pad in place (ascending order, destination index <= source index)
+            DH_LANE_ARRAY(float, cp, DH_FIR_L);
+            DH_FOR_LANES(lane) {
+                for (int j = 0; j < DH_FIR_L; j++) DH_LA(cp, lane)[j] = S.xf[DH_XPAD(lane * DH_FIR_L + j)];
+            }
+            DH_BARRIER();
+            DH_FOR_LANES(lane) {
+                for (int j = 0; j < DH_FIR_L; j++) S.xf[lane * DH_FIR_L + j] = DH_LA(cp, lane)[j];
             }
         }
         DH_BARRIER();
+        const float* fbuf = S.xf;
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
         DH_FOR_LANES(lane) {
@@ -192,7 +361,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
                 float sum = 0.0f, volume_sum = 0.0f;
                 for (uint32_t i = 0; i < sps; i++) {
-                    const float value = S.fbuf[s + i];
+                    const float value = fbuf[s + i];
                     if (i >= P.lo && i < P.hi) sum += value;
                     volume_sum += value;
                     S.var_rb[k * sps + i] = value;
@@ -203,39 +372,19 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         DH_BARRIER();
 
-        // ---- P4: sliding AGC min/max (calibrateAudio, gfsk_demodulator.cpp:109-116).
-        // Four lanes run the four order-independent scans; min/max are exact in any order.
-        const float FLT_MAX_ = 3.402823466e+38f, FLT_MIN_ = 1.175494351e-38f;   // sic: max seeds with FLT_MIN
-        DH_FOR_LANES(lane) {
-            const uint32_t k1 = k0 + m;                // one past the last symbol of the run
-            if (lane == 0) {
-                float c = FLT_MAX_;                    // old entries below k0 are in every window
-                for (uint32_t j = 0; j < k0; j++) c = S.vol_old[j] < c ? S.vol_old[j] : c;
-                for (uint32_t j = k0; j < k1; j++) { c = S.vol_new[j] < c ? S.vol_new[j] : c; S.mn_pre[j] = c; }
-            } else if (lane == 1) {
-                float c = FLT_MIN_;
-                for (uint32_t j = 0; j < k0; j++) c = S.vol_old[j] > c ? S.vol_old[j] : c;
-                for (uint32_t j = k0; j < k1; j++) { c = S.vol_new[j] > c ? S.vol_new[j] : c; S.mx_pre[j] = c; }
-            } else if (lane == 2) {
-                float c = FLT_MAX_;
-                S.mn_suf[DH_VOLUME_RB_SIZE] = c;
-                for (int j = DH_VOLUME_RB_SIZE - 1; j > (int) k0; j--) { c = S.vol_old[j] < c ? S.vol_old[j] : c; S.mn_suf[j] = c; }
-            } else if (lane == 3) {
-                float c = FLT_MIN_;
-                S.mx_suf[DH_VOLUME_RB_SIZE] = c;
-                for (int j = DH_VOLUME_RB_SIZE - 1; j > (int) k0; j--) { c = S.vol_old[j] > c ? S.vol_old[j] : c; S.mx_suf[j] = c; }
-            }
-        }
+        // ---- P4: sliding AGC min/max as two wave scans
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        dh_agc_scan(S, k0, k0 + m);
+#else
+        dh_agc_scan(S, k0, k0 + m);
+#endif
         DH_BARRIER();
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
         DH_FOR_LANES(lane) {
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
-                const float a = S.mn_pre[k], b = S.mn_suf[k + 1];
-                const float mn = b < a ? b : a;
-                const float c = S.mx_pre[k], d = S.mx_suf[k + 1];
-                const float mx = d > c ? d : c;
+                const float mn = S.mn[k], mx = S.mx[k];
                 const float center = (mx + mn) / 2.0f;
                 const float average = S.sum[q] / (float) (P.hi - P.lo);
                 uint8_t sym;
@@ -250,7 +399,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 syms[nsym + q] = sym;
             }
         }
-        DH_BARRIER();
 
         // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
         int32_t new_off = 0;
@@ -259,9 +407,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_FOR_LANES(lane) {
                 if ((uint32_t) lane < sps) {
                     float total = 0.0f;
+#pragma unroll 10
                     for (int k = 0; k < DH_VARIANCE_SYMBOLS; k++) total += S.var_rb[k * sps + lane];
                     const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
                     double dsum = 0.0;
+#pragma unroll 10
                     for (int k = 0; k < DH_VARIANCE_SYMBOLS; k++) {
                         const double diff = mean - (double) S.var_rb[k * sps + lane];
                         dsum += diff * diff;
@@ -295,11 +445,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         for (uint32_t j = lane; j < DH_VOLUME_RB_SIZE; j += DH_WAVE) st[DH_ST_VOL + j] = S.vol_old[j];
         for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) st[DH_ST_VAR + j] = S.var_rb[j];
         // tail may overlap its own source when p < tc: go through LDS
-        for (uint32_t j = lane; j < new_tc && j < DH_TAIL_MAX; j += DH_WAVE) S.xbuf[j] = dh_virtual_sample(tail, tc, in, p + j);
+        for (uint32_t j = lane; j < new_tc && j < DH_TAIL_MAX; j += DH_WAVE) S.xf[j] = dh_virtual_sample(tail, tc, in, p + j);
     }
     DH_BARRIER();
     DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < new_tc && j < DH_TAIL_MAX; j += DH_WAVE) tail[j] = S.xbuf[j];
+        for (uint32_t j = lane; j < new_tc && j < DH_TAIL_MAX; j += DH_WAVE) tail[j] = S.xf[j];
         if (DH_IS_LANE0(lane)) {
             sth[DH_ST_K] = k0;
             sth[DH_ST_OFF] = (uint32_t) off;
@@ -320,7 +470,7 @@ struct DhRrcParams {
     const float* hist;                                  // [B][nz] previous inputs (zeros after reset)
     uint32_t n, n_channels, nz;
     int32_t fast;
-    double gain; float inv_gain;
+    double gain, rgain; float inv_gain;
     float taps[DH_MAX_NZ / 2 + 1];
 };
 
@@ -337,39 +487,28 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
             const uint32_t v = t0 + e;
             float x = 0.0f;
             if (e < cnt + NZ) x = v < (uint32_t) NZ ? hist[v] : in[v - NZ];
-            S.xbuf[DH_XPAD(e)] = x;
+            S.xf[DH_XPAD(e)] = x;
         }
     }
     DH_BARRIER();
-    // FIR parameters live in a DhDspParams-shaped view for dh_fir_lane
+    float tv[NZ / 2 + 1];
+#pragma unroll
+    for (int i = 0; i <= NZ / 2; i++) { tv[i] = R.taps[i]; DH_TO_VGPR(tv[i]); }
+    DH_LANE_ARRAY(float, fo, DH_FIR_L);
+    DH_FOR_LANES(lane) {
+        if ((uint32_t) (lane * DH_FIR_L) < cnt)
+            dh_fir_lane<NZ, FAST>(tv, R.gain, R.rgain, R.inv_gain, S.xf, lane, DH_LA(fo, lane));
+    }
+    DH_BARRIER();
     DH_FOR_LANES(lane) {
         if ((uint32_t) (lane * DH_FIR_L) < cnt) {
-            float acc[DH_FIR_L];
 #pragma unroll
-            for (int j = 0; j < DH_FIR_L; j++) acc[j] = 0.0f;
-            const int base = lane * DH_FIR_L;
-#pragma unroll
-            for (int t = 0; t < NZ + DH_FIR_L; t++) {
-                const float x = S.xbuf[DH_XPAD(base + t)];
-#pragma unroll
-                for (int j = 0; j < DH_FIR_L; j++) {
-                    const int i = t - j;
-                    if (i >= 0 && i <= NZ) {
-                        const float c = R.taps[i <= NZ / 2 ? i : NZ - i];
-                        if (FAST) acc[j] = __builtin_fmaf(c, x, acc[j]);
-                        else acc[j] = acc[j] + c * x;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < DH_FIR_L; j++) {
-                const float y = FAST ? acc[j] * R.inv_gain : (float) ((double) acc[j] / R.gain);
-                S.fbuf[base + j] = y;
-            }
+            for (int j = 0; j < DH_FIR_L; j++) S.xf[lane * DH_FIR_L + j] = DH_LA(fo, lane)[j];
         }
     }
     DH_BARRIER();
     DH_FOR_LANES(lane) {
-        for (uint32_t e = lane; e < cnt; e += DH_WAVE) out[t0 + e] = S.fbuf[e];     // coalesced store
+        for (uint32_t e = lane; e < cnt; e += DH_WAVE) out[t0 + e] = S.xf[e];     // coalesced store
     }
+    DH_BARRIER();
 }

@@ -18,6 +18,7 @@
 #include "../../include/digiham_amd.h"
 #include "kernels_core.hpp"
 #include "fec_tables.hpp"
+#include "rrc_taps.h"
 
 namespace {
 
@@ -31,15 +32,16 @@ int hip_fail(hipError_t e, const char* what) {
 #define HIP_TRY(expr) do { if (hip_fail((expr), #expr)) return DH_EDEVICE; } while (0)
 
 // ---------------------------------------------------------------------------------- kernels
+// second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
 template <int NZ, bool FAST>
-__global__ __launch_bounds__(DH_WAVE) void k_rrc_demod(const DhDspParams P) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : 3)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
     dh_rrc_demod_channel<NZ, FAST>(P, blockIdx.x, S);
 }
 
 template <int NZ, bool FAST>
-__global__ __launch_bounds__(DH_WAVE) void k_rrc_tile(const DhRrcParams R) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : 3)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
     dh_rrc_tile<NZ, FAST>(R, blockIdx.y, blockIdx.x, S);
@@ -115,6 +117,11 @@ __global__ void k_whitening(const uint8_t* in, uint8_t* out, size_t stride, int 
 __global__ void k_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n) {
     const size_t ch = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     if (ch < B) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
+}
+
+__global__ void k_div_gain(const float* in, float* out, size_t n, double gain, double rgain) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        out[i] = dh_div_gain(in[i], gain, rgain);
 }
 
 inline unsigned grid_for(size_t n, unsigned block) {
@@ -313,6 +320,14 @@ static int dh_be_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n
 static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n, void* stream) {
     if (!B) return DH_OK;
     hipLaunchKernelGGL(k_dvfilter, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, out, state, B, stride, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+
+static int dh_be_div_gain(const float* in, float* out, size_t n, int narrow, void* stream) {
+    if (!n) return DH_OK;
+    const double gain = narrow ? DH_RRC_NARROW_GAIN : DH_RRC_WIDE_GAIN;
+    hipLaunchKernelGGL(k_div_gain, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, in, out, n, gain, 1.0 / gain);
     HIP_TRY(hipGetLastError());
     return DH_OK;
 }

@@ -190,7 +190,7 @@ struct Engine {
         if (L.rrc && !L.fused) {
             rrcp.in = d_in; rrcp.in_stride = stride; rrcp.out = filtered; rrcp.out_stride = L.max_samples;
             rrcp.hist = rrc_hist; rrcp.n = (uint32_t) n; rrcp.n_channels = L.B; rrcp.nz = L.nz; rrcp.fast = fast;
-            fill_taps(L.rrc, rrcp.taps, &rrcp.gain); rrcp.inv_gain = (float) (1.0 / rrcp.gain);
+            fill_taps(L.rrc, rrcp.taps, &rrcp.gain); rrcp.rgain = 1.0 / rrcp.gain; rrcp.inv_gain = (float) rrcp.rgain;
             if (n) rc |= be.launch_rrc_tiles(rrcp, L.nz, fast);
             if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, L.nz, L.B);
             demod_in = filtered; demod_stride = L.max_samples;
@@ -204,7 +204,7 @@ struct Engine {
             dsp.sps = L.sps; dsp.lo = L.lo; dsp.hi = L.hi;
             dsp.levels = L.demod; dsp.invert = (L.flags & DH_FLAG_FSK_INVERT) ? 1 : 0;
             dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast;
-            if (L.fused) { fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.inv_gain = (float) (1.0 / dsp.gain); }
+            if (L.fused) { fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain; }
             rc |= be.launch_rrc_demod(dsp, dsp.nz, fast);
         }
         be.timing_mark(2);

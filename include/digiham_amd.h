@@ -183,6 +183,14 @@ int  dh_engine_push_symbols(dh_engine* e, const uint8_t* d_syms, size_t stride, 
  * ---------------------------------------------------------------------- */
 int dh_dvfilter_s16(const int16_t* d_in, int16_t* d_out, float* d_state, size_t n_channels, size_t stride, size_t n, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Diagnostics: the RRC output scaling `(float)((double)sum / gain)` of
+ * src/rrc_filter/rrc_filter.cpp:33 exactly as the FIR kernels evaluate it
+ * (reciprocal multiply + exact-division fallback near float rounding ties).
+ * d_out[i] must equal (float)((double)d_in[i] / gain) for every float.
+ * ---------------------------------------------------------------------- */
+int dh_debug_div_gain(const float* d_in, float* d_out, size_t n, int narrow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

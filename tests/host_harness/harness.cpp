@@ -13,6 +13,7 @@
 #include "../../include/digiham_amd.h"
 #include "../../digiham_amd/csrc/kernels_core.hpp"
 #include "../../digiham_amd/csrc/fec_tables.hpp"
+#include "../../digiham_amd/csrc/rrc_taps.h"
 
 namespace {
 
@@ -113,6 +114,12 @@ static int dh_be_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n
 }
 static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n, void*) {
     for (size_t ch = 0; ch < B; ch++) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
+    return 0;
+}
+
+static int dh_be_div_gain(const float* in, float* out, size_t n, int narrow, void*) {
+    const double gain = narrow ? DH_RRC_NARROW_GAIN : DH_RRC_WIDE_GAIN, rgain = 1.0 / gain;
+    for (size_t i = 0; i < n; i++) out[i] = dh_div_gain(in[i], gain, rgain);
     return 0;
 }
 

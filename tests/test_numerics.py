@@ -1,0 +1,45 @@
+"""The arithmetic contract pieces that random signals rarely exercise."""
+import numpy as np
+import pytest
+
+from digiham_amd import _taps
+
+
+def _div_ref(x, gain):
+    return (x.astype(np.float64) / gain).astype(np.float32)
+
+
+def near_tie_operands(gain, start=0x3E000000, count=1 << 26, chunk=1 << 24, ulps=2000):
+    """Floats x whose quotient x/gain lies within `ulps` ulp(double) of a float rounding tie.  Within 4 ulp the
+    kernels take the exact-division fallback; from 5 ulp on they trust the reciprocal product, so this band is
+    where a wrong error bound would show (found by scanning: the density is ~ulps * 3.7e-9 per float)."""
+    r = 1.0 / gain
+    hits = []
+    for lo in range(start, start + count, chunk):
+        x = np.arange(lo, lo + chunk, dtype=np.uint32).view(np.float32)
+        m = (x.astype(np.float64) * r).view(np.uint64) & np.uint64(0x1FFFFFFF)
+        sel = np.abs(m.astype(np.int64) - 0x10000000) <= ulps
+        if sel.any():
+            hits.append(x[sel].copy())
+    return np.concatenate(hits) if hits else np.zeros(0, np.float32)
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_gain_division_is_exactly_the_double_division(ctx, narrow):
+    """(float)((double)sum / gain) (rrc_filter.cpp:33) via reciprocal-multiply + tie fallback: bit-exact for
+    random floats of every exponent, for subnormal results, and for operands found next to a float rounding
+    tie of the quotient (which force the fallback branch)."""
+    gain = _taps.NARROW_GAIN if narrow else _taps.WIDE_GAIN
+    rng = np.random.default_rng(17)
+    bits = rng.integers(0, 1 << 32, 2_000_000, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    signal = (rng.normal(0, 1, 1_000_000) * 10.0 ** rng.uniform(-6, 3, 1_000_000)).astype(np.float32)
+    tiny = (rng.normal(0, 1, 100_000) * 1e-37).astype(np.float32)
+    ties = near_tie_operands(gain)
+    assert ties.size > 0, "scan found no near-tie operand: enlarge the scan"
+    allx = np.concatenate([x, signal, tiny, np.array([0.0, -0.0, 1.0, -1.0], np.float32), ties, -ties])
+    got = ctx.debug_div_gain(allx, narrow)
+    ref = _div_ref(allx, gain)
+    assert got.tobytes() == ref.tobytes()
+    assert ties.size > 100
