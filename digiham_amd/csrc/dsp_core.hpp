@@ -69,6 +69,7 @@ struct DhDspShared {
     float mn[DH_SCAN_N], mx[DH_SCAN_N];                // AGC window min / max per symbol of the block
     float sum[DH_VOLUME_RB_SIZE];                      // mid-symbol window sums of the current run
     double variance[DH_MAX_SPS];
+    float mean[DH_MAX_SPS];
     // variance ring follows (100 * sps floats), sized at launch
     float var_rb[1];
 };
@@ -192,6 +193,11 @@ DH_HD void dh_fir_lane(const float* taps, double gain, double rgain, float inv_g
     }
 }
 
+// four consecutive floats from a 4-byte-aligned address (global_load_dwordx4: gfx950 allows dword alignment)
+struct __attribute__((aligned(4))) dh_f4 { float x, y, z, w; };
+DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
+DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+
 // virtual input stream of a channel for this push: carried tail followed by the new samples
 DH_HD float dh_virtual_sample(const float* tail, uint32_t tc, const float* in, uint32_t idx) {
     return idx < tc ? tail[idx] : in[idx - tc];
@@ -262,11 +268,15 @@ inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
 // ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
 // once (host harness; the DH_FOR_LANES loops then iterate the lanes).
-template <int NZ, bool FAST>
+// SPS = 10 bakes the DMR / YSF samples-per-symbol (and its evaluation window 3..6) into the code so the
+// per-symbol loops unroll; SPS = 0 takes them from the parameters.
+template <int NZ, bool FAST, int SPS>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
+    static_assert(SPS == 0 || SPS == 10, "only sps 10 is specialised");
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
-    const uint32_t sps = P.sps;
+    const uint32_t sps = SPS ? (uint32_t) SPS : P.sps;
+    const uint32_t ev_lo = SPS == 10 ? 3u : P.lo, ev_hi = SPS == 10 ? 7u : P.hi;
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
     const float* in = P.in + (size_t) ch * P.in_stride;
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
@@ -320,9 +330,27 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
 
         // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window (zeros beyond)
-        DH_FOR_LANES(lane) {
-            for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
-                S.xf[DH_XPAD(e)] = e < need + NZ ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
+        // After the first run of a push the whole window comes straight from `in`: 16 B per lane per load,
+        // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
+        if (p >= tc) {
+            const float* src = in + (p - tc);
+            const uint32_t have = need + NZ;
+            DH_FOR_LANES(lane) {
+                for (uint32_t e = 4u * (uint32_t) lane; e < DH_FTILE + NZ; e += 4u * DH_WAVE) {
+                    dh_f4 v;
+                    if (e + 4u <= have) v = dh_load4_unaligned(src + e);
+                    else {
+                        v.x = e + 0u < have ? src[e + 0u] : 0.0f; v.y = e + 1u < have ? src[e + 1u] : 0.0f;
+                        v.z = e + 2u < have ? src[e + 2u] : 0.0f; v.w = e + 3u < have ? src[e + 3u] : 0.0f;
+                    }
+                    dh_store4(&S.xf[DH_XPAD(e)], v);
+                }
+            }
+        } else {
+            DH_FOR_LANES(lane) {
+                for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
+                    S.xf[DH_XPAD(e)] = e < need + NZ ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
+            }
         }
         DH_BARRIER();
 
@@ -360,9 +388,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
                 float sum = 0.0f, volume_sum = 0.0f;
+#pragma unroll
                 for (uint32_t i = 0; i < sps; i++) {
                     const float value = fbuf[s + i];
-                    if (i >= P.lo && i < P.hi) sum += value;
+                    if (i >= ev_lo && i < ev_hi) sum += value;
                     volume_sum += value;
                     S.var_rb[k * sps + i] = value;
                 }
@@ -386,7 +415,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const uint32_t k = k0 + q;
                 const float mn = S.mn[k], mx = S.mx[k];
                 const float center = (mx + mn) / 2.0f;
-                const float average = S.sum[q] / (float) (P.hi - P.lo);
+                const float average = S.sum[q] / (float) (ev_hi - ev_lo);
                 uint8_t sym;
                 if (P.levels == 4) {
                     const float umid = (float) ((double) (mx - center) * 0.625 + (double) center);
@@ -404,22 +433,42 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         int32_t new_off = 0;
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done) {
+            // 6a: per-phase totals (the float sums must run in symbol order: one phase per lane)
             DH_FOR_LANES(lane) {
                 if ((uint32_t) lane < sps) {
                     float total = 0.0f;
 #pragma unroll 10
                     for (int k = 0; k < DH_VARIANCE_SYMBOLS; k++) total += S.var_rb[k * sps + lane];
-                    const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
-                    double dsum = 0.0;
-#pragma unroll 10
-                    for (int k = 0; k < DH_VARIANCE_SYMBOLS; k++) {
-                        const double diff = mean - (double) S.var_rb[k * sps + lane];
-                        dsum += diff * diff;
-                    }
-                    S.variance[lane] = dsum / (double) DH_VARIANCE_SYMBOLS;
+                    S.mean[lane] = total / (float) DH_VARIANCE_SYMBOLS;
                 }
             }
             DH_BARRIER();
+            // 6b: the squared deviations are independent -> all lanes, staged as doubles in the (now idle) xf
+            // block; 6c: the double sums must again run in symbol order -> one phase per lane.
+            double* sq = reinterpret_cast<double*>(S.xf);
+            const uint32_t kchunk = SPS == 10 ? 50u : dh_max<uint32_t>(1u, 600u / sps);
+            DH_LANE_ARRAY(double, dacc, 1);
+            DH_FOR_LANES(lane) { DH_LA(dacc, lane)[0] = 0.0; }
+            for (uint32_t kb = 0; kb < DH_VARIANCE_SYMBOLS; kb += kchunk) {
+                const uint32_t kn = dh_min<uint32_t>(kchunk, DH_VARIANCE_SYMBOLS - kb);
+                DH_FOR_LANES(lane) {
+                    for (uint32_t e = lane; e < kn * sps; e += DH_WAVE) {
+                        const double d = (double) S.mean[e % sps] - (double) S.var_rb[kb * sps + e];
+                        sq[e] = d * d;
+                    }
+                }
+                DH_BARRIER();
+                DH_FOR_LANES(lane) {
+                    if ((uint32_t) lane < sps) {
+                        double a = DH_LA(dacc, lane)[0];
+#pragma unroll 10
+                        for (uint32_t k = 0; k < kn; k++) a += sq[k * sps + lane];
+                        DH_LA(dacc, lane)[0] = a;
+                        if (kb + kn == DH_VARIANCE_SYMBOLS) S.variance[lane] = a / (double) DH_VARIANCE_SYMBOLS;
+                    }
+                }
+                DH_BARRIER();
+            }
             double vmin = S.variance[0]; uint32_t vmin_pos = 0;
             for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
             if (vmin <= 0 || vmin > 5000000) {

@@ -33,11 +33,11 @@ int hip_fail(hipError_t e, const char* what) {
 
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
-template <int NZ, bool FAST>
+template <int NZ, bool FAST, int SPS>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : 3)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
-    dh_rrc_demod_channel<NZ, FAST>(P, blockIdx.x, S);
+    dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
 }
 
 template <int NZ, bool FAST>
@@ -213,19 +213,23 @@ struct HipBackend {
         return DH_OK;
     }
 
-    template <int NZ, bool FAST> int go_rrc_demod(const DhDspParams& P) {
+    template <int NZ, bool FAST, int SPS> int go_rrc_demod(const DhDspParams& P) {
         const size_t lds = dh_dsp_shared_bytes(P.sps);
         if (lds > 48 * 1024) {
-            if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
+            if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
                          "hipFuncSetAttribute")) return -1;
         }
-        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P);
+        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST, SPS>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P);
         return launched("k_rrc_demod");
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
-        if (nz == 0) return go_rrc_demod<0, false>(P);
-        if (nz == 80) return fast ? go_rrc_demod<80, true>(P) : go_rrc_demod<80, false>(P);
-        if (nz == 160) return fast ? go_rrc_demod<160, true>(P) : go_rrc_demod<160, false>(P);
+        if (P.sps == 10) {                      // DMR / YSF: specialised symbol loops
+            if (nz == 0) return go_rrc_demod<0, false, 10>(P);
+            if (nz == 80) return fast ? go_rrc_demod<80, true, 10>(P) : go_rrc_demod<80, false, 10>(P);
+        }
+        if (nz == 0) return go_rrc_demod<0, false, 0>(P);
+        if (nz == 80) return fast ? go_rrc_demod<80, true, 0>(P) : go_rrc_demod<80, false, 0>(P);
+        if (nz == 160) return fast ? go_rrc_demod<160, true, 0>(P) : go_rrc_demod<160, false, 0>(P);
         return -1;
     }
     template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {

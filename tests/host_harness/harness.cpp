@@ -35,15 +35,17 @@ struct HostBackend {
     int timing_enable(uint32_t) { return 0; }
     int timing_read(float*, float*, float*, uint32_t* n) { *n = 0; return 0; }
 
-    template <int NZ, bool FAST> static void run_rrc_demod(const DhDspParams& P) {
+    template <int NZ, bool FAST, int SPS> static void run_rrc_demod(const DhDspParams& P) {
         std::vector<char> lds(dh_dsp_shared_bytes(P.sps) + 64);
         DhDspShared& S = *reinterpret_cast<DhDspShared*>(lds.data());
-        for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST>(P, ch, S);
+        for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, S);
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
-        if (nz == 0) run_rrc_demod<0, false>(P);
-        else if (nz == 80) { if (fast) run_rrc_demod<80, true>(P); else run_rrc_demod<80, false>(P); }
-        else if (nz == 160) { if (fast) run_rrc_demod<160, true>(P); else run_rrc_demod<160, false>(P); }
+        if (P.sps == 10 && nz == 0) run_rrc_demod<0, false, 10>(P);
+        else if (P.sps == 10 && nz == 80) { if (fast) run_rrc_demod<80, true, 10>(P); else run_rrc_demod<80, false, 10>(P); }
+        else if (nz == 0) run_rrc_demod<0, false, 0>(P);
+        else if (nz == 80) { if (fast) run_rrc_demod<80, true, 0>(P); else run_rrc_demod<80, false, 0>(P); }
+        else if (nz == 160) { if (fast) run_rrc_demod<160, true, 0>(P); else run_rrc_demod<160, false, 0>(P); }
         else return -1;
         return 0;
     }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel trace + PMC passes of the headline bench, summaries into gpurun_out/prof_$1
+#   tools/profile_gpu.sh <tag> [bench args...]
+set -u
+TAG=${1:-run}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --verify 0 $*"
+if [ -z "${SKIP_TRACE:-}" ]; then timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py $ARGS > $OUT/trace.log 2>&1; fi
+grep '^{' $OUT/trace.log > $OUT/bench_under_trace.json
+python tools/rocpd_summary.py $OUT/trace_results.db > $OUT/trace_summary.txt 2>&1
+# PMC passes: counters only, no tracing domains (gpurun refuses --pmc together with sys/hip/hsa traces)
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-include-regex "k_rrc_demod|k_dmr|k_ysf|k_rrc_tile" --pmc $set -d $OUT -o pmc$i -- python bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  python tools/rocpd_summary.py $OUT/pmc${i}_results.db 2>&1 | grep -A200 "PMC counters" | grep -E "k_rrc_demod|k_dmr|k_ysf|k_rrc_tile|PMC" > $OUT/pmc${i}_summary.txt
+done
+rm -f $OUT/*.db
+cat $OUT/trace_summary.txt | grep -v "at::native\|rocclr\|rtc\|twiddle\|r2c\|c2r" | head -12 | cut -c1-170
+cat $OUT/pmc*_summary.txt | cut -c1-200
