@@ -1,0 +1,97 @@
+// decoder.hpp -- Digiham::Decoder, Digiham::Dmr::Decoder, Digiham::Ysf::Decoder on the MI355X engine
+// (reference: include/decoder.hpp:17-30, include/dmr_decoder.hpp:9-17, include/ysf_decoder.hpp:9-12).
+//
+// Output bytes are the reference's.  The metadata tail of the reference (MetaCollector -> MetaWriter text
+// lines: talker alias, GPS, call signs) is outside this engine; every call the reference would make into its
+// MetaCollector is delivered as a dh_event (FEC-corrected LC / FICH / DCH bytes) to the event callback.
+#pragma once
+
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "csdr_compat.hpp"
+#include "engine_handle.hpp"
+
+#define BUF_SIZE 128
+#define RINGBUFFER_SIZE 1024
+
+namespace Digiham {
+
+    class MetaWriter;   // metadata text serialisation is not part of this engine (see header comment)
+
+    class Decoder: public Csdr::Module<unsigned char, unsigned char> {
+        public:
+            ~Decoder() override { dh_device_free(dSyms); dh_device_free(dCount); }
+            bool canProcess() override {
+                std::lock_guard<std::mutex> lock(processMutex);
+                return reader->available() > 0 && writer->writeable() >= maxOutputPerCall;
+            }
+            void process() override {
+                std::lock_guard<std::mutex> lock(processMutex);
+                ensure();
+                size_t n = reader->available();
+                if (n > chunk) n = chunk;
+                Amd::check(dh_copy_to_device(dSyms, reader->getReadPointer(), n), "dh_copy_to_device");
+                uint32_t cnt = (uint32_t) n;
+                Amd::check(dh_copy_to_device(dCount, &cnt, sizeof(cnt)), "dh_copy_to_device");
+                Amd::check(dh_engine_push_symbols(engine->get(), (const uint8_t*) dSyms, chunk, (const uint32_t*) dCount), "dh_engine_push_symbols");
+                reader->advance(n);
+                size_t got = writer->writeable();
+                Amd::check(dh_engine_read_frames(engine->get(), 0, writer->getWritePointer(), &got), "dh_engine_read_frames");
+                writer->advance(got);
+                if (onEvent) {
+                    events.resize(chunk / 20 + 64);
+                    size_t ne = events.size();
+                    Amd::check(dh_engine_read_events(engine->get(), 0, events.data(), &ne), "dh_engine_read_events");
+                    for (size_t i = 0; i < ne; i++) onEvent(events[i]);
+                }
+            }
+            // reference signature kept for source compatibility; the writer is owned and released, never fed
+            void setMetaWriter(MetaWriter* meta) { (void) meta; }
+            void setEventCallback(std::function<void(const dh_event&)> cb) { onEvent = std::move(cb); }
+        protected:
+            explicit Decoder(int proto): proto(proto) {}
+            void ensure() {
+                if (engine) return;
+                engine.reset(new Amd::Engine(DH_RRC_NONE, DH_DEMOD_NONE, 0, proto, 0, chunk, slotFilter));
+                Amd::check(dh_device_alloc(0, chunk, &dSyms), "dh_device_alloc");
+                Amd::check(dh_device_alloc(0, sizeof(uint32_t), &dCount), "dh_device_alloc");
+            }
+            std::unique_ptr<Amd::Engine> engine;
+            unsigned char slotFilter = 3;
+        private:
+            static constexpr size_t chunk = 16384;
+            // a call may emit one voice payload per 144-symbol burst (DMR, 27 bytes) or 95 bytes per 480-symbol frame (YSF)
+            static constexpr size_t maxOutputPerCall = (chunk + 512) / 144 * 27 + 128;
+            int proto;
+            void* dSyms = nullptr;
+            void* dCount = nullptr;
+            std::vector<dh_event> events;
+            std::function<void(const dh_event&)> onEvent;
+    };
+
+    namespace Dmr {
+
+        class Decoder: public Digiham::Decoder {
+            public:
+                Decoder(): Digiham::Decoder(DH_PROTO_DMR) {}
+                void setSlotFilter(unsigned char filter) {
+                    std::lock_guard<std::mutex> lock(processMutex);   // the reference races here (dmr_cli.cpp:57-69)
+                    slotFilter = filter;
+                    if (engine) Amd::check(dh_engine_set_slot_filter(engine->get(), filter), "dh_engine_set_slot_filter");
+                }
+        };
+
+    }
+
+    namespace Ysf {
+
+        class Decoder: public Digiham::Decoder {
+            public:
+                Decoder(): Digiham::Decoder(DH_PROTO_YSF) {}
+        };
+
+    }
+
+}

@@ -1,0 +1,38 @@
+// engine_handle.hpp -- RAII wrapper of a dh_engine for the single-channel operator classes.
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../digiham_amd.h"
+
+namespace Digiham {
+    namespace Amd {
+
+        inline void check(int rc, const char* what) {
+            if (rc != DH_OK && rc != DH_ECAPACITY) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + dh_last_error());
+        }
+
+        class Engine {
+            public:
+                Engine(int rrc, int demod, unsigned int sps, int proto, unsigned int flags, unsigned int maxSamples, unsigned int slotFilter = 3) {
+                    dh_engine_config cfg{};
+                    cfg.struct_size = sizeof(cfg); cfg.device = 0; cfg.n_channels = 1; cfg.max_samples = maxSamples;
+                    cfg.rrc = rrc; cfg.demod = demod; cfg.sps = sps; cfg.proto = proto; cfg.flags = flags; cfg.slot_filter = slotFilter;
+                    cfg.stream = nullptr;
+                    check(dh_engine_create(&cfg, &handle), "dh_engine_create");
+                    max = maxSamples;
+                }
+                ~Engine() { dh_engine_destroy(handle); }
+                Engine(const Engine&) = delete;
+                Engine& operator=(const Engine&) = delete;
+                dh_engine* get() { return handle; }
+                unsigned int maxSamples() const { return max; }
+            private:
+                dh_engine* handle = nullptr;
+                unsigned int max = 0;
+        };
+
+    }
+}
