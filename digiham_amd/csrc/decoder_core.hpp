@@ -13,6 +13,7 @@
 #pragma once
 
 #include "dh_portable.hpp"
+#include <stddef.h>
 #include "fec_core.hpp"
 
 #include "../../include/digiham_amd.h"     // dh_event, DH_EV_*
@@ -114,6 +115,7 @@ DH_HD int dh_dmr_sync_type(const DhPlanes& p, int start) {
 // ---------------------------------------------------------------------------------------------
 struct DhDecCtx {
     const DhDecParams* P;
+    const DhFecTables* T;              // LDS-resident prefix of the tables
     uint32_t* st;
     uint8_t* out; dh_event* ev;
     uint32_t nout, nev, consumed;
@@ -186,7 +188,7 @@ struct DhDmrFrameResult { bool to_sync; bool voice_out; bool want_bptc; uint8_t 
 // FramePhase::process up to (not including) the payload stores and the BPTC, which the caller runs
 // lane-parallel (dmr_phase.cpp:65-254).
 DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhPlanes& p) {
-    const DhFecTables& T = *c.P->T;
+    const DhFecTables& T = *c.T;          // LDS copy (codes + small LUTs); Golay LUTs via c.P->T
     uint32_t* s = c.st;
     DhDmrFrameResult R; R.to_sync = false; R.voice_out = false; R.want_bptc = false; R.data_type = 0;
 
@@ -285,7 +287,7 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhPlanes& p) {
         if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
         if (st == DH_SYNCTYPE_DATA) {
             uint32_t slot_type = (dh_syms_msb(p, 61, 5) << 10) | dh_syms_msb(p, 90, 5);   // :236-245
-            if (dh_block_decode(T.g208, T.lut_g208, slot_type)) {
+            if (dh_block_decode(T.g208, c.P->T->lut_g208, slot_type)) {
                 uint8_t cc = (uint8_t) ((slot_type >> 16) & 15u);
                 R.data_type = (uint8_t) ((slot_type >> 12) & 15u);
                 dh_emit(c, DH_EV_DMR_SLOTTYPE, (uint8_t) slot, R.data_type, &cc, 1);
@@ -304,8 +306,13 @@ DH_HD int dh_dmr_info_dibit_pos(int d) { return d < 49 ? 12 + d : 12 + 54 + 24 +
 DH_HD int dh_dmr_voice_dibit_pos(int d) { return d < 54 ? 12 + d : 12 + 54 + 24 + (d - 54); }
 
 // ------------------------------------------------------------------------------------------
+#define DH_SYMWIN 1024               // fresh symbols staged in LDS per refill (a DMR burst is 144, a YSF frame 480)
 struct DhDecShared {
-    uint8_t  carry[DH_SYM_CARRY_MAX];
+    uint8_t  carry[DH_SYM_CARRY_MAX];     // symbols carried from the previous push
+    uint8_t  symwin[DH_SYMWIN];           // window of this push's symbols (refilled with 16-byte-per-lane loads)
+    // codes + small syndrome LUTs (everything of DhFecTables in front of the two 16 KiB Golay LUTs): table lookups
+    // on the frame path are LDS reads instead of dependent global loads
+    uint32_t fec_small[(offsetof(DhFecTables, lut_g208) + 3) / 4];
     uint32_t state[DH_DEC_STATE_WORDS];   // wave-uniform working copy of the channel state
     DhPlanes planes;                      // bit planes of the current frame (wave-uniform; LDS broadcast reads)
     uint32_t colword[16];
@@ -317,8 +324,36 @@ struct DhDecShared {
 };
 
 // virtual symbol stream of a channel for this push: carried symbols, then the fresh ones
-struct DhSymView { const uint8_t* carry; uint32_t nc; const uint8_t* fresh; };
-DH_HD uint32_t dh_view_at(const DhSymView& v, uint32_t j) { return j < v.nc ? v.carry[j] : v.fresh[j - v.nc]; }
+// (both parts are read through LDS: `carry` is S.carry, fresh symbols come through the S.symwin window)
+struct DhSymView { const uint8_t* carry; uint32_t nc; const uint8_t* fresh; uint32_t nfresh; uint8_t* win; uint32_t wbase, wlen; };
+DH_HD uint32_t dh_view_at(const DhSymView& v, uint32_t j) { return j < v.nc ? v.carry[j] : v.win[(j - v.nc) - v.wbase]; }
+
+// make the symbols [pos, pos+need) of the virtual stream readable (wave-uniform; refills the LDS window when the
+// range runs past it).  need <= DH_SYMWIN - 4.
+DH_HD void dh_view_ensure(DhSymView& v, uint32_t pos, uint32_t need) {
+    const uint32_t end = pos + need;
+    if (end <= v.nc) return;                                   // entirely inside the carried part
+    const uint32_t f0 = pos > v.nc ? pos - v.nc : 0u;
+    uint32_t f1 = end - v.nc; if (f1 > v.nfresh) f1 = v.nfresh;
+    if (f0 >= v.wbase && f1 <= v.wbase + v.wlen) return;
+    const uint32_t mis = (uint32_t) ((uintptr_t) (v.fresh + f0) & 3u);
+    const uint32_t wb = f0 >= mis ? f0 - mis : f0;             // start the window on a 4-byte aligned address when possible
+    DH_BARRIER();                                              // earlier readers of the window are done
+    DH_FOR_LANES(lane) {
+        for (uint32_t idx = 4u * (uint32_t) lane; idx < DH_SYMWIN; idx += 4u * DH_WAVE) {
+            const uint32_t f = wb + idx;
+            const uint8_t* src = v.fresh + f;
+            uint32_t word = 0;
+            if (f + 4u <= v.nfresh && ((uintptr_t) src & 3u) == 0) word = *reinterpret_cast<const uint32_t*>(src);
+            else {
+                for (uint32_t b = 0; b < 4u; b++) if (f + b < v.nfresh) word |= (uint32_t) src[b] << (8u * b);
+            }
+            *reinterpret_cast<uint32_t*>(v.win + idx) = word;
+        }
+    }
+    DH_BARRIER();
+    v.wbase = wb; v.wlen = DH_SYMWIN;
+}
 
 DH_HD void dh_load_planes(const DhSymView& syms, uint32_t pos, uint32_t total, DhPlanes& pl, int nwords) {
     for (int w = 0; w < DH_PLANE_WORDS; w++) { pl.h[w] = 0; pl.l[w] = 0; }
@@ -333,6 +368,18 @@ DH_HD void dh_load_planes(const DhSymView& syms, uint32_t pos, uint32_t total, D
         pl.h[w] = mh; pl.l[w] = ml;
     }
 }
+
+// kernel prologue: carried symbols and the small FEC tables into LDS
+DH_HD void dh_stage_decoder_lds(const DhDecParams& P, DhDecShared& S, const uint8_t* carry_buf, uint32_t nc) {
+    const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(P.T);
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < nc; j += DH_WAVE) S.carry[j] = carry_buf[j];
+        for (uint32_t j = lane; j < sizeof(S.fec_small) / 4; j += DH_WAVE) S.fec_small[j] = tsrc[j];
+    }
+    DH_BARRIER();
+}
+// the LDS copy viewed as a DhFecTables: valid for the codes and the small LUTs only (not lut_g208 / lut_g2412)
+DH_HD const DhFecTables& dh_lds_tables(const DhDecShared& S) { return *reinterpret_cast<const DhFecTables*>(S.fec_small); }
 
 // BPTC(196,96) of a data burst, columns on lanes (bptc_196_96.c:5-59 on the dibits of dmr_phase.cpp:256-269)
 DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared& S, uint8_t* out12) {
@@ -378,7 +425,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared
 // One DMR channel, one push.
 DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     DhDecCtx c;
-    c.P = &P;
+    c.P = &P; c.T = &dh_lds_tables(S);
     c.st = P.state + (size_t) ch * P.state_stride;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
@@ -390,8 +437,10 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.writer = true;
 #endif
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = carry_buf; syms.nc = c.st[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
-    const uint32_t total = syms.nc + P.sym_count[ch];
+    DhSymView syms; syms.carry = S.carry; syms.nc = c.st[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    const uint32_t total = syms.nc + syms.nfresh;
+    dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0;
     uint32_t phase = c.st[DS_PHASE];
     // the state words are wave-uniform working copies; lane 0 stores them back at the end
@@ -405,6 +454,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         DhPlanes& pl = S.planes;
         if (phase == 0) {                                              // SyncPhase (dmr_phase.cpp:35-47)
             if (!(avail > 90)) break;
+            dh_view_ensure(syms, pos, 192);
             dh_load_planes(syms, pos, total, pl, 3);
             uint64_t hits = 0;
             DH_FOR_LANES(lane) {
@@ -422,6 +472,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             }
         } else {                                                       // FramePhase (dmr_phase.cpp:61-302)
             if (!(avail > 144)) break;
+            dh_view_ensure(syms, pos, 192);
             dh_load_planes(syms, pos, total, pl, 3);
             const DhDmrFrameResult R = dh_dmr_frame_head(c, pl);
             if (R.to_sync) { phase = 0; continue; }
@@ -440,7 +491,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 uint8_t lc[12];
                 for (int i = 0; i < 12; i++) lc[i] = 0;
                 const int slot = (int) s[DS_SLOT];
-                if (dh_dmr_bptc_wave(*P.T, pl, S, lc)) {
+                if (dh_dmr_bptc_wave(dh_lds_tables(S), pl, S, lc)) {
                     dh_emit(c, DH_EV_DMR_BPTC, (uint8_t) slot, R.data_type, lc, 12);
                     if (R.data_type == 1) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 0, lc, 9);
                     else if (R.data_type == 2 || R.data_type == 9) dh_emit(c, DH_EV_DMR_SOFT_RESET, (uint8_t) slot, R.data_type, nullptr, 0);
@@ -453,12 +504,10 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 
     // carry the unread symbols to the front of the buffer
     const uint32_t rem = total - pos;
+    dh_view_ensure(syms, pos, rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX);
     DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) S.carry[j] = (uint8_t) dh_view_at(syms, pos + j);
-    }
-    DH_BARRIER();
-    DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = S.carry[j];
+        // sources are LDS (carried part / window), destination is the global carry row: no overlap to worry about
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
         if (DH_IS_LANE0(lane)) {
             s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
             s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
@@ -610,9 +659,9 @@ DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.c
 
 // One YSF channel, one push.
 DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
-    const DhFecTables& T = *P.T;
+    const DhFecTables& T = dh_lds_tables(S);
     DhDecCtx c;
-    c.P = &P;
+    c.P = &P; c.T = &T;
     uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
@@ -627,8 +676,10 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.st = s;
     c.consumed = s[DS_CONSUMED];
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = carry_buf; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
-    const uint32_t total = syms.nc + P.sym_count[ch];
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    const uint32_t total = syms.nc + syms.nfresh;
+    dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0, phase = s[DS_PHASE];
 
     for (;;) {
@@ -636,6 +687,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         DhPlanes& pl = S.planes;
         if (phase == 0) {                                          // SyncPhase (ysf_phase.cpp:20-34)
             if (!(avail > 20)) break;
+            dh_view_ensure(syms, pos, 128);
             dh_load_planes(syms, pos, total, pl, 2);
             uint64_t hits = 0;
             DH_FOR_LANES(lane) {
@@ -653,6 +705,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         }
         // FramePhase (ysf_phase.cpp:41-172)
         if (!(avail > 480)) break;
+        dh_view_ensure(syms, pos, 512);
         dh_load_planes(syms, pos, total, pl, 8);
         int sync_count = (int) s[DS_SYNC_COUNT];
         if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
@@ -697,7 +750,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             uint32_t g[4];
             for (int i = 0; i < 4; i++) {
                 g[i] = (uint32_t) S.vit_out[0][i * 3] << 16 | (uint32_t) S.vit_out[0][i * 3 + 1] << 8 | S.vit_out[0][i * 3 + 2];
-                fresh &= dh_block_decode(T.g2412, T.lut_g2412, g[i]);
+                fresh &= dh_block_decode(T.g2412, P.T->lut_g2412, g[i]);
             }
             if (fresh) {
                 fich = (g[0] & 0x00FFF000u) << 8 | (g[1] & 0x00FFF000u) >> 4 | (g[2] & 0x00FF0000u) >> 16;
@@ -793,12 +846,10 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     }
 
     const uint32_t rem = total - pos;
+    dh_view_ensure(syms, pos, rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX);
     DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) S.carry[j] = (uint8_t) dh_view_at(syms, pos + j);
-    }
-    DH_BARRIER();
-    DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = S.carry[j];
+        // sources are LDS (carried part / window), destination is the global carry row: no overlap to worry about
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
         if (DH_IS_LANE0(lane)) {
             s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
             s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;

@@ -354,7 +354,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         DH_BARRIER();
 
-        // ---- P2: FIR into registers, then (after every lane has read its window) back into S.xf[0..need)
+        // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
+        // The filtered samples keep the padded layout (element n at DH_XPAD(n)): the 16-words-apart write-back
+        // would otherwise be a 16-way bank conflict.  Without an RRC stage the staged samples are used as they are.
         if (NZ > 0) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
             DH_FOR_LANES(lane) {
@@ -364,23 +366,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_BARRIER();
             DH_FOR_LANES(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need) {
+                    float* dst = S.xf + (DH_FIR_L + 1) * lane;       // DH_XPAD(16*lane + j) = 17*lane + j
 #pragma unroll
-                    for (int j = 0; j < DH_FIR_L; j++) S.xf[lane * DH_FIR_L + j] = DH_LA(fo, lane)[j];
+                    for (int j = 0; j < DH_FIR_L; j++) dst[j] = DH_LA(fo, lane)[j];
                 }
             }
-        } else {
-            // no RRC stage: un-pad in place (ascending order, destination index <= source index)
-            DH_LANE_ARRAY(float, cp, DH_FIR_L);
-            DH_FOR_LANES(lane) {
-                for (int j = 0; j < DH_FIR_L; j++) DH_LA(cp, lane)[j] = S.xf[DH_XPAD(lane * DH_FIR_L + j)];
-            }
             DH_BARRIER();
-            DH_FOR_LANES(lane) {
-                for (int j = 0; j < DH_FIR_L; j++) S.xf[lane * DH_FIR_L + j] = DH_LA(cp, lane)[j];
-            }
         }
-        DH_BARRIER();
         const float* fbuf = S.xf;
+#define DH_FB(n) fbuf[DH_XPAD(n)]
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
         DH_FOR_LANES(lane) {
@@ -390,7 +384,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 float sum = 0.0f, volume_sum = 0.0f;
 #pragma unroll
                 for (uint32_t i = 0; i < sps; i++) {
-                    const float value = fbuf[s + i];
+                    const float value = DH_FB(s + i);
                     if (i >= ev_lo && i < ev_hi) sum += value;
                     volume_sum += value;
                     S.var_rb[k * sps + i] = value;
@@ -551,13 +545,14 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
     DH_BARRIER();
     DH_FOR_LANES(lane) {
         if ((uint32_t) (lane * DH_FIR_L) < cnt) {
+            float* dst = S.xf + (DH_FIR_L + 1) * lane;               // padded layout: conflict-free write-back
 #pragma unroll
-            for (int j = 0; j < DH_FIR_L; j++) S.xf[lane * DH_FIR_L + j] = DH_LA(fo, lane)[j];
+            for (int j = 0; j < DH_FIR_L; j++) dst[j] = DH_LA(fo, lane)[j];
         }
     }
     DH_BARRIER();
     DH_FOR_LANES(lane) {
-        for (uint32_t e = lane; e < cnt; e += DH_WAVE) out[t0 + e] = S.xf[e];     // coalesced store
+        for (uint32_t e = lane; e < cnt; e += DH_WAVE) out[t0 + e] = S.xf[DH_XPAD(e)];     // coalesced store
     }
     DH_BARRIER();
 }

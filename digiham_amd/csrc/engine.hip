@@ -31,17 +31,20 @@ int hip_fail(hipError_t e, const char* what) {
 }
 #define HIP_TRY(expr) do { if (hip_fail((expr), #expr)) return DH_EDEVICE; } while (0)
 
+#ifndef DH_LB
+#define DH_LB 3          // minimum waves per SIMD the wide-filter kernels are register-budgeted for
+#endif
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
 template <int NZ, bool FAST, int SPS>
-__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : 3)) void k_rrc_demod(const DhDspParams P) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
     dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
 }
 
 template <int NZ, bool FAST>
-__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : 3)) void k_rrc_tile(const DhRrcParams R) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
     dh_rrc_tile<NZ, FAST>(R, blockIdx.y, blockIdx.x, S);
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(DH_WAVE) void k_dmr(const DhDecParams P) {
     dh_dmr_channel(P, blockIdx.x, S);
 }
 
-__global__ __launch_bounds__(DH_WAVE) void k_ysf(const DhDecParams P) {
+__global__ __launch_bounds__(DH_WAVE, 4) void k_ysf(const DhDecParams P) {
     __shared__ DhDecShared S;
     dh_ysf_channel(P, blockIdx.x, S);
 }
