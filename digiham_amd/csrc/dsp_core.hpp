@@ -33,7 +33,7 @@
 // per-channel state block in HBM (floats / u32 words, AoS, `state_stride` words apart):
 //   [0..15]                      header: k, pending offset, tail count, symbols produced (lo), ...
 //   [16 .. 16+100)               volume ring  (volume_rb)
-//   [116 .. 116+100*sps)         variance ring (variance_rb)
+//   [116 .. 116+100*sps)         variance ring (variance_rb), phase-major: [sample i][symbol k]
 //   [.. + DH_TAIL_MAX)           raw-sample tail: the last nz inputs + not yet consumed samples
 enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3 };
 #define DH_ST_VOL DH_STATE_HDR
@@ -69,13 +69,12 @@ struct DhDspShared {
     float mn[DH_SCAN_N], mx[DH_SCAN_N];                // AGC window min / max per symbol of the block
     float sum[DH_VOLUME_RB_SIZE];                      // mid-symbol window sums of the current run
     double variance[DH_MAX_SPS];
-    float mean[DH_MAX_SPS];
-    // variance ring follows (100 * sps floats), sized at launch
-    float var_rb[1];
+    // variance ring follows (sps rows of 100 floats: row i holds sample i of the last 100 symbols), sized at launch
+    alignas(16) float var_rb[4];
 };
 
 DH_HD size_t dh_dsp_shared_bytes(uint32_t sps) {
-    return sizeof(DhDspShared) + sizeof(float) * (size_t) (DH_VARIANCE_SYMBOLS * sps);
+    return sizeof(DhDspShared) + sizeof(float) * (size_t) (DH_VARIANCE_SYMBOLS * sps) + 16;
 }
 
 // per-lane values that must survive a barrier: registers on the GPU, [lane] arrays in the harness
@@ -195,6 +194,7 @@ DH_HD void dh_fir_lane(const float* taps, double gain, double rgain, float inv_g
 
 // four consecutive floats from a 4-byte-aligned address (global_load_dwordx4: gfx950 allows dword alignment)
 struct __attribute__((aligned(4))) dh_f4 { float x, y, z, w; };
+struct alignas(16) dh_f4a { float x, y, z, w; };     // 16-byte aligned: one ds_read_b128
 DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
 DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
 
@@ -296,7 +296,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     }
     DH_BARRIER();
 
-    // FIR taps: wave-uniform, loop-invariant, one VGPR each (41 for the wide filter)
+    // FIR taps: wave-uniform, loop-invariant, kept in VGPRs (the 102 SGPRs are needed elsewhere)
     float tv[NZ / 2 + 1];
 #pragma unroll
     for (int i = 0; i <= NZ / 2; i++) { tv[i] = P.taps[i]; DH_TO_VGPR(tv[i]); }
@@ -387,7 +387,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     const float value = DH_FB(s + i);
                     if (i >= ev_lo && i < ev_hi) sum += value;
                     volume_sum += value;
-                    S.var_rb[k * sps + i] = value;
+                    S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;       // transposed ring: phase-major
                 }
                 S.sum[q] = sum;
                 S.vol_new[k] = volume_sum / (float) sps;
@@ -427,42 +427,31 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         int32_t new_off = 0;
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done) {
-            // 6a: per-phase totals (the float sums must run in symbol order: one phase per lane)
+            // Both sums of a phase must run in symbol order (float total, then double sum of squared deviations):
+            // one phase per lane, its 100 samples contiguous in the transposed ring and fetched 16 bytes at a time,
+            // five loads in flight per batch.  Only `sps` lanes work here, but the chain is latency- not issue-bound.
             DH_FOR_LANES(lane) {
                 if ((uint32_t) lane < sps) {
+                    const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
                     float total = 0.0f;
-#pragma unroll 10
-                    for (int k = 0; k < DH_VARIANCE_SYMBOLS; k++) total += S.var_rb[k * sps + lane];
-                    S.mean[lane] = total / (float) DH_VARIANCE_SYMBOLS;
+#pragma unroll 5
+                    for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                        const dh_f4a v = row[q];
+                        total += v.x; total += v.y; total += v.z; total += v.w;
+                    }
+                    const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
+                    double dsum = 0.0;
+#pragma unroll 5
+                    for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                        const dh_f4a v = row[q];
+                        const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
+                        const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+                        dsum += s0; dsum += s1; dsum += s2; dsum += s3;
+                    }
+                    S.variance[lane] = dsum / (double) DH_VARIANCE_SYMBOLS;
                 }
             }
             DH_BARRIER();
-            // 6b: the squared deviations are independent -> all lanes, staged as doubles in the (now idle) xf
-            // block; 6c: the double sums must again run in symbol order -> one phase per lane.
-            double* sq = reinterpret_cast<double*>(S.xf);
-            const uint32_t kchunk = SPS == 10 ? 50u : dh_max<uint32_t>(1u, 600u / sps);
-            DH_LANE_ARRAY(double, dacc, 1);
-            DH_FOR_LANES(lane) { DH_LA(dacc, lane)[0] = 0.0; }
-            for (uint32_t kb = 0; kb < DH_VARIANCE_SYMBOLS; kb += kchunk) {
-                const uint32_t kn = dh_min<uint32_t>(kchunk, DH_VARIANCE_SYMBOLS - kb);
-                DH_FOR_LANES(lane) {
-                    for (uint32_t e = lane; e < kn * sps; e += DH_WAVE) {
-                        const double d = (double) S.mean[e % sps] - (double) S.var_rb[kb * sps + e];
-                        sq[e] = d * d;
-                    }
-                }
-                DH_BARRIER();
-                DH_FOR_LANES(lane) {
-                    if ((uint32_t) lane < sps) {
-                        double a = DH_LA(dacc, lane)[0];
-#pragma unroll 10
-                        for (uint32_t k = 0; k < kn; k++) a += sq[k * sps + lane];
-                        DH_LA(dacc, lane)[0] = a;
-                        if (kb + kn == DH_VARIANCE_SYMBOLS) S.variance[lane] = a / (double) DH_VARIANCE_SYMBOLS;
-                    }
-                }
-                DH_BARRIER();
-            }
             double vmin = S.variance[0]; uint32_t vmin_pos = 0;
             for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
             if (vmin <= 0 || vmin > 5000000) {
