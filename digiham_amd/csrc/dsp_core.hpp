@@ -25,6 +25,7 @@
 #define DH_VOLUME_RB_SIZE 100        // include/gfsk_demodulator.hpp:6
 #define DH_FTILE 1024                // filtered samples produced per FIR pass (64 lanes x 16)
 #define DH_FIR_L 16                  // consecutive outputs per lane
+#define DH_PF_N 5                    // 16-byte prefetch loads per lane covering 1024 + 160 samples
 #define DH_MAX_NZ 160
 #define DH_MAX_SPS 40
 #define DH_TAIL_MAX 256              // raw samples carried between pushes (>= nz + sps + 2)
@@ -69,6 +70,7 @@ struct DhDspShared {
     float mn[DH_SCAN_N], mx[DH_SCAN_N];                // AGC window min / max per symbol of the block
     float sum[DH_VOLUME_RB_SIZE];                      // mid-symbol window sums of the current run
     double variance[DH_MAX_SPS];
+    float tapsf[DH_MAX_NZ / 2 + 1];                    // FIR taps (first half + centre)
     // variance ring follows (sps rows of 100 floats: row i holds sample i of the last 100 symbols), sized at launch
     alignas(16) float var_rb[4];
 };
@@ -118,6 +120,12 @@ DH_HD float dh_div_gain(float acc, double gain, double rgain) {
 #define DH_TO_VGPR(x) asm volatile("" : "+v"(x))
 #else
 #define DH_TO_VGPR(x) ((void) 0)
+#endif
+// compiler-only memory fence: values cached from memory before it must be re-read after it
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_COMPILER_FENCE() asm volatile("" ::: "memory")
+#else
+#define DH_COMPILER_FENCE() ((void) 0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -296,12 +304,14 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     }
     DH_BARRIER();
 
-    // FIR taps: wave-uniform, loop-invariant, kept in VGPRs (the 102 SGPRs are needed elsewhere)
-    float tv[NZ / 2 + 1];
-#pragma unroll
-    for (int i = 0; i <= NZ / 2; i++) { tv[i] = P.taps[i]; DH_TO_VGPR(tv[i]); }
+    // FIR taps are parked in LDS and pulled into VGPRs at the start of every FIR pass (see P2): their live range
+    // must end with the FIR, or they pin ~80 registers through the latency-bound phases where the prefetch lives.
+    DH_FOR_LANES(lane) {
+        for (int i = lane; i <= NZ / 2; i += DH_WAVE) S.tapsf[i] = P.taps[i];
+    }
 
     uint32_t p = 0;                                     // read position in the filtered stream
+    bool staged = false; uint32_t staged_p = 0;         // the LDS window already holds V[staged_p ...) (prefetch)
     uint32_t nsym = 0;
     bool overflow = false;
     const uint32_t max_run = (DH_FTILE - 2) / sps;      // symbols whose windows fit one FIR pass
@@ -332,9 +342,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window (zeros beyond)
         // After the first run of a push the whole window comes straight from `in`: 16 B per lane per load,
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
-        if (p >= tc) {
+        // From the second run on, the window was already put there by the previous iteration's prefetch.
+        if (staged && staged_p == p) {
+        } else if (p >= tc) {
             const float* src = in + (p - tc);
-            const uint32_t have = need + NZ;
+            const uint32_t have = dh_min<uint32_t>(DH_FTILE + NZ, nv - p);
             DH_FOR_LANES(lane) {
                 for (uint32_t e = 4u * (uint32_t) lane; e < DH_FTILE + NZ; e += 4u * DH_WAVE) {
                     dh_f4 v;
@@ -349,7 +361,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         } else {
             DH_FOR_LANES(lane) {
                 for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
-                    S.xf[DH_XPAD(e)] = e < need + NZ ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
+                    S.xf[DH_XPAD(e)] = p + e < nv ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
             }
         }
         DH_BARRIER();
@@ -359,6 +371,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // would otherwise be a 16-way bank conflict.  Without an RRC stage the staged samples are used as they are.
         if (NZ > 0) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
+            DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
+            float tv[NZ / 2 + 1];
+#pragma unroll
+            for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
             DH_FOR_LANES(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need)
                     dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
@@ -394,6 +410,32 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         DH_BARRIER();
+
+        // ---- prefetch: the raw window of the NEXT run.  Its start is already known (the timing decision of this
+        // block only moves symbols 1.. of the next one), the window block is idle from here to the end of the
+        // iteration, and P4-P6 are latency-bound with few live registers: the HBM latency of these loads hides
+        // behind them.  Five 16-byte loads per lane, parked in registers until P7.
+        const uint32_t p_next = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
+        const bool pf_ok = p_next >= tc && p_next < nv;
+        const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
+        DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
+        if (pf_ok) {
+            const float* src = in + (p_next - tc);
+            DH_FOR_LANES(lane) {
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    dh_f4 v; v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; v.w = 0.0f;
+                    if (e + 4u <= pf_have) v = dh_load4_unaligned(src + e);
+                    else if (e < pf_have) {
+                        v.x = src[e];
+                        if (e + 1u < pf_have) v.y = src[e + 1u];
+                        if (e + 2u < pf_have) v.z = src[e + 2u];
+                    }
+                    DH_LA(pf, lane)[r] = v;
+                }
+            }
+        }
 
         // ---- P4: sliding AGC min/max as two wave scans
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -462,9 +504,17 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
         DH_FOR_LANES(lane) {
             for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k];
+            if (pf_ok) {
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XPAD(e)], DH_LA(pf, lane)[r]);
+                }
+            }
         }
+        staged = pf_ok; staged_p = p_next;
         DH_BARRIER();
-        p = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
+        p = p_next;
         nsym += m;
         if (k0 == 0) off = 0;                           // the pending step has been consumed (:36-38)
         k0 += m;
