@@ -52,14 +52,15 @@ def cpu_baseline(x_host_fn, proto, budget_s=12.0):
     per_sample = (time.perf_counter() - t0) / min(n, 96000)
     # size the sample for ~budget_s of wall time with every core busy
     chans = max(cores, int(budget_s / (per_sample * n) * cores))
-    chans = min(chans, 4096)
+    chans = min(chans, 16384)
     x = x_host_fn(chans)
     t0 = time.perf_counter()
     O.chain(x, proto=1 if proto == "dmr" else 2, threads=cores)
     dt = time.perf_counter() - t0
     rate = x.size / dt
     return {"value": rate / SAMPLE_RATE, "unit": "channels", "msamples_per_s": rate / 1e6,
-            "msamples_per_s_per_core": rate / 1e6 / cores, "cores": cores, "kind": "port",
+            "msamples_per_s_per_core": rate / 1e6 / cores, "single_thread_msamples_per_s": 1e-6 / per_sample,
+            "cores": cores, "kind": "port",
             "sample": "%d channels x %d samples of the same synthetic workload through oracle/ (scalar C restatement of "
                       "rrc_filter|gfsk_demodulator|%s_decoder, bit-exact with the GPU path), %d pthreads, %.1f s wall"
                       % (chans, x.shape[1], proto, cores, dt)}

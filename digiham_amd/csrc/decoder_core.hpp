@@ -530,11 +530,83 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 // predecessor wins ties, the best final state is the lowest index among the minimum metric;
 // survivors are recovered by trace-back over the stored decision votes instead of copying
 // sixteen bit strings per step.
-DH_HD void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4], multiples of 4 not required*/) {
+// Final step shared by both forward passes: pick the best end state of every codeword (lowest index among the
+// minimum metric, trellis.c:94-98) and trace the decisions back.  Output bits are assembled in a register and
+// stored once per byte; the eight decision words of a byte are fetched together (their addresses do not depend
+// on the trace-back state).
+DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
+    DH_FOR_LANES(lane) {
+        if ((lane & 15) == 0) {
+            const int g = lane >> 4;
+            const int size = g == 0 ? sizes[0] : g == 1 ? sizes[1] : g == 2 ? sizes[2] : sizes[3];
+            if (size > 0) {
+                uint32_t best = 0, bm = S.vit_metric[fin][g * 16];
+                for (uint32_t i = 1; i < 16; i++) {
+                    const uint32_t m = S.vit_metric[fin][g * 16 + i];
+                    if (m < bm) { bm = m; best = i; }
+                }
+                S.vit_best_metric[g] = (uint8_t) bm;
+                const int nbytes = (size + 7) >> 3;
+                for (int b = nbytes; b < 24; b++) S.vit_out[g][b] = 0;
+                uint32_t state = best;
+                const int gsh = g * 16;
+                for (int b = nbytes - 1; b >= 0; b--) {
+                    uint64_t d[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) d[j] = S.vit_dec[(b * 8 + j) < 192 ? (b * 8 + j) : 191];
+                    uint32_t byte = 0;
+#pragma unroll
+                    for (int j = 7; j >= 0; j--) {
+                        if (b * 8 + j < size) {
+                            byte |= (state >> 3) << (7 - j);
+                            const uint32_t k = (uint32_t) ((d[j] >> (gsh + (int) state)) & 1ull);
+                            state = ((state << 1) & 0xEu) | k;
+                        }
+                    }
+                    S.vit_out[g][b] = (uint8_t) byte;
+                }
+            }
+        }
+    }
+    DH_BARRIER();
+}
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// gfx950 forward pass: path metrics stay in registers, the two predecessor metrics come through ds_bpermute
+// (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.
+__device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
+    const int lane = (int) threadIdx.x, g = lane >> 4, i = lane & 15;
+    int steps = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) steps = sizes[q] > steps ? sizes[q] : steps;
+    const int mysize = g == 0 ? sizes[0] : g == 1 ? sizes[1] : g == 2 ? sizes[2] : sizes[3];   // static indices only
+    const uint32_t outbit = (uint32_t) i >> 3;
+    const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
+    const uint32_t t0 = dh_trellis_out(p0, outbit), t1 = dh_trellis_out(p1, outbit);
+    const int src0 = (g << 4) | (int) p0, src1 = src0 | 1;
+    const uint8_t* inrow = S.vit_in[g];
+    uint32_t m = 0;
+    for (int pos = 0; pos < steps; pos++) {
+        const uint32_t in = ((uint32_t) inrow[pos >> 2] >> (2 * (3 - (pos & 3)))) & 3u;
+        const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
+        const uint32_t m0 = (a + (uint32_t) __popc(in ^ t0)) & 0xFFu;
+        const uint32_t m1 = (b + (uint32_t) __popc(in ^ t1)) & 0xFFu;
+        const bool active = pos < mysize;
+        const bool sel = active && (m1 < m0);
+        if (active) m = sel ? m1 : m0;
+        const uint64_t dec = __ballot(sel ? 1 : 0);
+        if (lane == 0) S.vit_dec[pos] = dec;
+    }
+    S.vit_metric[0][lane] = m;
+    __syncthreads();
+    dh_viterbi_finish(S, sizes, 0);
+}
+#else
+// plain statement of the same recursion for the CPU harness: metrics exchanged through the LDS arrays
+inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
     int steps = 0;
     for (int g = 0; g < 4; g++) steps = sizes[g] > steps ? sizes[g] : steps;
     DH_FOR_LANES(lane) { S.vit_metric[0][lane] = 0; }
-    DH_BARRIER();
     for (int pos = 0; pos < steps; pos++) {
         const int cur = pos & 1;
         uint64_t dec = 0;
@@ -555,35 +627,13 @@ DH_HD void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4], multiples of 
             DH_BALLOT_ACC(dec, sel, lane);
         }
         S.vit_dec[pos] = dec;
-        DH_BARRIER();
     }
-    const int fin = steps & 1;
-    DH_FOR_LANES(lane) {
-        if ((lane & 15) == 0) {
-            const int g = lane >> 4;
-            const int size = sizes[g];
-            if (size > 0) {
-                uint32_t best = 0, bm = S.vit_metric[fin][g * 16];
-                for (uint32_t i = 1; i < 16; i++) {
-                    const uint32_t m = S.vit_metric[fin][g * 16 + i];
-                    if (m < bm) { bm = m; best = i; }
-                }
-                S.vit_best_metric[g] = (uint8_t) bm;
-                for (int b = 0; b < 24; b++) S.vit_out[g][b] = 0;
-                uint32_t state = best;
-                for (int pos = size - 1; pos >= 0; pos--) {
-                    S.vit_out[g][pos >> 3] |= (uint8_t) ((state >> 3) << (7 - (pos & 7)));
-                    const uint32_t k = (uint32_t) ((S.vit_dec[pos] >> (g * 16 + state)) & 1ull);
-                    state = ((state << 1) & 0xEu) | k;
-                }
-            }
-        }
-    }
-    DH_BARRIER();
+    dh_viterbi_finish(S, sizes, steps & 1);
 }
+#endif
 
-// note: when sizes differ, a shorter codeword's metrics simply stop updating (they are copied
-// forward), so `fin` indexes the right buffer for every group.
+// note: when sizes differ, a shorter codeword's metrics simply stop updating, so the final metric
+// buffer is the right one for every group.
 
 // PN9 whitening sequence (whitening.c:6-22), packed: bits first..first+63, bit (first+j) in bit j
 constexpr uint64_t dh_pn9_word(int first) {      // bits first..first+63, bit (first+j) in bit j
@@ -715,7 +765,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         }
         s[DS_SYNC_COUNT] = (uint32_t) sync_count;
 
-        // gather the four convolutional codewords of this frame (FICH, V/D2 DCH, header CSD1/CSD2)
+        // stage 1: the two 100-dibit codewords of a frame (FICH and, speculatively, the V/D2 DCH) in one Viterbi pass
         DH_FOR_LANES(lane) {
             if (lane < 25) {
                 uint32_t f = 0, d = 0;
@@ -726,23 +776,12 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 }
                 S.vit_in[0][lane] = (uint8_t) f; S.vit_in[1][lane] = (uint8_t) d;
             }
-            if (lane < 45) {
-                uint32_t a = 0, b = 0;
-                for (int q = 0; q < 4; q++) {
-                    const int i = lane * 4 + q;
-                    const int streampos = (i % 9) * 20 + i / 9;                               // ysf_phase.cpp:323-333
-                    const int inpos = 120 + (streampos / 36) * 72 + streampos % 36;
-                    a = (a << 2) | dh_sym_at(pl, inpos);
-                    b = (b << 2) | dh_sym_at(pl, inpos + 36);
-                }
-                S.vit_in[2][lane] = (uint8_t) a; S.vit_in[3][lane] = (uint8_t) b;
-            }
         }
         DH_BARRIER();
-        // which codewords can matter: the header pair only if the (possibly stale) running FICH or the
-        // fresh one says "header"; we do not know the fresh FICH yet, so decode speculatively.
-        const int sizes[4] = { 100, 100, 180, 180 };
-        dh_viterbi_wave(S, sizes);
+        {
+            const int sizes1[4] = { 100, 100, 0, 0 };
+            dh_viterbi_wave(S, sizes1);
+        }
 
         // FICH: 4 x Golay(24,12) + CRC16 (fich.cpp:24-49)
         uint32_t fich = 0; bool fresh = true;
@@ -826,6 +865,25 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 }
             } else if (frame_type == 0) {                                           // header (:139-161)
                 dh_emit(c, DH_EV_YSF_META_RESET, 0, 1, nullptr, 0);
+                // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333)
+                DH_FOR_LANES(lane) {
+                    if (lane < 45) {
+                        uint32_t a = 0, b = 0;
+                        for (int q = 0; q < 4; q++) {
+                            const int i = lane * 4 + q;
+                            const int streampos = (i % 9) * 20 + i / 9;
+                            const int inpos = 120 + (streampos / 36) * 72 + streampos % 36;
+                            a = (a << 2) | dh_sym_at(pl, inpos);
+                            b = (b << 2) | dh_sym_at(pl, inpos + 36);
+                        }
+                        S.vit_in[2][lane] = (uint8_t) a; S.vit_in[3][lane] = (uint8_t) b;
+                    }
+                }
+                DH_BARRIER();
+                {
+                    const int sizes2[4] = { 0, 0, 180, 180 };
+                    dh_viterbi_wave(S, sizes2);
+                }
                 for (int half = 0; half < 2; half++) {
                     const uint8_t* w = S.vit_out[2 + half];
                     const uint32_t checksum = (uint32_t) w[20] << 8 | w[21];
