@@ -141,7 +141,7 @@ DH_HD float dh_div_gain(float acc, double gain, double rgain) {
 typedef float dh_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ dh_f2 dh_f2_make(float a, float b) { dh_f2 v; v.x = a; v.y = b; return v; }
 template <bool FAST> __device__ __forceinline__ dh_f2 dh_f2_mac(float c, dh_f2 w, dh_f2 acc) {
-    if (FAST) return dh_f2_make(__builtin_fmaf(c, w.x, acc.x), __builtin_fmaf(c, w.y, acc.y));
+    if (FAST) { const dh_f2 cc = dh_f2_make(c, c); return __builtin_elementwise_fma(cc, w, acc); }   // v_pk_fma_f32
     const dh_f2 p = c * w;                                 // v_pk_mul_f32, rounded
     return acc + p;                                        // v_pk_add_f32, rounded (-ffp-contract=off)
 }
@@ -205,6 +205,7 @@ struct __attribute__((aligned(4))) dh_f4 { float x, y, z, w; };
 struct alignas(16) dh_f4a { float x, y, z, w; };     // 16-byte aligned: one ds_read_b128
 DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
 DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+DH_HD void dh_store4_unaligned(float* q, const dh_f4& v) { __builtin_memcpy(q, &v, sizeof(v)); }   // global_store_dwordx4
 
 // virtual input stream of a channel for this push: carried tail followed by the new samples
 DH_HD float dh_virtual_sample(const float* tail, uint32_t tc, const float* in, uint32_t idx) {
@@ -563,35 +564,55 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
     float* out = R.out + (size_t) ch * R.out_stride;
     const uint32_t t0 = tile * DH_FTILE;
     const uint32_t cnt = dh_min<uint32_t>(DH_FTILE, R.n - t0);
-    DH_FOR_LANES(lane) {
-        // virtual stream = hist (NZ samples) ++ in; output t needs virtual [t, t+NZ]
-        for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE) {
-            const uint32_t v = t0 + e;
-            float x = 0.0f;
-            if (e < cnt + NZ) x = v < (uint32_t) NZ ? hist[v] : in[v - NZ];
-            S.xf[DH_XPAD(e)] = x;
+    // virtual stream = hist (NZ samples) ++ in; output t needs virtual [t, t+NZ]
+    if (t0 >= (uint32_t) NZ) {
+        // every tile but the first reads `in` only: 16 bytes per lane per load
+        const float* src = in + (t0 - NZ);
+        const uint32_t have = cnt + NZ;
+        DH_FOR_LANES(lane) {
+            for (uint32_t e = 4u * (uint32_t) lane; e < DH_FTILE + NZ; e += 4u * DH_WAVE) {
+                dh_f4 v; v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; v.w = 0.0f;
+                if (e + 4u <= have) v = dh_load4_unaligned(src + e);
+                else if (e < have) {
+                    v.x = src[e];
+                    if (e + 1u < have) v.y = src[e + 1u];
+                    if (e + 2u < have) v.z = src[e + 2u];
+                }
+                dh_store4(&S.xf[DH_XPAD(e)], v);
+            }
+        }
+    } else {
+        DH_FOR_LANES(lane) {
+            for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE) {
+                const uint32_t v = t0 + e;
+                float x = 0.0f;
+                if (e < cnt + NZ) x = v < (uint32_t) NZ ? hist[v] : in[v - NZ];
+                S.xf[DH_XPAD(e)] = x;
+            }
         }
     }
     DH_BARRIER();
     float tv[NZ / 2 + 1];
 #pragma unroll
     for (int i = 0; i <= NZ / 2; i++) { tv[i] = R.taps[i]; DH_TO_VGPR(tv[i]); }
-    DH_LANE_ARRAY(float, fo, DH_FIR_L);
+    // each lane owns 16 consecutive outputs = 64 contiguous bytes of the row: stored straight from registers
     DH_FOR_LANES(lane) {
-        if ((uint32_t) (lane * DH_FIR_L) < cnt)
-            dh_fir_lane<NZ, FAST>(tv, R.gain, R.rgain, R.inv_gain, S.xf, lane, DH_LA(fo, lane));
-    }
-    DH_BARRIER();
-    DH_FOR_LANES(lane) {
-        if ((uint32_t) (lane * DH_FIR_L) < cnt) {
-            float* dst = S.xf + (DH_FIR_L + 1) * lane;               // padded layout: conflict-free write-back
+        const uint32_t o0 = (uint32_t) lane * DH_FIR_L;
+        if (o0 < cnt) {
+            float fo[DH_FIR_L];
+            dh_fir_lane<NZ, FAST>(tv, R.gain, R.rgain, R.inv_gain, S.xf, lane, fo);
+            float* dst = out + t0 + o0;
+            if (o0 + DH_FIR_L <= cnt) {
 #pragma unroll
-            for (int j = 0; j < DH_FIR_L; j++) dst[j] = DH_LA(fo, lane)[j];
+                for (int q = 0; q < DH_FIR_L / 4; q++) {
+                    dh_f4 v; v.x = fo[4 * q]; v.y = fo[4 * q + 1]; v.z = fo[4 * q + 2]; v.w = fo[4 * q + 3];
+                    dh_store4_unaligned(dst + 4 * q, v);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < DH_FIR_L; j++) if (o0 + (uint32_t) j < cnt) dst[j] = fo[j];
+            }
         }
-    }
-    DH_BARRIER();
-    DH_FOR_LANES(lane) {
-        for (uint32_t e = lane; e < cnt; e += DH_WAVE) out[t0 + e] = S.xf[DH_XPAD(e)];     // coalesced store
     }
     DH_BARRIER();
 }

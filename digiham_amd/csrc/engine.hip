@@ -44,7 +44,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(co
 }
 
 template <int NZ, bool FAST>
-__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_tile(const DhRrcParams R) {
+__global__ __launch_bounds__(DH_WAVE, ((NZ > 80 || FAST) ? 2 : DH_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
     dh_rrc_tile<NZ, FAST>(R, blockIdx.y, blockIdx.x, S);
