@@ -190,9 +190,9 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        shard.barrier()
         dist.destroy_process_group()
 
 

@@ -24,18 +24,28 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     rank, world, local = rank_world()
-    if world > 1 and not dist.is_initialized():
+    # DH_FORCE_DIST=1 initialises the process group even for a single rank (exercises the RCCL path on a 1-GPU box)
+    if (world > 1 or os.environ.get("DH_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # one process per GPU: bind the device before RCCL creates its communicator
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
 def barrier():
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_report(seconds, units, device=None):
