@@ -55,6 +55,14 @@ class TorchCudaMemory:
         return self.torch.is_tensor(x) and x.is_cuda
 
 
+def parse_lc(payload):
+    """Fields of a 9-byte DMR link control word (DH_EV_DMR_LC payload): what Digiham::Dmr::Lc's getters return
+    (src/dmr_decoder/lc.cpp:26-43)."""
+    d = bytes(bytearray(payload[:9]))
+    return {"opcode": d[0] & 0x3F, "feature_set_id": d[1], "target": d[3] << 16 | d[4] << 8 | d[5],
+            "source": d[6] << 16 | d[7] << 8 | d[8], "data": d[2:9]}
+
+
 def _check(rc, what, lib):
     if rc != 0:
         raise DhError(rc, what, lib.dh_last_error().decode(errors="replace"))

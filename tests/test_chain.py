@@ -141,3 +141,23 @@ def test_decoder_only_engine(ctx, oracle):
             o, ev = d.process(syms[b])
             assert (np.concatenate(got_f[b]) == o).all()
             assert np.concatenate(got_e[b]).tobytes() == ev.tobytes()
+
+
+def test_lc_fields_from_events(ctx):
+    """The LC words carried by DH_EV_DMR_LC events decode to the source / target ids the generator put in
+    (Digiham::Dmr::Lc getters, lc.cpp:26-43) -- for the voice-header LC (BPTC) and the embedded LC alike."""
+    from digiham_amd import api
+    rng = np.random.default_rng(77)
+    bursts = synth.dmr_call(rng, 0, cc=5, dst=1234, src=5678901, n_superframes=3)
+    idle = [synth.dmr_idle_burst(1, 5, rng) for _ in bursts]
+    s = list(rng.integers(0, 4, 341))            # the slicer's AGC needs ~100 symbols to settle (zeroed volume ring)
+    for a, b in zip(bursts, idle):
+        s += a + b
+    s += list(rng.integers(0, 4, 300))
+    x = synth.shape(np.array(s, np.uint8))[None, :]
+    res = run_engine(ctx, x, "dmr", [x.shape[1]])
+    lcs = [e for e in res["events"][0] if e["type"] == 4]
+    assert {int(e["b"]) for e in lcs} == {0, 1}            # from the voice header and from the embedded signalling
+    for e in lcs:
+        f = api.parse_lc(e["payload"])
+        assert (f["opcode"], f["target"], f["source"]) == (0, 1234, 5678901)
