@@ -61,5 +61,9 @@ def test_reset_restores_initial_state(gpu_ctx):
     eng.reset()
     eng.push(x); c = eng.frames(); sc_ = eng.symbols()
     eng.close()
-    assert (a[1] == c[1]).all() and (a[0] == c[0]).all() and (sa[0] == sc_[0]).all()
-    assert not ((a[1] == b[1]).all() and (a[0] == b[0]).all())   # the second push continued the stream
+    B = 64
+    assert (a[1] == c[1]).all() and (sa[1] == sc_[1]).all()
+    assert _digest(a[0], a[1]) == _digest(c[0], c[1]) and _digest(sa[0], sa[1]) == _digest(sc_[0], sc_[1])
+    assert int(a[1].sum()) > 0
+    # the second push continued the stream (decoder already in sync, timing already settled): not the same bytes
+    assert _digest(a[0], a[1]) != _digest(b[0], b[1])
