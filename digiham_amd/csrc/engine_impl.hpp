@@ -77,6 +77,7 @@ inline void fill_taps(int rrc, float* half, double* gain) {
 //   void* alloc(size_t bytes); void free(void*);
 //   int zero(void* p, size_t bytes);                       // async on the engine stream
 //   int upload(void* dst, const void* src, size_t bytes);  // host -> device, async
+//   int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
 //   int download(void* dst, const void* src, size_t bytes);// device -> host, synchronous
 //   int sync();
 //   int launch_rrc_demod(const DhDspParams&, uint32_t nz, bool fast);
@@ -220,8 +221,8 @@ struct Engine {
     int push_host(const float* h_in, size_t stride, size_t n) {
         if (!h_in || n > L.max_samples || stride < n) return DH_EINVAL;
         if (!staging) { staging = (float*) be.alloc(sizeof(float) * (size_t) L.B * L.max_samples); if (!staging) return DH_ENOMEM; }
-        for (uint32_t ch = 0; ch < L.B; ch++)
-            if (be.upload(staging + (size_t) ch * L.max_samples, h_in + (size_t) ch * stride, sizeof(float) * n)) return DH_EDEVICE;
+        // one strided copy for the whole batch (rows of n floats, host pitch `stride`, device pitch max_samples)
+        if (be.upload2d(staging, sizeof(float) * L.max_samples, h_in, sizeof(float) * stride, sizeof(float) * n, L.B)) return DH_EDEVICE;
         return push(staging, L.max_samples, n);
     }
 
