@@ -14,7 +14,7 @@ DH_OK, DH_EINVAL, DH_ENOMEM, DH_EDEVICE, DH_ENODEV, DH_ECAPACITY = 0, -1, -2, -3
 RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2}
 DEMOD = {"none": 0, None: 0, "fsk": 2, "fsk2": 2, "gfsk": 4, "gfsk4": 4}
 PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2}
-FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS = 1, 2, 4, 8
+FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED_TIMING = 1, 2, 4, 8, 16
 
 
 class EngineConfig(C.Structure):
@@ -30,7 +30,7 @@ class DhError(RuntimeError):
         self.code = code
 
 
-def declare(L):
+def declare(L, lenient=False):
     """Attach argtypes / restypes for every symbol of include/digiham_amd.h."""
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.dh_version.restype = C.c_char_p
@@ -61,8 +61,12 @@ def declare(L):
         "dh_engine_sync": [vp],
         "dh_engine_timing_enable": [vp, u32],
         "dh_engine_timing_read": [vp, vp, vp, vp, C.POINTER(u32)],
+        "dh_engine_timing_stats": [vp, vp, vp],
+        "dh_engine_debug_header": [vp, u32, vp],
     }
     for name, args in sig.items():
+        if lenient and not hasattr(L, name):        # A/B build variants of older sources (tools/) may lack new entry points
+            continue
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
@@ -79,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "dh_engine_set_slot_filter", "dh_engine_push", "dh_engine_push_host", "dh_engine_push_symbols",
     "dh_engine_filtered", "dh_engine_symbols", "dh_engine_frames", "dh_engine_events", "dh_engine_read_symbols",
     "dh_engine_read_frames", "dh_engine_read_events", "dh_engine_read_filtered", "dh_engine_sync",
-    "dh_engine_timing_enable", "dh_engine_timing_read",
+    "dh_engine_timing_enable", "dh_engine_timing_read", "dh_engine_timing_stats", "dh_engine_debug_header",
 ]
 
 _LIB = None
@@ -101,7 +105,7 @@ def load(path=None):
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = declare(C.CDLL(p))
+    L = declare(C.CDLL(p), lenient=path is not None)
     if path is None:
         _LIB = L
     return L

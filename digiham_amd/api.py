@@ -145,11 +145,12 @@ class Engine:
     """B independent `rrc_filter | gfsk_demodulator | dmr_decoder` pipes with state resident in HBM."""
 
     def __init__(self, n_channels, max_samples, rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=False,
-                 keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0):
+                 keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False):
         self.ctx = ctx if ctx is not None else Context(device=device)
         lib, mem = self.ctx.lib, self.ctx.mem
         flags = (_capi.FLAG_FAST_FIR if fast_fir else 0) | (_capi.FLAG_KEEP_FILTERED if keep_filtered else 0) | \
-                (_capi.FLAG_FSK_INVERT if invert else 0) | (0 if events else _capi.FLAG_NO_EVENTS)
+                (_capi.FLAG_FSK_INVERT if invert else 0) | (0 if events else _capi.FLAG_NO_EVENTS) | \
+                (_capi.FLAG_ORDERED_TIMING if ordered_timing else 0)
         cfg = _capi.EngineConfig(C.sizeof(_capi.EngineConfig), getattr(mem, "index", 0), n_channels, max_samples,
                                  _capi.RRC[rrc], _capi.DEMOD[demod], sps, _capi.PROTO[proto], flags, slot_filter,
                                  mem.stream())
@@ -208,6 +209,18 @@ class Engine:
         _check(self.ctx.lib.dh_engine_timing_read(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                                   c.ctypes.data_as(C.c_void_p), C.byref(n)), "dh_engine_timing_read", self.ctx.lib)
         return a[:n.value], b[:n.value], c[:n.value]
+
+    def timing_stats(self):
+        """(blocks, ordered) per channel: 100-symbol timing blocks evaluated, and those decided by the in-order chain."""
+        blocks, ordered = np.zeros(self.B, np.uint32), np.zeros(self.B, np.uint32)
+        _check(self.ctx.lib.dh_engine_timing_stats(self._h, blocks.ctypes.data_as(C.c_void_p), ordered.ctypes.data_as(C.c_void_p)),
+               "dh_engine_timing_stats", self.ctx.lib)
+        return blocks, ordered
+
+    def debug_header(self, word):
+        out = np.zeros(self.B, np.uint32)
+        _check(self.ctx.lib.dh_engine_debug_header(self._h, word, out.ctypes.data_as(C.c_void_p)), "dh_engine_debug_header", self.ctx.lib)
+        return out
 
     def sync(self):
         _check(self.ctx.lib.dh_engine_sync(self._h), "dh_engine_sync", self.ctx.lib)

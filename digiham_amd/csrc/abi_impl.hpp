@@ -121,6 +121,14 @@ int dh_engine_events(dh_engine* e, const dh_event** d, size_t* stride, const uin
     if (cnt) *cnt = e->impl.ev_count;
     return DH_OK;
 }
+int dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out) {
+    if (!e) return DH_EINVAL;
+    return e->impl.debug_header(word, h_out);
+}
+int dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered) {
+    if (!e) return DH_EINVAL;
+    return e->impl.timing_stats(h_blocks, h_ordered);
+}
 int dh_engine_read_symbols(dh_engine* e, uint32_t ch, uint8_t* h, size_t* n) {
     if (!e || !e->impl.syms) return DH_EINVAL;
     return e->impl.read_row(e->impl.syms, e->impl.L.sym_stride, ch, e->impl.sym_count, 1, h, n);

@@ -32,11 +32,12 @@
 #define DH_STATE_HDR 16              // u32 words of per-channel header
 
 // per-channel state block in HBM (floats / u32 words, AoS, `state_stride` words apart):
-//   [0..15]                      header: k, pending offset, tail count, symbols produced (lo), ...
+//   [0..15]                      header: k, pending offset, tail count, symbols produced (lo),
+//                                timing blocks decided by the ordered chain, timing blocks total, ...
 //   [16 .. 16+100)               volume ring  (volume_rb)
 //   [116 .. 116+100*sps)         variance ring (variance_rb), phase-major: [sample i][symbol k]
 //   [.. + DH_TAIL_MAX)           raw-sample tail: the last nz inputs + not yet consumed samples
-enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3 };
+enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED = 4, DH_ST_BLOCKS = 5 };
 #define DH_ST_VOL DH_STATE_HDR
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
 
@@ -52,6 +53,7 @@ struct DhDspParams {
     int32_t levels, invert;                            // 4 = GFSK, 2 = FSK
     uint32_t nz;                                       // FIR order (0 = no RRC stage)
     int32_t fast;                                      // 1 = FMA FIR
+    int32_t ordered_timing;                            // 1 = always run the ordered variance chain (DH_FLAG_ORDERED_TIMING)
     double gain, rgain; float inv_gain;                // rgain = 1/gain rounded to double
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
 };
@@ -67,9 +69,14 @@ struct DhDspShared {
     float xf[DH_XPAD(DH_FTILE + DH_MAX_NZ) + 1];
     float vol_old[DH_SCAN_N];                          // ring content before the current run (+ identity padding)
     float vol_new[DH_SCAN_N];                          // entries written by the current run
-    float mn[DH_SCAN_N], mx[DH_SCAN_N];                // AGC window min / max per symbol of the block
+    alignas(16) float mn[DH_SCAN_N];                   // AGC window min / max per symbol of the block; after the
+    alignas(16) float mx[DH_SCAN_N];                   // slice (P5) both are scratch for the timing estimate (P6)
     float sum[DH_VOLUME_RB_SIZE];                      // mid-symbol window sums of the current run
     double variance[DH_MAX_SPS];
+    uint32_t stats[2];                                 // timing blocks of this push: all / decided by the ordered chain
+#ifdef DH_PHASE_CLOCKS
+    uint32_t clk[8];
+#endif
     float tapsf[DH_MAX_NZ / 2 + 1];                    // FIR taps (first half + centre)
     // variance ring follows (sps rows of 100 floats: row i holds sample i of the last 100 symbols), sized at launch
     alignas(16) float var_rb[4];
@@ -78,6 +85,17 @@ struct DhDspShared {
 DH_HD size_t dh_dsp_shared_bytes(uint32_t sps) {
     return sizeof(DhDspShared) + sizeof(float) * (size_t) (DH_VARIANCE_SYMBOLS * sps) + 16;
 }
+
+// Diagnostic build (-DDH_PHASE_CLOCKS, tools/build_variant.sh): per-phase shader-clock totals of each channel's
+// wavefront, accumulated in LDS and added to header words 6.. of the channel state (units of 64 cycles);
+// read them with dh_engine_debug_header().  Not compiled into the product library.
+#if defined(DH_PHASE_CLOCKS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_CLK_BEGIN() uint64_t dh_clk_t = clock64()
+#define DH_CLK(i) do { const uint64_t dh_clk_n = clock64(); if (threadIdx.x == 0) S.clk[i] += (uint32_t) (dh_clk_n - dh_clk_t); dh_clk_t = clock64(); } while (0)
+#else
+#define DH_CLK_BEGIN() ((void) 0)
+#define DH_CLK(i) ((void) 0)
+#endif
 
 // per-lane values that must survive a barrier: registers on the GPU, [lane] arrays in the harness
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -155,32 +173,11 @@ template <bool FAST> inline dh_f2 dh_f2_mac(float c, dh_f2 w, dh_f2 acc) {
 }
 #endif
 #define DH_FIR_H (DH_FIR_L / 2)
+#define DH_XLOFF(e) ((e) + ((e) >> 4))                 // dword offset of window element e from the lane's base
 
-template <int NZ, bool FAST>
-DH_HD void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
-    // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
-    const float* xs = xs_all + (DH_FIR_L + 1) * lane;
-#define DH_XL(e) xs[(e) + ((e) >> 4)]
-    dh_f2 accp[DH_FIR_H], w[DH_FIR_H];
-#pragma unroll
-    for (int j = 0; j < DH_FIR_H; j++) {
-        accp[j] = dh_f2_make(0.0f, 0.0f);
-        w[j] = dh_f2_make(DH_XL(j), DH_XL(j + DH_FIR_H));
-    }
-#pragma unroll
-    for (int i = 0; i <= NZ; i++) {
-        const float c = taps[i <= NZ / 2 ? i : NZ - i];
-#pragma unroll
-        for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac<FAST>(c, w[j], accp[j]);
-        if (i < NZ) {
-#pragma unroll
-            for (int j = 0; j < DH_FIR_H - 1; j++) w[j] = w[j + 1];
-            w[DH_FIR_H - 1] = dh_f2_make(DH_XL(DH_FIR_H + i), DH_XL(2 * DH_FIR_H + i));
-        }
-    }
-    float acc[DH_FIR_L];
-#pragma unroll
-    for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
+// (float)((double)acc / gain) for the 16 accumulators of a lane, see dh_div_gain_fast
+template <bool FAST>
+DH_HD void dh_fir_finish(const float* acc, double gain, double rgain, float inv_gain, float* out16) {
     if (FAST) {
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) out16[j] = acc[j] * inv_gain;
@@ -199,6 +196,102 @@ DH_HD void dh_fir_lane(const float* taps, double gain, double rgain, float inv_g
         }
     }
 }
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// Window pairs come from LDS through inline asm: every sample is needed twice, 8 taps apart -- first as the high
+// half of a pair, then as the low half of another.  Given ordinary loads the compiler keeps the first copy, pairs
+// up adjacent addresses instead, and shuffles halves with ~2 v_mov per tap on the VALU, which is the bottleneck
+// of this kernel; the LDS pipe is idle.  One ds_read2_b32 per tap delivers (x[t], x[t+8]) straight into an aligned
+// register pair.  The loads run one batch of DH_FIR_G taps ahead of the arithmetic; the compiler does not track
+// them, so each batch passes through an explicit `s_waitcnt lgkmcnt(0)` (robust against any other LDS / scalar
+// memory operation the compiler may have in flight) before its first use.
+#define DH_FIR_G 4
+template <int O0, int O1> __device__ __forceinline__ dh_f2 dh_lds_read2(uint32_t addr) {
+    static_assert(O0 < 256 && O1 < 256, "ds_read2_b32 offsets are 8-bit dword counts");
+    dh_f2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
+// pair i of the slide sequence: (x[8 + i], x[16 + i]), consumed when tap i has been accumulated
+template <int NZ, int I> __device__ __forceinline__ void dh_fir_issue_one(uint32_t addr, dh_f2& d) {
+    if constexpr (I < NZ) d = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr);
+    else d = dh_f2_make(0.0f, 0.0f);
+}
+template <int NZ, int B> __device__ __forceinline__ void dh_fir_issue(uint32_t addr, dh_f2 (&d)[DH_FIR_G]) {
+    dh_fir_issue_one<NZ, B * DH_FIR_G + 0>(addr, d[0]); dh_fir_issue_one<NZ, B * DH_FIR_G + 1>(addr, d[1]);
+    dh_fir_issue_one<NZ, B * DH_FIR_G + 2>(addr, d[2]); dh_fir_issue_one<NZ, B * DH_FIR_G + 3>(addr, d[3]);
+}
+__device__ __forceinline__ void dh_fir_arrived(dh_f2 (&d)[DH_FIR_G]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
+}
+template <int NZ, bool FAST, int B> struct DhFirBatch {
+    static __device__ __forceinline__ void run(const float* taps, uint32_t addr, dh_f2 (&accp)[DH_FIR_H], dh_f2 (&w)[DH_FIR_H], dh_f2 (&cur)[DH_FIR_G]) {
+        if constexpr (B * DH_FIR_G <= NZ) {
+            dh_f2 nxt[DH_FIR_G];
+            dh_fir_issue<NZ, B + 1>(addr, nxt);
+#pragma unroll
+            for (int g = 0; g < DH_FIR_G; g++) {
+                const int i = B * DH_FIR_G + g;
+                if (i <= NZ) {
+                    const float c = taps[i <= NZ / 2 ? i : NZ - i];
+#pragma unroll
+                    for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac<FAST>(c, w[j], accp[j]);
+                    if (i < NZ) {
+#pragma unroll
+                        for (int j = 0; j < DH_FIR_H - 1; j++) w[j] = w[j + 1];
+                        w[DH_FIR_H - 1] = cur[g];
+                    }
+                }
+            }
+            if constexpr ((B + 1) * DH_FIR_G < NZ) dh_fir_arrived(nxt);
+            DhFirBatch<NZ, FAST, B + 1>::run(taps, addr, accp, w, nxt);
+        }
+    }
+};
+
+template <int NZ, bool FAST>
+__device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
+    // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
+    const uint32_t addr = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (xs_all + (DH_FIR_L + 1) * lane);
+    dh_f2 accp[DH_FIR_H], w[DH_FIR_H], cur[DH_FIR_G];
+    w[0] = dh_lds_read2<DH_XLOFF(0), DH_XLOFF(8)>(addr);  w[1] = dh_lds_read2<DH_XLOFF(1), DH_XLOFF(9)>(addr);
+    w[2] = dh_lds_read2<DH_XLOFF(2), DH_XLOFF(10)>(addr); w[3] = dh_lds_read2<DH_XLOFF(3), DH_XLOFF(11)>(addr);
+    w[4] = dh_lds_read2<DH_XLOFF(4), DH_XLOFF(12)>(addr); w[5] = dh_lds_read2<DH_XLOFF(5), DH_XLOFF(13)>(addr);
+    w[6] = dh_lds_read2<DH_XLOFF(6), DH_XLOFF(14)>(addr); w[7] = dh_lds_read2<DH_XLOFF(7), DH_XLOFF(15)>(addr);
+    dh_fir_issue<NZ, 0>(addr, cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) :: "memory");
+    dh_fir_arrived(cur);
+#pragma unroll
+    for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_make(0.0f, 0.0f);
+    DhFirBatch<NZ, FAST, 0>::run(taps, addr, accp, w, cur);
+    float acc[DH_FIR_L];
+#pragma unroll
+    for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
+    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16);
+}
+#else
+template <int NZ, bool FAST>
+inline void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
+    const float* xs = xs_all + (DH_FIR_L + 1) * lane;
+#define DH_XL(e) xs[DH_XLOFF(e)]
+    dh_f2 accp[DH_FIR_H], w[DH_FIR_H];
+    for (int j = 0; j < DH_FIR_H; j++) {
+        accp[j] = dh_f2_make(0.0f, 0.0f);
+        w[j] = dh_f2_make(DH_XL(j), DH_XL(j + DH_FIR_H));
+    }
+    for (int i = 0; i <= NZ; i++) {
+        const float c = taps[i <= NZ / 2 ? i : NZ - i];
+        for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac<FAST>(c, w[j], accp[j]);
+        if (i < NZ) {
+            for (int j = 0; j < DH_FIR_H - 1; j++) w[j] = w[j + 1];
+            w[DH_FIR_H - 1] = dh_f2_make(DH_XL(DH_FIR_H + i), DH_XL(2 * DH_FIR_H + i));
+        }
+    }
+    float acc[DH_FIR_L];
+    for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
+    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16);
+}
+#endif
 
 // four consecutive floats from a 4-byte-aligned address (global_load_dwordx4: gfx950 allows dword alignment)
 struct __attribute__((aligned(4))) dh_f4 { float x, y, z, w; };
@@ -289,7 +382,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
     const float* in = P.in + (size_t) ch * P.in_stride;
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
+    const float* in_end = P.in + (size_t) (P.n_channels - 1u) * P.in_stride + P.n;    // end of the readable input
 
+    DH_CLK_BEGIN();
     // ---- load carried state
     uint32_t k0 = sth[DH_ST_K];
     int32_t off = (int32_t) sth[DH_ST_OFF];
@@ -309,6 +404,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // must end with the FIR, or they pin ~80 registers through the latency-bound phases where the prefetch lives.
     DH_FOR_LANES(lane) {
         for (int i = lane; i <= NZ / 2; i += DH_WAVE) S.tapsf[i] = P.taps[i];
+        if (lane < 2) S.stats[lane] = 0;
+#ifdef DH_PHASE_CLOCKS
+        if (lane < 8) S.clk[lane] = 0;
+#endif
     }
 
     uint32_t p = 0;                                     // read position in the filtered stream
@@ -317,6 +416,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     bool overflow = false;
     const uint32_t max_run = (DH_FTILE - 2) / sps;      // symbols whose windows fit one FIR pass
 
+    DH_CLK(7);
     for (;;) {
         // ---- run planning (wave-uniform): symbols k0 .. k0+m-1 of the current variance block.
         // A symbol at filtered position s is produced iff nf - s > sps + 1 (gfsk_demodulator.cpp:18-22);
@@ -366,6 +466,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         DH_BARRIER();
+        DH_CLK(0);
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
         // The filtered samples keep the padded layout (element n at DH_XPAD(n)): the 16-words-apart write-back
@@ -390,6 +491,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
             DH_BARRIER();
         }
+        DH_CLK(1);
         const float* fbuf = S.xf;
 #define DH_FB(n) fbuf[DH_XPAD(n)]
 
@@ -411,6 +513,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         DH_BARRIER();
+        DH_CLK(2);
 
         // ---- prefetch: the raw window of the NEXT run.  Its start is already known (the timing decision of this
         // block only moves symbols 1.. of the next one), the window block is idle from here to the end of the
@@ -420,20 +523,17 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const bool pf_ok = p_next >= tc && p_next < nv;
         const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
         DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
-        if (pf_ok) {
+        // Only when the whole window lies inside the input buffer (every run but the last ones of the last
+        // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
+        // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
+        const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
+        if (pf_plain) {
             const float* src = in + (p_next - tc);
             DH_FOR_LANES(lane) {
 #pragma unroll
                 for (int r = 0; r < DH_PF_N; r++) {
                     const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                    dh_f4 v; v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; v.w = 0.0f;
-                    if (e + 4u <= pf_have) v = dh_load4_unaligned(src + e);
-                    else if (e < pf_have) {
-                        v.x = src[e];
-                        if (e + 1u < pf_have) v.y = src[e + 1u];
-                        if (e + 2u < pf_have) v.z = src[e + 2u];
-                    }
-                    DH_LA(pf, lane)[r] = v;
+                    DH_LA(pf, lane)[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
                 }
             }
         }
@@ -445,6 +545,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         dh_agc_scan(S, k0, k0 + m);
 #endif
         DH_BARRIER();
+        DH_CLK(3);
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
         DH_FOR_LANES(lane) {
@@ -466,35 +567,121 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
 
+        DH_CLK(4);
         // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
+        // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
+        // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
+        // 100-long dependent chain on `sps` lanes.  For sps = 10 an estimate with a proven error bound is taken
+        // first: 50 lanes = 10 phases x 5 groups of 20 symbols, partial sums combined through LDS.  With
+        //   A = mean |x|, u = 2^-24:  |mean_ref - mu| <= 100.1 u A,  |mean' - mu| <= 24.1 u A
+        //   F(m) = sum (m - x)^2 / 100 = sigma^2 + (m - mu)^2  =>  |F(mean') - F(mean_ref)| <= (100.1 u A)^2 < 3.6e-11 A^2
+        //   double rounding of either summation order <= 104 * 2^-53 F < 1.2e-14 F
+        // so |V' - V_ref| <= tol = 1e-10 A^2 + 1e-13 V' + 1e-88 (the last term covers float-subnormal means).
+        // If the bound separates the smallest V' from every other phase, from 0 and from 5e6, the decision is
+        // the reference's; otherwise (exact ties, constant input, non-finite samples) the ordered chain decides.
         int32_t new_off = 0;
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done) {
-            // Both sums of a phase must run in symbol order (float total, then double sum of squared deviations):
-            // one phase per lane, its 100 samples contiguous in the transposed ring and fetched 16 bytes at a time,
-            // five loads in flight per batch.  Only `sps` lanes work here, but the chain is latency- not issue-bound.
-            DH_FOR_LANES(lane) {
-                if ((uint32_t) lane < sps) {
-                    const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
-                    float total = 0.0f;
-#pragma unroll 5
-                    for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
-                        const dh_f4a v = row[q];
-                        total += v.x; total += v.y; total += v.z; total += v.w;
+            bool ordered = true;
+            if (SPS == 10 && !P.ordered_timing) {
+                DH_BARRIER();                                   // mn / mx are dead from here: scratch
+                float* psum = S.mn; float* pabs = S.mn + DH_WAVE;
+                double* pd = reinterpret_cast<double*>(S.mx);
+                DH_FOR_LANES(lane) {
+                    if (lane < 50) {
+                        const int i = lane % 10, g = lane / 10;
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
+                        float sx = 0.0f, sa = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const dh_f4a v = row[q];
+                            sx += v.x; sx += v.y; sx += v.z; sx += v.w;
+                            sa += __builtin_fabsf(v.x); sa += __builtin_fabsf(v.y); sa += __builtin_fabsf(v.z); sa += __builtin_fabsf(v.w);
+                        }
+                        psum[lane] = sx; pabs[lane] = sa;
                     }
-                    const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
-                    double dsum = 0.0;
-#pragma unroll 5
-                    for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
-                        const dh_f4a v = row[q];
-                        const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
-                        const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
-                        dsum += s0; dsum += s1; dsum += s2; dsum += s3;
+                }
+                DH_BARRIER();
+                DH_FOR_LANES(lane) {
+                    if (lane < 50) {
+                        const int i = lane % 10, g = lane / 10;
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
+                        const float total = (((psum[i] + psum[i + 10]) + psum[i + 20]) + psum[i + 30]) + psum[i + 40];
+                        const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const dh_f4a v = row[q];
+                            const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
+                            acc = __builtin_fma(d0, d0, acc); acc = __builtin_fma(d1, d1, acc);
+                            acc = __builtin_fma(d2, d2, acc); acc = __builtin_fma(d3, d3, acc);
+                        }
+                        pd[lane] = acc;
                     }
-                    S.variance[lane] = dsum / (double) DH_VARIANCE_SYMBOLS;
+                }
+                DH_BARRIER();
+                DH_FOR_LANES(lane) {
+                    if (lane < 10) {
+                        const int i = lane;
+                        const double v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) / (double) DH_VARIANCE_SYMBOLS;
+                        const float asum = (((pabs[i] + pabs[i + 10]) + pabs[i + 20]) + pabs[i + 30]) + pabs[i + 40];
+                        const double a = (double) asum * 0.01;
+                        double tol = 1e-10 * a * a + 1e-13 * v + 1e-88;
+                        if (!(asum < 1e37f)) tol = __builtin_inf();      // float sums may have overflowed: no bound
+                        if (asum == 0.0f) tol = -1.0;                   // every sample of the phase is 0: V_ref is exactly 0
+                        S.variance[i] = v; S.variance[10 + i] = tol;
+                    }
+                }
+                DH_BARRIER();
+                double best = S.variance[0]; uint32_t bpos = 0;
+                bool finite = true, zero_phase = false;
+                for (uint32_t i = 0; i < 10; i++) {
+                    const double v = S.variance[i], t = S.variance[10 + i];
+                    if (i > 0 && v < best) { best = v; bpos = i; }
+                    if (!(v < 1e300) || !(t < 1e300)) finite = false;
+                    if (t < 0) zero_phase = true;
+                }
+                if (finite && zero_phase) {
+                    ordered = false;                            // the minimum over finite variances >= 0 is an exact 0 -> "vmin <= 0"
+                } else if (finite) {
+                    const double btol = S.variance[10 + bpos];
+                    const double hi = best + btol;
+                    ordered = false;
+                    for (uint32_t i = 0; i < 10; i++)
+                        if (i != bpos && !(S.variance[i] - S.variance[10 + i] > hi)) ordered = true;
+                    if (!(best - btol > 0.0)) ordered = true;
+                    if (!(hi < 4999999.0)) ordered = true;
                 }
             }
-            DH_BARRIER();
+            if (ordered) {
+                // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
+                // ring and fetched 16 bytes at a time
+                DH_BARRIER();
+                DH_FOR_LANES(lane) {
+                    if ((uint32_t) lane < sps) {
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
+                        float total = 0.0f;
+#pragma unroll 5
+                        for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                            const dh_f4a v = row[q];
+                            total += v.x; total += v.y; total += v.z; total += v.w;
+                        }
+                        const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
+                        double dsum = 0.0;
+#pragma unroll 5
+                        for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                            const dh_f4a v = row[q];
+                            const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
+                            const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+                            dsum += s0; dsum += s1; dsum += s2; dsum += s3;
+                        }
+                        S.variance[lane] = dsum / (double) DH_VARIANCE_SYMBOLS;
+                    }
+                }
+                DH_BARRIER();
+                DH_FOR_LANES(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+            }
+            DH_FOR_LANES(lane) { if (DH_IS_LANE0(lane)) S.stats[0]++; }
             double vmin = S.variance[0]; uint32_t vmin_pos = 0;
             for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
             if (vmin <= 0 || vmin > 5000000) {
@@ -502,24 +689,39 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
         }
 
+        DH_CLK(5);
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
         DH_FOR_LANES(lane) {
             for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k];
-            if (pf_ok) {
+            if (pf_plain && pf_have >= DH_FTILE + NZ) {         // the usual case: a full window, stored as loaded
 #pragma unroll
                 for (int r = 0; r < DH_PF_N; r++) {
                     const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
                     if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XPAD(e)], DH_LA(pf, lane)[r]);
                 }
+            } else if (pf_plain) {                              // last window of the push: zeros beyond the input
+                uint32_t l4 = 4u * (uint32_t) lane;
+                DH_TO_VGPR(l4);                                 // recomputed here, not hoisted (and spilled) across the FIR
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
+                    if (e < DH_FTILE + NZ) {
+                        dh_f4 v = DH_LA(pf, lane)[r];
+                        v.x = e + 0u < pf_have ? v.x : 0.0f; v.y = e + 1u < pf_have ? v.y : 0.0f;
+                        v.z = e + 2u < pf_have ? v.z : 0.0f; v.w = e + 3u < pf_have ? v.w : 0.0f;
+                        dh_store4(&S.xf[DH_XPAD(e)], v);
+                    }
+                }
             }
         }
-        staged = pf_ok; staged_p = p_next;
+        staged = pf_plain; staged_p = p_next;
         DH_BARRIER();
         p = p_next;
         nsym += m;
         if (k0 == 0) off = 0;                           // the pending step has been consumed (:36-38)
         k0 += m;
         if (block_done) { k0 = 0; off = new_off; }
+        DH_CLK(6);
     }
 
     // ---- write back state: rings, header, and the raw tail V[p .. nv)
@@ -538,6 +740,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             sth[DH_ST_OFF] = (uint32_t) off;
             sth[DH_ST_TAIL] = new_tc < DH_TAIL_MAX ? new_tc : DH_TAIL_MAX;
             sth[DH_ST_NSYM] += nsym;
+#ifdef DH_PHASE_CLOCKS
+            for (int i = 0; i < 8; i++) sth[6 + i] += S.clk[i] >> 6;
+#endif
+            sth[DH_ST_BLOCKS] += S.stats[0];
+            sth[DH_ST_ORDERED] += S.stats[1];
             P.sym_count[ch] = nsym;
             if ((overflow || new_tc > DH_TAIL_MAX) && P.overflow) *P.overflow = 1u;
         }

@@ -181,6 +181,11 @@ struct HipBackend {
         // pageable source: hipMemcpyAsync stages it before returning, so the caller may free `src`
         return hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)");
     }
+    int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+        if (!width || !rows) return 0;
+        if (hip_fail(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, stream), "hipMemcpy2DAsync(D2H)")) return -1;
+        return hip_fail(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    }
     int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
         if (!width || !rows) return 0;
         return hip_fail(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, stream), "hipMemcpy2DAsync(H2D)");

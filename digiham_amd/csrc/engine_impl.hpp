@@ -77,6 +77,7 @@ inline void fill_taps(int rrc, float* half, double* gain) {
 //   void* alloc(size_t bytes); void free(void*);
 //   int zero(void* p, size_t bytes);                       // async on the engine stream
 //   int upload(void* dst, const void* src, size_t bytes);  // host -> device, async
+//   int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);  // synchronous
 //   int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
 //   int download(void* dst, const void* src, size_t bytes);// device -> host, synchronous
 //   int sync();
@@ -205,6 +206,7 @@ struct Engine {
             dsp.sps = L.sps; dsp.lo = L.lo; dsp.hi = L.hi;
             dsp.levels = L.demod; dsp.invert = (L.flags & DH_FLAG_FSK_INVERT) ? 1 : 0;
             dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast;
+            dsp.ordered_timing = (L.flags & DH_FLAG_ORDERED_TIMING) ? 1 : 0;
             if (L.fused) { fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain; }
             rc |= be.launch_rrc_demod(dsp, dsp.nz, fast);
         }
@@ -237,6 +239,20 @@ struct Engine {
         uint32_t flag = 0;
         if (be.download(&flag, overflow, sizeof(flag))) return DH_EDEVICE;
         return flag ? DH_ECAPACITY : DH_OK;
+    }
+
+    // per-channel header words of the slicer state: timing blocks evaluated / decided by the ordered chain
+    int timing_stats(uint32_t* h_blocks, uint32_t* h_ordered) {
+        if (!dsp_state) return DH_EINVAL;
+        const size_t pitch = sizeof(uint32_t) * L.state_words;
+        if (h_blocks && be.download2d(h_blocks, sizeof(uint32_t), dsp_state + DH_ST_BLOCKS, pitch, sizeof(uint32_t), L.B)) return DH_EDEVICE;
+        if (h_ordered && be.download2d(h_ordered, sizeof(uint32_t), dsp_state + DH_ST_ORDERED, pitch, sizeof(uint32_t), L.B)) return DH_EDEVICE;
+        return DH_OK;
+    }
+
+    int debug_header(uint32_t word, uint32_t* h_out) {
+        if (!dsp_state || word >= DH_STATE_HDR || !h_out) return DH_EINVAL;
+        return be.download2d(h_out, sizeof(uint32_t), dsp_state + word, sizeof(uint32_t) * L.state_words, sizeof(uint32_t), L.B) ? DH_EDEVICE : DH_OK;
     }
 
     int read_row(const void* base, size_t row_bytes, uint32_t channel, const uint32_t* counts, size_t elem, void* h_out, size_t* n) {

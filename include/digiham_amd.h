@@ -102,6 +102,7 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2 };
 #define DH_FLAG_KEEP_FILTERED   0x2   /* also materialise the RRC output [B][n] (unfused path; BASELINE config 2) */
 #define DH_FLAG_FSK_INVERT      0x4   /* FskDemodulator(sps, invert = true) */
 #define DH_FLAG_NO_EVENTS       0x8   /* do not record decoder events */
+#define DH_FLAG_ORDERED_TIMING  0x10  /* always run the in-order variance chain of the timing recovery (diagnostic; results are identical) */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(dh_engine_config) */
@@ -166,6 +167,12 @@ int  dh_engine_read_filtered(dh_engine* e, uint32_t channel, float* h_out, size_
  * kernel and the decoder kernel.  *n in: capacity of the arrays, out: pushes recorded. */
 int  dh_engine_timing_enable(dh_engine* e, uint32_t max_pushes);
 int  dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float* decoder_ms, uint32_t* n);
+/* Timing-recovery statistics since create/reset, per channel (host arrays of n_channels, either may be NULL):
+ * blocks = 100-symbol variance blocks evaluated (gfsk_demodulator.cpp:41-80), ordered = those in which the
+ * error-bounded estimate could not separate the phases and the reference's in-order sums decided. Synchronises. */
+int  dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered);
+/* Diagnostic: word `word` (0..15) of every channel's slicer state header into h_out[n_channels]. Synchronises. */
+int  dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out);
 /* wait for all enqueued work; returns DH_ECAPACITY if any channel overflowed an output buffer */
 int  dh_engine_sync(dh_engine* e);
 

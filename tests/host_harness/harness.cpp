@@ -28,6 +28,9 @@ struct HostBackend {
     void free(void* p) { ::free(p); }
     int zero(void* p, size_t bytes) { memset(p, 0, bytes); return 0; }
     int upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+    int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+        return upload2d(dst, dpitch, src, spitch, width, rows);
+    }
     int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
         for (size_t r = 0; r < rows; r++) memcpy((char*) dst + r * dpitch, (const char*) src + r * spitch, width);
         return 0;

@@ -14,7 +14,7 @@ from digiham_amd import _capi, api
 
 
 def main(libs):
-    B, T = 16384, 190080
+    B, T = int(os.environ.get("FB_B", 16384)), int(os.environ.get("FB_T", 190080))
     torch.manual_seed(0)
     x = (torch.randn((B, T), device="cuda") * 0.3).contiguous()
     for path in libs or [None]:
@@ -36,7 +36,7 @@ def main(libs):
             a, b, c = eng.timing_read()
             row.append("%s %.2f" % (name, float(np.mean(a) + np.mean(b))))
             eng.close()
-        print(os.path.basename(path or "default"), " | ".join(row), flush=True)
+        print(os.path.basename(path or "default"), "B=%d T=%d" % (B, T), " | ".join(row), flush=True)
 
 
 if __name__ == "__main__":
