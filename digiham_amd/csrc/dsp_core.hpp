@@ -316,8 +316,38 @@ DH_HD float dh_fmin_(float a, float b) { return b < a ? b : a; }
 DH_HD float dh_fmax_(float a, float b) { return b > a ? b : a; }
 
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-// lane l owns ring slots 2l and 2l+1; inclusive prefix scan with __shfl_up, exclusive suffix scan with
-// __shfl_down (ds_bpermute: no LDS traffic, no barriers)
+// v_min_f32 / v_max_f32 return the operand that is not NaN -- exactly what `if (v < min) min = v` does with a
+// NaN entry (it is skipped) -- and cost one VALU instruction where compare + select cost two.
+__device__ __forceinline__ float dh_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float dh_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// Inclusive wave64 prefix min (mn) and max (mx) in lane order, on the VALU's DPP network: row_shr 1/2/4/8 inside
+// each row of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes without a source
+// keep their value.  A DPP read needs two wait states after the VALU write of its source: the min / max streams
+// are interleaved and padded with s_nop (inline asm gets no hazard handling from the compiler).
+__device__ __forceinline__ void dh_wave_prefix_minmax(float& mn, float& mx) {
+#define DH_SCAN_STEP(ctrl) \
+    "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl "\n\t"
+    asm volatile(DH_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 DH_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 DH_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 DH_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 DH_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 DH_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(mn), "+v"(mx));
+#undef DH_SCAN_STEP
+}
+// value of the previous lane (lane 0 keeps `first`): wave_shr:1
+__device__ __forceinline__ float dh_wave_prev(float v, float first) {
+    float r = first;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(r) : "v"(v));
+    return r;
+}
+
+// lane l owns ring slots 2l and 2l+1 for the prefix part; the suffix part is the same scan over the ring read
+// backwards (lane l takes slots 126-2l and 127-2l), handed back to the owning lanes through LDS (S.mn / S.mx are
+// the exchange buffers: each slot is written once with its suffix value and then overwritten with the result).
 __device__ __forceinline__ void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
     const int lane = (int) threadIdx.x;
     const uint32_t e0 = 2u * (uint32_t) lane, e1 = e0 + 1u;
@@ -327,31 +357,27 @@ __device__ __forceinline__ void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_
     const bool v0 = e0 < k1, v1 = e1 < k1;
     const float pmn0 = v0 ? c0 : DH_FLT_MAX, pmn1 = v1 ? c1 : DH_FLT_MAX;
     const float pmx0 = v0 ? c0 : DH_FLT_MIN, pmx1 = v1 ? c1 : DH_FLT_MIN;
-    float pmn = dh_fmin_(pmn0, pmn1), pmx = dh_fmax_(pmx0, pmx1);
-    // suffix source: the old ring (slots >= 100 hold the identity, see the staging code)
-    const float o0 = S.vol_old[e0], o1 = S.vol_old[e1];
-    const float omn0 = e0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MAX, omn1 = e1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MAX;
-    const float omx0 = e0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MIN, omx1 = e1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MIN;
-    float smn = dh_fmin_(omn0, omn1), smx = dh_fmax_(omx0, omx1);
-#pragma unroll
-    for (int d = 1; d < DH_WAVE; d <<= 1) {
-        const float a = __shfl_up(pmn, d), b = __shfl_up(pmx, d);
-        const float c = __shfl_down(smn, d), e = __shfl_down(smx, d);
-        if (lane >= d) { pmn = dh_fmin_(pmn, a); pmx = dh_fmax_(pmx, b); }
-        if (lane + d < DH_WAVE) { smn = dh_fmin_(smn, c); smx = dh_fmax_(smx, e); }
-    }
-    // exclusive parts from the neighbours
-    float epmn = __shfl_up(pmn, 1), epmx = __shfl_up(pmx, 1);
-    float esmn = __shfl_down(smn, 1), esmx = __shfl_down(smx, 1);
-    if (lane == 0) { epmn = DH_FLT_MAX; epmx = DH_FLT_MIN; }
-    if (lane == DH_WAVE - 1) { esmn = DH_FLT_MAX; esmx = DH_FLT_MIN; }
-    // slot e0: prefix = excl + own e0; suffix (exclusive of e0) = own e1 + later lanes
-    const float mn0 = dh_fmin_(dh_fmin_(epmn, pmn0), dh_fmin_(omn1, esmn));
-    const float mx0 = dh_fmax_(dh_fmax_(epmx, pmx0), dh_fmax_(omx1, esmx));
-    // slot e1: prefix = inclusive through e1; suffix = later lanes only
-    const float mn1 = dh_fmin_(pmn, esmn);
-    const float mx1 = dh_fmax_(pmx, esmx);
-    S.mn[e0] = mn0; S.mx[e0] = mx0; S.mn[e1] = mn1; S.mx[e1] = mx1;
+    float pmn = dh_vmin(pmn0, pmn1), pmx = dh_vmax(pmx0, pmx1);
+    // suffix source: the old ring backwards (slots >= 100 hold the identity)
+    const uint32_t r0 = 126u - e0, r1 = r0 + 1u;
+    const float o0 = S.vol_old[r0], o1 = S.vol_old[r1];
+    const float omn0 = r0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MAX, omn1 = r1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MAX;
+    const float omx0 = r0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MIN, omx1 = r1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MIN;
+    float smn = dh_vmin(omn0, omn1), smx = dh_vmax(omx0, omx1);
+    dh_wave_prefix_minmax(pmn, pmx);
+    dh_wave_prefix_minmax(smn, smx);
+    // exclusive parts: everything before this lane's pair (prefix), everything after slot r1 (suffix)
+    const float epmn = dh_wave_prev(pmn, DH_FLT_MAX), epmx = dh_wave_prev(pmx, DH_FLT_MIN);
+    const float esmn = dh_wave_prev(smn, DH_FLT_MAX), esmx = dh_wave_prev(smx, DH_FLT_MIN);
+    // suffix (exclusive of the slot itself) for slots r1 and r0
+    S.mn[r1] = esmn; S.mx[r1] = esmx;
+    S.mn[r0] = dh_vmin(omn1, esmn); S.mx[r0] = dh_vmax(omx1, esmx);
+    __syncthreads();
+    const float s0n = S.mn[e0], s0x = S.mx[e0], s1n = S.mn[e1], s1x = S.mx[e1];
+    __syncthreads();
+    // slot e0: prefix through e0 = before this lane + own e0; slot e1: inclusive prefix of the lane
+    S.mn[e0] = dh_vmin(dh_vmin(epmn, pmn0), s0n); S.mx[e0] = dh_vmax(dh_vmax(epmx, pmx0), s0x);
+    S.mn[e1] = dh_vmin(pmn, s1n); S.mx[e1] = dh_vmax(pmx, s1x);
 }
 #else
 inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
@@ -364,6 +390,18 @@ inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
         for (uint32_t j = k + 1; j < DH_VOLUME_RB_SIZE; j++) { smn = dh_fmin_(smn, S.vol_old[j]); smx = dh_fmax_(smx, S.vol_old[j]); }
         S.mn[k] = dh_fmin_(pmn, smn); S.mx[k] = dh_fmax_(pmx, smx);
     }
+}
+#endif
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// minimum of lanes 0..15 (one DPP row), valid in lane 15 and returned wave-uniform: four v_min_f32 with row_shr
+__device__ __forceinline__ float dh_row_min_to_lane15(float v) {
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
 }
 #endif
 
@@ -571,34 +609,38 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
         // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
         // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
-        // 100-long dependent chain on `sps` lanes.  For sps = 10 an estimate with a proven error bound is taken
-        // first: 50 lanes = 10 phases x 5 groups of 20 symbols, partial sums combined through LDS.  With
-        //   A = mean |x|, u = 2^-24:  |mean_ref - mu| <= 100.1 u A,  |mean' - mu| <= 24.1 u A
-        //   F(m) = sum (m - x)^2 / 100 = sigma^2 + (m - mu)^2  =>  |F(mean') - F(mean_ref)| <= (100.1 u A)^2 < 3.6e-11 A^2
-        //   double rounding of either summation order <= 104 * 2^-53 F < 1.2e-14 F
-        // so |V' - V_ref| <= tol = 1e-10 A^2 + 1e-13 V' + 1e-88 (the last term covers float-subnormal means).
-        // If the bound separates the smallest V' from every other phase, from 0 and from 5e6, the decision is
-        // the reference's; otherwise (exact ties, constant input, non-finite samples) the ordered chain decides.
+        // 100-long dependent chain on `sps` lanes.  For sps = 10 a float estimate V' with a proven error bound is
+        // taken first: 50 lanes = 10 phases x 5 groups of 20 symbols, partials combined through LDS.  With
+        // u = 2^-24, mu / sigma^2 the exact mean / variance of the phase, A = mean |x|, F(m) = sum (m - x)^2 / 100
+        // = sigma^2 + (m - mu)^2:
+        //   |mean_ref - mu| <= 100.1 u A,  |mean' - mu| <= 25.2 u A   =>  |F(mean') - F(mean_ref)| <= (100.1 u A)^2
+        //   A^2 <= mean x^2 = sigma^2 + mu^2 <= 1.01 (F(mean') + 2 mean'^2)   =>  that difference < 1e-10 (V' + mean'^2)
+        //   V_ref = F(mean_ref)(1 + 1.2e-14);  V' = F(mean')(1 + 28 u) up to 25 subnormal roundings (< 1e-42)
+        // so |V' - V_ref| <= tol = 4e-6 V' + 1.2e-10 (V' + mean'^2) + 1e-42, provided nothing overflows (max |x|
+        // < 1e16 is checked).  If the intervals [V' - tol, V' + tol] separate the smallest phase from all others,
+        // from 0 and from 5e6, the reference's decision is known; an all-zero phase gives vmin = 0 exactly.
+        // Anything else (ties, constant input, non-finite or huge samples) is decided by the ordered chain.
         int32_t new_off = 0;
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done) {
             bool ordered = true;
             if (SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
-                float* psum = S.mn; float* pabs = S.mn + DH_WAVE;
-                double* pd = reinterpret_cast<double*>(S.mx);
+                float* psum = S.mn; float* pmax = S.mn + DH_WAVE; float* pd = S.mx;
+                DH_LANE_ARRAY(float, pmean, 1);
                 DH_FOR_LANES(lane) {
                     if (lane < 50) {
                         const int i = lane % 10, g = lane / 10;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
-                        float sx = 0.0f, sa = 0.0f;
+                        float sx = 0.0f, ax = 0.0f;
 #pragma unroll
                         for (int q = 0; q < 5; q++) {
                             const dh_f4a v = row[q];
                             sx += v.x; sx += v.y; sx += v.z; sx += v.w;
-                            sa += __builtin_fabsf(v.x); sa += __builtin_fabsf(v.y); sa += __builtin_fabsf(v.z); sa += __builtin_fabsf(v.w);
+                            ax = __builtin_fmaxf(__builtin_fmaxf(ax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
+                            ax = __builtin_fmaxf(__builtin_fmaxf(ax, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
                         }
-                        psum[lane] = sx; pabs[lane] = sa;
+                        psum[lane] = sx; pmax[lane] = ax;
                     }
                 }
                 DH_BARRIER();
@@ -607,50 +649,62 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         const int i = lane % 10, g = lane / 10;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
                         const float total = (((psum[i] + psum[i + 10]) + psum[i + 20]) + psum[i + 30]) + psum[i + 40];
-                        const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
-                        double acc = 0.0;
+                        const float mean = total * 0.01f;
+                        float acc = 0.0f;
 #pragma unroll
                         for (int q = 0; q < 5; q++) {
                             const dh_f4a v = row[q];
-                            const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
-                            acc = __builtin_fma(d0, d0, acc); acc = __builtin_fma(d1, d1, acc);
-                            acc = __builtin_fma(d2, d2, acc); acc = __builtin_fma(d3, d3, acc);
+                            const float d0 = mean - v.x, d1 = mean - v.y, d2 = mean - v.z, d3 = mean - v.w;
+                            acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
+                            acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
                         }
                         pd[lane] = acc;
+                        DH_LA(pmean, lane)[0] = mean;
                     }
                 }
                 DH_BARRIER();
+                // lanes 0..9 hold one phase each; the others hold neutral values
+                DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
+                uint64_t vote_guard = 0, vote_zero = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
                 DH_FOR_LANES(lane) {
+                    float l = DH_FLT_MAX, h = DH_FLT_MAX;
+                    bool guard = true, zero = false;
                     if (lane < 10) {
                         const int i = lane;
-                        const double v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) / (double) DH_VARIANCE_SYMBOLS;
-                        const float asum = (((pabs[i] + pabs[i + 10]) + pabs[i + 20]) + pabs[i + 30]) + pabs[i + 40];
-                        const double a = (double) asum * 0.01;
-                        double tol = 1e-10 * a * a + 1e-13 * v + 1e-88;
-                        if (!(asum < 1e37f)) tol = __builtin_inf();      // float sums may have overflowed: no bound
-                        if (asum == 0.0f) tol = -1.0;                   // every sample of the phase is 0: V_ref is exactly 0
-                        S.variance[i] = v; S.variance[10 + i] = tol;
+                        const float v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) * 0.01f;
+                        const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(pmax[i], pmax[i + 10]), __builtin_fmaxf(pmax[i + 20], pmax[i + 30])), pmax[i + 40]);
+                        const float mean = DH_LA(pmean, lane)[0];
+                        const float e = __builtin_fmaf(mean, mean, v);
+                        const float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
+                        guard = (e < 1e30f) && (amax < 1e16f);           // false for NaN
+                        zero = amax == 0.0f;
+                        l = v - tol; h = v + tol;
                     }
+                    DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
+                    DH_BALLOT_ACC(vote_guard, guard, lane);
+                    DH_BALLOT_ACC(vote_zero, zero, lane);
+                    DH_BALLOT_ACC(vote_pos, l > 0.0f, lane);
+                    DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
                 }
-                DH_BARRIER();
-                double best = S.variance[0]; uint32_t bpos = 0;
-                bool finite = true, zero_phase = false;
-                for (uint32_t i = 0; i < 10; i++) {
-                    const double v = S.variance[i], t = S.variance[10 + i];
-                    if (i > 0 && v < best) { best = v; bpos = i; }
-                    if (!(v < 1e300) || !(t < 1e300)) finite = false;
-                    if (t < 0) zero_phase = true;
-                }
-                if (finite && zero_phase) {
-                    ordered = false;                            // the minimum over finite variances >= 0 is an exact 0 -> "vmin <= 0"
-                } else if (finite) {
-                    const double btol = S.variance[10 + bpos];
-                    const double hi = best + btol;
+                float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                hmin = dh_row_min_to_lane15(hi[0]);
+#else
+                hmin = DH_FLT_MAX;
+                for (int q = 0; q < 10; q++) hmin = dh_fmin_(hmin, hi[q][0]);
+#endif
+                DH_FOR_LANES(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
+                const uint32_t ten = 0x3FFu;
+                const uint32_t above = (uint32_t) vote_above & ten;
+                const uint32_t cand = ~above & ten;                 // phases whose interval reaches below hmin
+                if (((uint32_t) vote_guard & ten) != ten) {
+                } else if ((uint32_t) vote_zero & ten) {
+                    ordered = false;                                // vmin == 0 exactly: no step
+                } else if (dh_popc32(cand) == 1 && ((uint32_t) vote_pos & cand) && ((uint32_t) vote_small & cand)) {
                     ordered = false;
-                    for (uint32_t i = 0; i < 10; i++)
-                        if (i != bpos && !(S.variance[i] - S.variance[10 + i] > hi)) ordered = true;
-                    if (!(best - btol > 0.0)) ordered = true;
-                    if (!(hi < 4999999.0)) ordered = true;
+                    const uint32_t vmin_pos = (uint32_t) dh_ffs64((uint64_t) cand);
+                    if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
+                    else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
                 }
             }
             if (ordered) {
@@ -680,13 +734,13 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
                 DH_BARRIER();
                 DH_FOR_LANES(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+                double vmin = S.variance[0]; uint32_t vmin_pos = 0;
+                for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
+                if (vmin <= 0 || vmin > 5000000) {
+                } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
             }
             DH_FOR_LANES(lane) { if (DH_IS_LANE0(lane)) S.stats[0]++; }
-            double vmin = S.variance[0]; uint32_t vmin_pos = 0;
-            for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
-            if (vmin <= 0 || vmin > 5000000) {
-            } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
-            else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
         }
 
         DH_CLK(5);
