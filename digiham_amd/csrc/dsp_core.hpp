@@ -119,10 +119,19 @@ DH_HD float dh_div_gain_exact(float acc, double gain) { return (float) ((double)
 DH_HD float dh_div_gain_fast(float acc, double rgain, bool& suspect) {
     const double q = (double) acc * rgain;
     union { double d; uint64_t u; } b; b.d = q;
-    const uint32_t m = (uint32_t) b.u & 0x1FFFFFFFu;
-    const uint32_t e = (uint32_t) (b.u >> 52) & 0x7FFu;
-    const bool near_tie = (m - 0x0FFFFFFCu) <= 8u;                  // within 4 ulp(double) of a float midpoint
-    const bool odd_range = (e < 1023u - 125u && (b.u << 1) != 0) || e > 1023u + 126u;   // float subnormal / overflow / nan
+    // within 4 ulp(double) of a float midpoint: low 29 mantissa bits in [0x0FFFFFFC, 0x10000004]; the shift drops
+    // the three bits above them, so this is one v_lshl_add_u32 and one compare
+    const bool near_tie = (((uint32_t) b.u << 3) + 0x80000020u) <= 64u;
+    // Results that may be float subnormals (or overflow) round at other bit positions: with 1 < gain < 128 they
+    // need |acc| < 2^-118 (or >= 2^126).  0, inf and nan are fine: acc * rgain is then acc / gain bit for bit.
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    const int ex = __builtin_amdgcn_frexp_expf(acc);               // 0 for zero / inf / nan
+    const bool odd_range = (uint32_t) (ex + 117) > 243u;
+#else
+    union { float f; uint32_t u; } a; a.f = acc;
+    const uint32_t be = (a.u >> 23) & 0xFFu;
+    const bool odd_range = be == 0u ? (a.u << 1) != 0u : (be != 255u && (be < 127u - 118u || be >= 127u + 126u));
+#endif
     suspect = near_tie || odd_range;
     return (float) q;
 }
@@ -507,8 +516,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_CLK(0);
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
-        // The filtered samples keep the padded layout (element n at DH_XPAD(n)): the 16-words-apart write-back
-        // would otherwise be a 16-way bank conflict.  Without an RRC stage the staged samples are used as they are.
+        // The filtered samples go back UNPADDED (element n at word n, four 16-byte stores per lane): the symbol
+        // windows of P3 then sit at compile-time offsets from one per-lane base, which saves two address
+        // instructions per sample on the VALU; the bank conflicts of the 16-words-apart stores cost LDS cycles
+        // only, and the LDS pipe has slack.  Without an RRC stage the staged (padded) samples are used as they are.
         if (NZ > 0) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
@@ -522,16 +533,20 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_BARRIER();
             DH_FOR_LANES(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need) {
-                    float* dst = S.xf + (DH_FIR_L + 1) * lane;       // DH_XPAD(16*lane + j) = 17*lane + j
+                    dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
 #pragma unroll
-                    for (int j = 0; j < DH_FIR_L; j++) dst[j] = DH_LA(fo, lane)[j];
+                    for (int j = 0; j < DH_FIR_L / 4; j++) {
+                        dh_f4a v; v.x = DH_LA(fo, lane)[4 * j]; v.y = DH_LA(fo, lane)[4 * j + 1];
+                        v.z = DH_LA(fo, lane)[4 * j + 2]; v.w = DH_LA(fo, lane)[4 * j + 3];
+                        dst[j] = v;
+                    }
                 }
             }
             DH_BARRIER();
         }
         DH_CLK(1);
         const float* fbuf = S.xf;
-#define DH_FB(n) fbuf[DH_XPAD(n)]
+#define DH_FB(n) fbuf[NZ > 0 ? (n) : DH_XPAD(n)]
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
         DH_FOR_LANES(lane) {
@@ -594,8 +609,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const float average = S.sum[q] / (float) (ev_hi - ev_lo);
                 uint8_t sym;
                 if (P.levels == 4) {
-                    const float umid = (float) ((double) (mx - center) * 0.625 + (double) center);
-                    const float lmid = (float) ((double) (mn - center) * 0.625 + (double) center);
+                    // (float)((double)(max - center) * 0.625 + center), gfsk_demodulator.cpp:117-118: the product is exact
+                    // in double (24 x 3 bits) and the sum is either exact there too or so lopsided that the small term
+                    // cannot reach a float rounding boundary (|center| >= 2^-25 |max - center| unless it is 0), so the
+                    // double-rounded result equals the single rounding of the exact value: one float FMA.
+                    const float umid = __builtin_fmaf(mx - center, 0.625f, center);
+                    const float lmid = __builtin_fmaf(mn - center, 0.625f, center);
                     if (average > center) sym = average > umid ? 1 : 0;
                     else sym = average < lmid ? 3 : 2;
                 } else {
