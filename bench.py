@@ -4,14 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (fused RRC + GFSK slicer kernel, then the DMR decoder kernel)
+A "step" is one pass of the hot path (one kernel: every channel's wavefront filters + slices its samples
+and then runs the DMR decoder over the symbols it produced; --split-stages launches the two stages separately)
 over one batch of synthetic input that is already resident in HBM: by default BASELINE.json
 configs[2], 16 384 DMR channels x 3.96 s of 48 kS/s audio per GPU, full chain incl. BPTC(196,96).
 State (filter history, timing recovery, decoder phase) carries from step to step exactly as in a
 continuous stream; the input buffer is periodic so the stream is seamless.
 
 One JSON line on rank 0: value = whole-job real-time 48 kS/s channels = samples/s / 48 000, plus
-`roofline` for the dominant kernel (k_rrc_demod, timed with HIP events on its own stream inside
+`roofline` for the dominant kernel (k_chain, timed with HIP events on its own stream inside
 the timed region) and `cpu_baseline` (the oracle's scalar restatement of the reference pipe on
 this box's host cores, bounded sample, rank 0 at N = 1 only).
 """
@@ -75,6 +76,7 @@ def main():
     ap.add_argument("--channels", type=int, default=16384, help="channels per GPU (weak scaling)")
     ap.add_argument("--units", type=int, default=0, help="bursts (DMR, 30 ms) or frames (YSF, 100 ms) per step; 0 = ~4 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-stages", action="store_true", help="slicer and decoder as two kernels (per-stage timing)")
     ap.add_argument("--verify", type=int, default=8, help="channels checked bit-exact against the oracle after the run")
     args = ap.parse_args()
 
@@ -94,6 +96,8 @@ def main():
     x, info = synth_torch.make_batch(torch, device, proto, B, units, seed=1000 + 7919 * rank)
     T = info["samples_per_channel"]
     ctx = api.Context(device=local)
+    if args.split_stages:
+        kw = dict(kw, split_stages=True)
     eng = api.Engine(B, T, ctx=ctx, **kw)
     n_timed = args.steps
     eng.timing_enable(max(n_timed, 1))
@@ -112,6 +116,9 @@ def main():
     dt = time.perf_counter() - t0
     eng.sync()                              # raises on any output-buffer overflow
     rrc_ms, slicer_ms, dec_ms = eng.timing_read()
+    frame_bytes_step = 0
+    if kw["proto"] != "none":
+        frame_bytes_step = int(eng.frames()[1].sum())          # decoder output of the last step, all channels
 
     samples = float(B) * T * args.steps
     dt_max, samples_all = shard.reduce_report(dt, samples, device)
@@ -157,7 +164,10 @@ def main():
             dom_name = "k_rrc_tile"
         else:
             dom_ms = float(np.mean(slicer_ms)) if len(slicer_ms) else float("nan")
-            dom_name = "k_rrc_demod"
+            chained = kw["proto"] != "none" and not args.split_stages
+            dom_name = "k_chain" if chained else "k_rrc_demod"
+            if chained:
+                alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         fir_flops = B * T * 162.0            # 81 mul + 81 add per sample, unfused
         line = {

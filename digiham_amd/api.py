@@ -145,12 +145,12 @@ class Engine:
     """B independent `rrc_filter | gfsk_demodulator | dmr_decoder` pipes with state resident in HBM."""
 
     def __init__(self, n_channels, max_samples, rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=False,
-                 keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False):
+                 keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False, split_stages=False):
         self.ctx = ctx if ctx is not None else Context(device=device)
         lib, mem = self.ctx.lib, self.ctx.mem
         flags = (_capi.FLAG_FAST_FIR if fast_fir else 0) | (_capi.FLAG_KEEP_FILTERED if keep_filtered else 0) | \
                 (_capi.FLAG_FSK_INVERT if invert else 0) | (0 if events else _capi.FLAG_NO_EVENTS) | \
-                (_capi.FLAG_ORDERED_TIMING if ordered_timing else 0)
+                (_capi.FLAG_ORDERED_TIMING if ordered_timing else 0) | (_capi.FLAG_SPLIT_STAGES if split_stages else 0)
         cfg = _capi.EngineConfig(C.sizeof(_capi.EngineConfig), getattr(mem, "index", 0), n_channels, max_samples,
                                  _capi.RRC[rrc], _capi.DEMOD[demod], sps, _capi.PROTO[proto], flags, slot_filter,
                                  mem.stream())

@@ -43,6 +43,21 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(co
     dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
 }
 
+// The whole chain of one channel in one wavefront: slice this push's samples, then run the protocol decoder over
+// the symbols just produced.  The decoder is latency-bound (scalar control, LDS round trips); inside this kernel
+// its stalls are covered by the other wavefronts' FIR arithmetic instead of by nothing, as in a separate launch.
+// The two stages use the LDS block one after the other.
+template <int NZ, bool FAST, int PROTO>
+__global__ __launch_bounds__(DH_WAVE, DH_LB) void k_chain(const DhDspParams P, const DhDecParams D) {
+    extern __shared__ __attribute__((aligned(16))) char dh_smem[];
+    dh_rrc_demod_channel<NZ, FAST, 10>(P, blockIdx.x, *reinterpret_cast<DhDspShared*>(dh_smem));
+    __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
+    __syncthreads();
+    DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
+    if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, blockIdx.x, S);
+    else dh_ysf_channel(D, blockIdx.x, S);
+}
+
 template <int NZ, bool FAST>
 __global__ __launch_bounds__(DH_WAVE, ((NZ > 80 || FAST) ? 2 : DH_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
@@ -243,6 +258,20 @@ struct HipBackend {
         if (nz == 80) return fast ? go_rrc_demod<80, true, 0>(P) : go_rrc_demod<80, false, 0>(P);
         if (nz == 160) return fast ? go_rrc_demod<160, true, 0>(P) : go_rrc_demod<160, false, 0>(P);
         return -1;
+    }
+    template <int NZ, bool FAST, int PROTO> int go_chain(const DhDspParams& P, const DhDecParams& D) {
+        size_t lds = dh_dsp_shared_bytes(10);
+        if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
+        hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P, D);
+        return launched("k_chain");
+    }
+    // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
+    int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
+        if (P.sps != 10 || (nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;
+        const bool dmr = proto == DH_PROTO_DMR;
+        if (nz == 0) return dmr ? go_chain<0, false, DH_PROTO_DMR>(P, D) : go_chain<0, false, DH_PROTO_YSF>(P, D);
+        if (fast) return dmr ? go_chain<80, true, DH_PROTO_DMR>(P, D) : go_chain<80, true, DH_PROTO_YSF>(P, D);
+        return dmr ? go_chain<80, false, DH_PROTO_DMR>(P, D) : go_chain<80, false, DH_PROTO_YSF>(P, D);
     }
     template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;

@@ -78,6 +78,7 @@ inline void fill_taps(int rrc, float* half, double* gain) {
 //   int zero(void* p, size_t bytes);                       // async on the engine stream
 //   int upload(void* dst, const void* src, size_t bytes);  // host -> device, async
 //   int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);  // synchronous
+//   int launch_chain(const DhDspParams&, const DhDecParams&, uint32_t nz, bool fast, int proto);   // 1 = unavailable
 //   int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
 //   int download(void* dst, const void* src, size_t bytes);// device -> host, synchronous
 //   int sync();
@@ -188,6 +189,7 @@ struct Engine {
         int rc = 0;
         const float* demod_in = d_in; size_t demod_stride = stride;
         const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;
+        bool decoder_done = false;
         be.timing_mark(0);
         if (L.rrc && !L.fused) {
             rrcp.in = d_in; rrcp.in_stride = stride; rrcp.out = filtered; rrcp.out_stride = L.max_samples;
@@ -208,10 +210,19 @@ struct Engine {
             dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast;
             dsp.ordered_timing = (L.flags & DH_FLAG_ORDERED_TIMING) ? 1 : 0;
             if (L.fused) { fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain; }
-            rc |= be.launch_rrc_demod(dsp, dsp.nz, fast);
+            // slicer and decoder of a channel in one wavefront where the backend has that kernel (sps 10, wide or
+            // no RRC); DH_FLAG_SPLIT_STAGES keeps the two launches (per-stage timing, A/B measurements)
+            int chained = 1;
+            if (L.proto && !(L.flags & DH_FLAG_SPLIT_STAGES)) {
+                fill_dec_params(syms, L.sym_stride, sym_count);
+                chained = be.launch_chain(dsp, dec, dsp.nz, fast, L.proto);
+                if (chained < 0) rc |= chained;
+            }
+            if (chained == 1) rc |= be.launch_rrc_demod(dsp, dsp.nz, fast);
+            decoder_done = chained == 0;
         }
         be.timing_mark(2);
-        if (L.proto && L.demod) {
+        if (L.proto && L.demod && !decoder_done) {
             fill_dec_params(syms, L.sym_stride, sym_count);
             rc |= be.launch_decoder(dec, L.proto);
         }

@@ -102,6 +102,7 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2 };
 #define DH_FLAG_KEEP_FILTERED   0x2   /* also materialise the RRC output [B][n] (unfused path; BASELINE config 2) */
 #define DH_FLAG_FSK_INVERT      0x4   /* FskDemodulator(sps, invert = true) */
 #define DH_FLAG_NO_EVENTS       0x8   /* do not record decoder events */
+#define DH_FLAG_SPLIT_STAGES    0x20  /* launch slicer and decoder as two kernels even where the one-wavefront chain kernel exists */
 #define DH_FLAG_ORDERED_TIMING  0x10  /* always run the in-order variance chain of the timing recovery (diagnostic; results are identical) */
 
 typedef struct {

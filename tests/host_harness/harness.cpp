@@ -74,6 +74,12 @@ struct HostBackend {
         for (uint32_t ch = 0; ch < B; ch++) dh_rrc_hist_channel(hist, in, in_stride, n, nz, ch, sh);
         return 0;
     }
+    int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
+        // same order of work as the device kernel: channel by channel, slicer then decoder
+        if (P.sps != 10 || (nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;
+        if (launch_rrc_demod(P, nz, fast)) return -1;
+        return launch_decoder(D, proto) ? -1 : 0;
+    }
     int launch_decoder(const DhDecParams& P, int proto) {
         DhDecShared* S = new DhDecShared;
         for (uint32_t ch = 0; ch < P.n_channels; ch++) {

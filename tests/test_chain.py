@@ -22,6 +22,16 @@ def test_full_chain_bit_exact(ctx, oracle, proto, chunks):
     assert sum(len(f) for f in res["frames"]) > 0
 
 
+@pytest.mark.parametrize("proto", ["dmr", "ysf"])
+def test_split_stages_equal_chain_kernel(ctx, oracle, proto):
+    """DH_FLAG_SPLIT_STAGES (slicer and decoder as two launches) and the one-wavefront chain kernel agree with the oracle."""
+    x = make_channels(proto, [31, 32, 33], 14)
+    ref = oracle.chain(x, proto=1 if proto == "dmr" else 2)
+    for split in (True, False):
+        res = run_engine(ctx, x, proto, [5000, 12345], split_stages=split)
+        assert_matches_oracle(res, ref, len(x), "split" if split else "chain")
+
+
 def test_chain_golden_vectors(ctx, golden):
     g = golden["chain"]
     for name, proto in (("dmr_a", "dmr"), ("dmr_b", "dmr"), ("ysf_a", "ysf")):
