@@ -147,164 +147,6 @@ DH_HD void dh_dmr_enter_frame_phase(uint32_t* s) {
     s[DS_SLOT_FILTER] = s[DS_SLOT_FILTER_DECODER];
 }
 
-// EmbeddedCollector::getLc (embedded.cpp:32-94) on the 16 collected bytes (4 big-endian words)
-DH_HD bool dh_dmr_embedded_lc(const DhFecTables& T, const uint32_t* data, uint32_t off, uint8_t* lc) {
-    if (off < 3) return false;
-    uint32_t m[8];
-    for (int k = 0; k < 8; k++) m[k] = 0;
-    for (int i = 0; i < 16; i++) {
-        const uint32_t byte = (data[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
-        for (int k = 0; k < 8; k++) m[k] = (m[k] << 1) | ((byte >> (7 - k)) & 1u);
-    }
-    for (int i = 0; i < 7; i++) if (!dh_block_decode(T.h1611, T.lut_h1611, m[i])) return false;
-    uint32_t parity = 0;
-    for (int i = 0; i < 8; i++) parity ^= m[i];
-    if (parity != 0) return false;
-    // 72 LC bits: 11 from rows 0,1 and 10 from rows 2..6 (ETSI B.2.1); 5 checksum bits = bit 5 of rows 2..6
-    uint64_t acc = 0; int nacc = 0, ob = 0; uint32_t received = 0, sum = 0;
-    for (int r = 0; r < 7; r++) {
-        const int nb = r < 2 ? 11 : 10;
-        acc = (acc << nb) | ((m[r] >> (16 - nb)) & ((1u << nb) - 1)); nacc += nb;
-        while (nacc >= 8) { lc[ob] = (uint8_t) (acc >> (nacc - 8)); sum += lc[ob]; ob++; nacc -= 8; }
-        if (r >= 2) received |= ((m[r] >> 5) & 1u) << (4 - (r - 2));
-    }
-    return (sum % 31u) == received;
-}
-
-DH_HD void dh_dmr_slot_sync_lost(DhDecCtx& c, int slot) {     // dmr_phase.cpp:175-182 == :194-200
-    uint32_t* s = c.st;
-    int v = (int) s[DS_SLOT_SYNC0 + slot] - 1;
-    if (v < 0) {
-        v = 0;
-        s[DS_SYNC_TYPE0 + slot] = (uint32_t) -1;
-        dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
-        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
-    }
-    s[DS_SLOT_SYNC0 + slot] = (uint32_t) v;
-}
-
-struct DhDmrFrameResult { bool to_sync; bool voice_out; bool want_bptc; uint8_t data_type; };
-
-// FramePhase::process up to (not including) the payload stores and the BPTC, which the caller runs
-// lane-parallel (dmr_phase.cpp:65-254).
-DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhPlanes& p) {
-    const DhFecTables& T = *c.T;          // LDS copy (codes + small LUTs); Golay LUTs via c.P->T
-    uint32_t* s = c.st;
-    DhDmrFrameResult R; R.to_sync = false; R.voice_out = false; R.want_bptc = false; R.data_type = 0;
-
-    // CACH: the 7 TACT bits sit on the bit1 plane of dibits 0,2,4,6,7,9,11 (cach.cpp:7,11-19)
-    const uint32_t h12 = (uint32_t) (p.h[0] & 0xFFFu);
-    uint32_t tact = ((h12 >> 0) & 1u) << 6 | ((h12 >> 2) & 1u) << 5 | ((h12 >> 4) & 1u) << 4 | ((h12 >> 6) & 1u) << 3 |
-                    ((h12 >> 7) & 1u) << 2 | ((h12 >> 9) & 1u) << 1 | ((h12 >> 11) & 1u);
-    const bool has_tact = dh_block_decode(T.h74, T.lut_h74, tact);
-    const int tact_slot = (int) ((tact >> 5) & 1u);
-
-    int slot = (int) s[DS_SLOT], stab = (int) s[DS_SLOT_STABILITY];
-    const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
-    if (has_tact) {
-        if (tact_slot != next) {
-            if (stab < 5) {
-                stab = 0; slot = tact_slot;
-                const int other = slot ^ 1;
-                s[DS_SYNC_TYPE0 + other] = (uint32_t) -1;
-                dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) other, 0, nullptr, 0);
-                if ((int) s[DS_ACTIVE_SLOT] == other) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
-            } else {
-                stab--;
-                if (slot != -1) slot = next;
-            }
-        } else {
-            if (++stab > 100) stab = 100;
-            slot = next;
-        }
-    } else if (slot != -1) {
-        if (stab-- < -100) stab = -100;
-        slot = next;
-    }
-    s[DS_SLOT] = (uint32_t) slot; s[DS_SLOT_STABILITY] = (uint32_t) stab;
-    if (slot == -1) return R;
-
-    int sync_count = (int) s[DS_SYNC_COUNT];
-    const int sync_type = dh_dmr_sync_type(p, 66);
-    if (sync_type > 0) {
-        if (++sync_count > 5) sync_count = 5;
-        int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
-        s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
-        uint8_t soft = ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) ? 1 : 0;
-        s[DS_SYNC_TYPE0 + slot] = (uint32_t) sync_type;
-        dh_emit(c, DH_EV_DMR_SYNC, (uint8_t) slot, (uint8_t) sync_type, &soft, 1);
-        s[DS_SUPERFRAME0 + slot] = 0;
-        s[DS_EMB_OFF0 + slot] = 0;
-    } else if ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && s[DS_SUPERFRAME0 + slot] < 5) {
-        s[DS_SUPERFRAME0 + slot]++;
-        // EMB: dibits 66..69 and 86..89 (:123-132), QR(16,7)
-        uint32_t emb = (dh_syms_msb(p, 66, 4) << 8) | dh_syms_msb(p, 86, 4);
-        if (dh_block_decode(T.qr, T.lut_qr, emb)) {
-            if (++sync_count > 5) sync_count = 5;
-            int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
-            s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
-            const uint32_t frag = dh_syms_msb(p, 70, 16);               // 32 embedded bits (:141-145)
-            const uint32_t lcss = (emb >> 9) & 3u; uint8_t cc = (uint8_t) ((emb >> 12) & 15u);
-            dh_emit(c, DH_EV_DMR_EMB, (uint8_t) slot, (uint8_t) lcss, &cc, 1);
-            uint32_t off = s[DS_EMB_OFF0 + slot];
-            uint32_t* data = s + (slot ? DS_EMB_DATA1 : DS_EMB_DATA0);
-            if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
-            if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
-                if (off <= 3) { data[off] = frag; off++; }
-            }
-            if (lcss == 2) {                                             // LCSS_STOP
-                uint8_t lc[9];
-                if (dh_dmr_embedded_lc(T, data, off, lc)) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
-                off = 0;
-            }
-            s[DS_EMB_OFF0 + slot] = off;
-        } else {
-            dh_dmr_slot_sync_lost(c, slot);
-            if (--sync_count < 0) {
-                dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
-                R.to_sync = true; return R;
-            }
-        }
-    } else {
-        s[DS_SUPERFRAME0 + slot] = 0;
-        s[DS_EMB_OFF0 + slot] = 0;
-        dh_dmr_slot_sync_lost(c, slot);
-        if (--sync_count < 0) {
-            dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
-            R.to_sync = true; return R;
-        }
-    }
-    s[DS_SYNC_COUNT] = (uint32_t) sync_count;
-
-    const int st = (int) s[DS_SYNC_TYPE0 + slot];
-    if (st == DH_SYNCTYPE_VOICE) {
-        const int active = (int) s[DS_ACTIVE_SLOT];
-        if (((slot + 1) & (int) s[DS_SLOT_FILTER]) && (active == -1 || active == slot)) {
-            s[DS_ACTIVE_SLOT] = (uint32_t) slot;
-            if (c.P->out_cap - c.nout < 27) c.overflow = true; else R.voice_out = true;
-        }
-    } else {
-        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
-        if (st == DH_SYNCTYPE_DATA) {
-            uint32_t slot_type = (dh_syms_msb(p, 61, 5) << 10) | dh_syms_msb(p, 90, 5);   // :236-245
-            if (dh_block_decode(T.g208, c.P->T->lut_g208, slot_type)) {
-                uint8_t cc = (uint8_t) ((slot_type >> 16) & 15u);
-                R.data_type = (uint8_t) ((slot_type >> 12) & 15u);
-                dh_emit(c, DH_EV_DMR_SLOTTYPE, (uint8_t) slot, R.data_type, &cc, 1);
-                if (R.data_type != 8) R.want_bptc = true;               // rate 3/4 data is not decoded (:251-253)
-            }
-        } else {
-            dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
-        }
-    }
-    return R;
-}
-
-// position (symbol index in the burst) of info dibit d (0..97) of a data burst (:256-269)
-DH_HD int dh_dmr_info_dibit_pos(int d) { return d < 49 ? 12 + d : 12 + 54 + 24 + 5 + (d - 49); }
-// position of voice payload dibit d (0..107) (:215-225)
-DH_HD int dh_dmr_voice_dibit_pos(int d) { return d < 54 ? 12 + d : 12 + 54 + 24 + (d - 54); }
-
 // ------------------------------------------------------------------------------------------
 #define DH_SYMWIN 1024               // fresh symbols staged in LDS per refill (a DMR burst is 144, a YSF frame 480)
 struct DhDecShared {
@@ -321,6 +163,9 @@ struct DhDecShared {
     uint8_t  vit_in[4][48];           // up to 4 concurrent codewords, dibits packed 4/byte
     uint8_t  vit_out[4][24];
     uint8_t  vit_best_metric[4];
+#ifdef DH_PHASE_CLOCKS
+    uint32_t clk[4];
+#endif
 };
 
 // virtual symbol stream of a channel for this push: carried symbols, then the fresh ones
@@ -354,6 +199,219 @@ DH_HD void dh_view_ensure(DhSymView& v, uint32_t pos, uint32_t need) {
     DH_BARRIER();
     v.wbase = wb; v.wlen = DH_SYMWIN;
 }
+
+
+// `cnt` (<= 16) symbols given as two bit masks (symbol i in bit i), packed MSB-first 2 bits per symbol -- what the
+// reference's `(v << 2) | raw[i]` loops build (e.g. dmr_phase.cpp:123-132, :236-245)
+DH_HD uint32_t dh_pack_msb(uint32_t h, uint32_t l, int cnt) {
+    return (dh_spread16(dh_brev32(h) >> (32 - cnt)) << 1) | dh_spread16(dh_brev32(l) >> (32 - cnt));
+}
+
+// EmbeddedCollector::getLc (embedded.cpp:32-94) on the 16 collected bytes (4 big-endian words).
+// The 16 x 8 bit transpose and the seven Hamming(16,11) rows run one row per lane: row k collects bit 7-k of
+// every byte (a multiply gathers the four bytes of a word into a nibble).
+DH_HD bool dh_dmr_embedded_lc(const DhFecTables& T, const uint32_t* data, uint32_t off, DhDecShared& S, uint8_t* lc) {
+    if (off < 3) return false;
+    uint64_t okmask = 0;
+    DH_FOR_LANES(lane) {
+        bool ok = true;
+        if (lane < 8) {
+            uint32_t row = 0;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x = (data[j] >> (7 - lane)) & 0x01010101u;
+                row |= ((x * 0x10204080u) >> 28) << (12 - 4 * j);
+            }
+            if (lane < 7) ok = dh_block_decode(T.h1611, T.lut_h1611, row);
+            S.colword[lane] = row;
+        }
+        DH_BALLOT_ACC(okmask, ok, lane);
+    }
+    DH_BARRIER();
+    uint32_t m[8];
+    for (int k = 0; k < 8; k++) m[k] = dh_uniform(S.colword[k]);
+    DH_BARRIER();
+    if (okmask != ~0ull) return false;
+    uint32_t parity = 0;
+    for (int i = 0; i < 8; i++) parity ^= m[i];
+    if (parity != 0) return false;
+    // 72 LC bits: 11 from rows 0,1 and 10 from rows 2..6 (ETSI B.2.1); 5 checksum bits = bit 5 of rows 2..6
+    uint64_t acc = 0; int nacc = 0, ob = 0; uint32_t received = 0, sum = 0;
+    for (int r = 0; r < 7; r++) {
+        const int nb = r < 2 ? 11 : 10;
+        acc = (acc << nb) | ((m[r] >> (16 - nb)) & ((1u << nb) - 1)); nacc += nb;
+        while (nacc >= 8) { lc[ob] = (uint8_t) (acc >> (nacc - 8)); sum += lc[ob]; ob++; nacc -= 8; }
+        if (r >= 2) received |= ((m[r] >> 5) & 1u) << (4 - (r - 2));
+    }
+    return (sum % 31u) == received;
+}
+
+DH_HD void dh_dmr_slot_sync_lost(DhDecCtx& c, int slot) {     // dmr_phase.cpp:175-182 == :194-200
+    uint32_t* s = c.st;
+    int v = (int) s[DS_SLOT_SYNC0 + slot] - 1;
+    if (v < 0) {
+        v = 0;
+        s[DS_SYNC_TYPE0 + slot] = (uint32_t) -1;
+        dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
+        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+    }
+    s[DS_SLOT_SYNC0 + slot] = (uint32_t) v;
+}
+
+struct DhDmrFrameResult { bool to_sync; bool voice_out; bool want_bptc; uint8_t data_type; };
+
+// dmr_phase.cpp:18-33 on the sync slot given as bit masks (dibit 66+i in bit i)
+DH_HD int dh_dmr_sync_type_bits(uint32_t h, uint32_t l) {
+    constexpr uint32_t SL = DH_DMR_SYNC_L, BD = DH_DMR_BS_DATA_H, BV = DH_DMR_BS_VOICE_H,
+                       MD = DH_DMR_MS_DATA_H, MV = DH_DMR_MS_VOICE_H;
+    const int dl = dh_popc32(l ^ SL);
+    if (dh_popc32(h ^ BD) + dl <= 3) return DH_SYNCTYPE_DATA;
+    if (dh_popc32(h ^ BV) + dl <= 3) return DH_SYNCTYPE_VOICE;
+    if (dh_popc32(h ^ MD) + dl <= 3) return DH_SYNCTYPE_DATA;
+    if (dh_popc32(h ^ MV) + dl <= 3) return DH_SYNCTYPE_VOICE;
+    return -1;
+}
+
+// FramePhase::process up to (not including) the payload stores and the BPTC, which the caller runs
+// lane-parallel (dmr_phase.cpp:65-254).  The burst starts at symbol `pos` of the view.
+// Every field of the burst head comes out of ONE vote: lanes 0..23 present bit 1 of the 24 dibits of the sync
+// slot (66..89), lanes 24..47 their bit 0, lanes 48..54 bit 1 of the seven TACT dibits; sync correlation, EMB
+// and the embedded-signalling fragment are then scalar bit arithmetic on that 55-bit word.
+DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uint32_t pos, DhDecShared& S) {
+    uint64_t headvote = 0;
+    DH_FOR_LANES(lane) {
+        const uint32_t l = (uint32_t) lane;
+        uint32_t at, sh;
+        if (l < 24) { at = 66u + l; sh = 1u; }
+        else if (l < 48) { at = 66u + (l - 24u); sh = 0u; }
+        else { const uint32_t i = l - 48u; at = 2u * i - (i > 3u ? 1u : 0u); sh = 1u; }   // dibits 0,2,4,6,7,9,11 (cach.cpp:7)
+        bool b = false;
+        if (l < 55u) b = ((dh_view_at(syms, pos + at) >> sh) & 1u) != 0;
+        DH_BALLOT_ACC(headvote, b, lane);
+    }
+    const uint32_t sync_h = (uint32_t) headvote & 0xFFFFFFu, sync_l = (uint32_t) (headvote >> 24) & 0xFFFFFFu;
+    const DhFecTables& T = *c.T;          // LDS copy (codes + small LUTs); Golay LUTs via c.P->T
+    uint32_t* s = c.st;
+    DhDmrFrameResult R; R.to_sync = false; R.voice_out = false; R.want_bptc = false; R.data_type = 0;
+
+    // CACH: the 7 TACT bits, first one in the MSB (cach.cpp:7,11-19)
+    uint32_t tact = dh_brev32((uint32_t) (headvote >> 48) & 0x7Fu) >> 25;
+    const bool has_tact = dh_block_decode_wave<3>(T.h74, T.lut_h74, tact);
+    const int tact_slot = (int) ((tact >> 5) & 1u);
+
+    int slot = (int) s[DS_SLOT], stab = (int) s[DS_SLOT_STABILITY];
+    const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
+    if (has_tact) {
+        if (tact_slot != next) {
+            if (stab < 5) {
+                stab = 0; slot = tact_slot;
+                const int other = slot ^ 1;
+                s[DS_SYNC_TYPE0 + other] = (uint32_t) -1;
+                dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) other, 0, nullptr, 0);
+                if ((int) s[DS_ACTIVE_SLOT] == other) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+            } else {
+                stab--;
+                if (slot != -1) slot = next;
+            }
+        } else {
+            if (++stab > 100) stab = 100;
+            slot = next;
+        }
+    } else if (slot != -1) {
+        if (stab-- < -100) stab = -100;
+        slot = next;
+    }
+    s[DS_SLOT] = (uint32_t) slot; s[DS_SLOT_STABILITY] = (uint32_t) stab;
+    if (slot == -1) return R;
+
+    int sync_count = (int) s[DS_SYNC_COUNT];
+    const int sync_type = dh_dmr_sync_type_bits(sync_h, sync_l);
+    if (sync_type > 0) {
+        if (++sync_count > 5) sync_count = 5;
+        int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
+        s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
+        uint8_t soft = ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) ? 1 : 0;
+        s[DS_SYNC_TYPE0 + slot] = (uint32_t) sync_type;
+        dh_emit(c, DH_EV_DMR_SYNC, (uint8_t) slot, (uint8_t) sync_type, &soft, 1);
+        s[DS_SUPERFRAME0 + slot] = 0;
+        s[DS_EMB_OFF0 + slot] = 0;
+    } else if ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && s[DS_SUPERFRAME0 + slot] < 5) {
+        s[DS_SUPERFRAME0 + slot]++;
+        // EMB: dibits 66..69 and 86..89 (:123-132), QR(16,7)
+        uint32_t emb = (dh_pack_msb(sync_h & 15u, sync_l & 15u, 4) << 8) | dh_pack_msb(sync_h >> 20, sync_l >> 20, 4);
+        if (dh_block_decode_wave<9>(T.qr, T.lut_qr, emb)) {
+            if (++sync_count > 5) sync_count = 5;
+            int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
+            s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
+            const uint32_t frag = dh_pack_msb((sync_h >> 4) & 0xFFFFu, (sync_l >> 4) & 0xFFFFu, 16);   // 32 embedded bits (:141-145)
+            const uint32_t lcss = (emb >> 9) & 3u; uint8_t cc = (uint8_t) ((emb >> 12) & 15u);
+            dh_emit(c, DH_EV_DMR_EMB, (uint8_t) slot, (uint8_t) lcss, &cc, 1);
+            uint32_t off = s[DS_EMB_OFF0 + slot];
+            uint32_t* data = s + (slot ? DS_EMB_DATA1 : DS_EMB_DATA0);
+            if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
+            if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
+                if (off <= 3) { data[off] = frag; off++; }
+            }
+            if (lcss == 2) {                                             // LCSS_STOP
+                uint8_t lc[9];
+                if (dh_dmr_embedded_lc(T, data, off, S, lc)) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
+                off = 0;
+            }
+            s[DS_EMB_OFF0 + slot] = off;
+        } else {
+            dh_dmr_slot_sync_lost(c, slot);
+            if (--sync_count < 0) {
+                dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
+                R.to_sync = true; return R;
+            }
+        }
+    } else {
+        s[DS_SUPERFRAME0 + slot] = 0;
+        s[DS_EMB_OFF0 + slot] = 0;
+        dh_dmr_slot_sync_lost(c, slot);
+        if (--sync_count < 0) {
+            dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
+            R.to_sync = true; return R;
+        }
+    }
+    s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+
+    const int st = (int) s[DS_SYNC_TYPE0 + slot];
+    if (st == DH_SYNCTYPE_VOICE) {
+        const int active = (int) s[DS_ACTIVE_SLOT];
+        if (((slot + 1) & (int) s[DS_SLOT_FILTER]) && (active == -1 || active == slot)) {
+            s[DS_ACTIVE_SLOT] = (uint32_t) slot;
+            if (c.P->out_cap - c.nout < 27) c.overflow = true; else R.voice_out = true;
+        }
+    } else {
+        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
+        if (st == DH_SYNCTYPE_DATA) {
+            // slot type: dibits 61..65 and 90..94 (:236-245); lanes 0..9 vote their bit 1, lanes 10..19 their bit 0
+            uint64_t stvote = 0;
+            DH_FOR_LANES(lane) {
+                const uint32_t l = (uint32_t) lane, k = l < 10u ? l : l - 10u;
+                bool b = false;
+                if (l < 20u) b = ((dh_view_at(syms, pos + (k < 5u ? 61u + k : 85u + k)) >> (l < 10u ? 1u : 0u)) & 1u) != 0;
+                DH_BALLOT_ACC(stvote, b, lane);
+            }
+            const uint32_t st_h = (uint32_t) stvote & 0x3FFu, st_l = (uint32_t) (stvote >> 10) & 0x3FFu;
+            uint32_t slot_type = (dh_pack_msb(st_h & 31u, st_l & 31u, 5) << 10) | dh_pack_msb(st_h >> 5, st_l >> 5, 5);
+            if (dh_block_decode_wave<12>(T.g208, c.P->T->lut_g208, slot_type)) {
+                uint8_t cc = (uint8_t) ((slot_type >> 16) & 15u);
+                R.data_type = (uint8_t) ((slot_type >> 12) & 15u);
+                dh_emit(c, DH_EV_DMR_SLOTTYPE, (uint8_t) slot, R.data_type, &cc, 1);
+                if (R.data_type != 8) R.want_bptc = true;               // rate 3/4 data is not decoded (:251-253)
+            }
+        } else {
+            dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
+        }
+    }
+    return R;
+}
+
+// position (symbol index in the burst) of info dibit d (0..97) of a data burst (:256-269)
+DH_HD int dh_dmr_info_dibit_pos(int d) { return d < 49 ? 12 + d : 12 + 54 + 24 + 5 + (d - 49); }
+// position of voice payload dibit d (0..107) (:215-225)
+DH_HD int dh_dmr_voice_dibit_pos(int d) { return d < 54 ? 12 + d : 12 + 54 + 24 + (d - 54); }
 
 DH_HD void dh_load_planes(const DhSymView& syms, uint32_t pos, uint32_t total, DhPlanes& pl, int nwords) {
     for (int w = 0; w < DH_PLANE_WORDS; w++) { pl.h[w] = 0; pl.l[w] = 0; }
@@ -423,7 +481,19 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared
 }
 
 // One DMR channel, one push.
+#if defined(DH_PHASE_CLOCKS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_DCLK_BEGIN() uint64_t dh_clk_t = clock64()
+#define DH_DCLK(i) do { const uint64_t dh_clk_n = clock64(); if (threadIdx.x == 0) S.clk[i] += (uint32_t) (dh_clk_n - dh_clk_t); dh_clk_t = clock64(); } while (0)
+#else
+#define DH_DCLK_BEGIN() ((void) 0)
+#define DH_DCLK(i) ((void) 0)
+#endif
+
 DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+#ifdef DH_PHASE_CLOCKS
+    DH_FOR_LANES(lane) { if (lane < 4) S.clk[lane] = 0; }
+#endif
+    DH_DCLK_BEGIN();
     DhDecCtx c;
     c.P = &P; c.T = &dh_lds_tables(S);
     c.st = P.state + (size_t) ch * P.state_stride;
@@ -448,6 +518,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     for (int i = 0; i < DH_DEC_STATE_WORDS; i++) s[i] = c.st[i];
     uint32_t* const st_global = c.st;
     c.st = s;
+    DH_DCLK(0);
 
     for (;;) {
         const uint32_t avail = total - pos;
@@ -473,21 +544,23 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         } else {                                                       // FramePhase (dmr_phase.cpp:61-302)
             if (!(avail > 144)) break;
             dh_view_ensure(syms, pos, 192);
-            dh_load_planes(syms, pos, total, pl, 3);
-            const DhDmrFrameResult R = dh_dmr_frame_head(c, pl);
+            DH_DCLK(1);
+            const DhDmrFrameResult R = dh_dmr_frame_head(c, syms, pos, S);
+            DH_DCLK(2);
             if (R.to_sync) { phase = 0; continue; }
             if (R.voice_out) {
                 uint8_t* o = c.out + c.nout;
                 DH_FOR_LANES(lane) {
                     if (lane < 27) {
                         uint32_t v = 0;
-                        for (int i = 0; i < 4; i++) v = (v << 2) | dh_sym_at(pl, dh_dmr_voice_dibit_pos(lane * 4 + i));
+                        for (int i = 0; i < 4; i++) v = (v << 2) | dh_view_at(syms, pos + (uint32_t) dh_dmr_voice_dibit_pos(lane * 4 + i));
                         o[lane] = (uint8_t) v;
                     }
                 }
                 c.nout += 27;
             }
             if (R.want_bptc) {
+                dh_load_planes(syms, pos, total, pl, 3);
                 uint8_t lc[12];
                 for (int i = 0; i < 12; i++) lc[i] = 0;
                 const int slot = (int) s[DS_SLOT];
@@ -498,6 +571,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 }
             }
             pos += 144; c.consumed += 144;
+            DH_DCLK(3);
         }
         if (c.overflow) break;
     }
@@ -512,6 +586,9 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
             s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
             for (int i = 0; i < DH_DEC_STATE_WORDS; i++) st_global[i] = s[i];
+#ifdef DH_PHASE_CLOCKS
+            for (int i = 0; i < 4; i++) st_global[28 + i] += S.clk[i] >> 6;
+#endif
             P.out_count[ch] = c.nout;
             if (P.ev_count) P.ev_count[ch] = c.nev;
             if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;

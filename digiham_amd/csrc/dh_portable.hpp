@@ -43,6 +43,16 @@
 #define DH_IS_LANE0(lane) ((lane) == 0)
 #endif
 
+// A value every lane holds identically (loaded from LDS / memory at a wave-uniform address): moving it to a
+// scalar register lets the arithmetic that follows run on the scalar ALU instead of costing VALU issue cycles.
+DH_HD uint32_t dh_uniform(uint32_t x) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t) __builtin_amdgcn_readfirstlane((int) x);
+#else
+    return x;
+#endif
+}
+
 DH_HD int dh_popc32(uint32_t x) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     return __popc(x);

@@ -123,14 +123,14 @@ DH_HD float dh_div_gain_fast(float acc, double rgain, bool& suspect) {
     // the three bits above them, so this is one v_lshl_add_u32 and one compare
     const bool near_tie = (((uint32_t) b.u << 3) + 0x80000020u) <= 64u;
     // Results that may be float subnormals (or overflow) round at other bit positions: with 1 < gain < 128 they
-    // need |acc| < 2^-118 (or >= 2^126).  0, inf and nan are fine: acc * rgain is then acc / gain bit for bit.
+    // need |acc| < 2^-118; the quotient of a finite acc cannot overflow.  0, inf and nan are fine: acc * rgain is
+    // then acc / gain bit for bit.
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-    const int ex = __builtin_amdgcn_frexp_expf(acc);               // 0 for zero / inf / nan
-    const bool odd_range = (uint32_t) (ex + 117) > 243u;
+    const bool odd_range = __builtin_fabsf(acc) < 0x1p-118f && acc != 0.0f;      // two compares, masks ANDed on the SALU
 #else
     union { float f; uint32_t u; } a; a.f = acc;
     const uint32_t be = (a.u >> 23) & 0xFFu;
-    const bool odd_range = be == 0u ? (a.u << 1) != 0u : (be != 255u && (be < 127u - 118u || be >= 127u + 126u));
+    const bool odd_range = be == 0u ? (a.u << 1) != 0u : be < 127u - 118u;
 #endif
     suspect = near_tie || odd_range;
     return (float) q;
@@ -191,17 +191,20 @@ DH_HD void dh_fir_finish(const float* acc, double gain, double rgain, float inv_
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) out16[j] = acc[j] * inv_gain;
     } else {
-        uint32_t suspects = 0;
+        bool any = false;                                 // OR of sixteen compare masks: scalar work, no per-lane bit set
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) {
             bool s;
             out16[j] = dh_div_gain_fast(acc[j], rgain, s);
-            suspects |= (s ? 1u : 0u) << j;
+            any = any || s;
         }
-        if (suspects) {                                   // ~2e-8 per sample: one copy of the IEEE division, not sixteen
+        if (any) {                                        // ~2e-8 per sample: one copy of the IEEE division, not sixteen
 #pragma unroll 1
-            for (int j = 0; j < DH_FIR_L; j++)
-                if ((suspects >> j) & 1u) out16[j] = dh_div_gain_exact(acc[j], gain);
+            for (int j = 0; j < DH_FIR_L; j++) {
+                bool s;
+                (void) dh_div_gain_fast(acc[j], rgain, s);
+                if (s) out16[j] = dh_div_gain_exact(acc[j], gain);
+            }
         }
     }
 }

@@ -262,6 +262,10 @@ struct Engine {
     }
 
     int debug_header(uint32_t word, uint32_t* h_out) {
+        if (word >= 100u) {                                  // 100 + w: word w of the decoder state
+            if (!dec_state || word - 100u >= DH_DEC_STATE_WORDS || !h_out) return DH_EINVAL;
+            return be.download2d(h_out, sizeof(uint32_t), dec_state + (word - 100u), sizeof(uint32_t) * DH_DEC_STATE_WORDS, sizeof(uint32_t), L.B) ? DH_EDEVICE : DH_OK;
+        }
         if (!dsp_state || word >= DH_STATE_HDR || !h_out) return DH_EINVAL;
         return be.download2d(h_out, sizeof(uint32_t), dsp_state + word, sizeof(uint32_t) * L.state_words, sizeof(uint32_t), L.B) ? DH_EDEVICE : DH_OK;
     }

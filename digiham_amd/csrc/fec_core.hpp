@@ -47,6 +47,24 @@ DH_HD bool dh_block_decode(const DhCode& c, const LutT* lut, uint32_t& word) {
     return true;
 }
 
+// Same decode for a wave-uniform word with the wavefront's help: lane i evaluates parity-check row i, a vote
+// collects the syndrome (first row in the MSB), the pattern lookup is one load.  R = n - k.
+template <int R, typename LutT>
+DH_HD bool dh_block_decode_wave(const DhCode& c, const LutT* lut, uint32_t& word) {
+    uint64_t votes = 0;
+    DH_FOR_LANES(lane) {
+        bool b = false;
+        if (lane < R) b = (dh_popc32(word & c.h[lane]) & 1) != 0;
+        DH_BALLOT_ACC(votes, b, lane);
+    }
+    const uint32_t s = dh_brev32((uint32_t) votes) >> (32 - R);
+    if (s == 0) return true;
+    const uint32_t p = dh_uniform((uint32_t) lut[s]);
+    if (p == 0) return false;
+    word ^= p;
+    return true;
+}
+
 // ------------------------------------------------------------------ BPTC(196,96)
 // reference: src/dmr_decoder/bptc_196_96.c:5-59.  `raw` holds the 196 received bits MSB-first
 // in 25 bytes.  The de-interleave (i*181 mod 196) and the 13x15 pivot are folded into one gather.

@@ -172,7 +172,8 @@ int  dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float*
  * blocks = 100-symbol variance blocks evaluated (gfsk_demodulator.cpp:41-80), ordered = those in which the
  * error-bounded estimate could not separate the phases and the reference's in-order sums decided. Synchronises. */
 int  dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered);
-/* Diagnostic: word `word` (0..15) of every channel's slicer state header into h_out[n_channels]. Synchronises. */
+/* Diagnostic: word `word` (0..15) of every channel's slicer state header, or word `word - 100` (0..31) of its
+ * decoder state, into h_out[n_channels]. Synchronises. */
 int  dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out);
 /* wait for all enqueued work; returns DH_ECAPACITY if any channel overflowed an output buffer */
 int  dh_engine_sync(dh_engine* e);
