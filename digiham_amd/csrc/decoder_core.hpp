@@ -113,10 +113,43 @@ DH_HD int dh_dmr_sync_type(const DhPlanes& p, int start) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The 32 state words of a channel while its wavefront runs: ONE vector register, word i in lane i.  The frame
+// state machines index them with run-time (wave-uniform) indices such as DS_SYNC_TYPE0 + slot; v_readlane /
+// v_writelane take the index from a scalar register, so a read or write is a single instruction with no memory
+// round trip (an LDS copy costs ~100 cycles of latency per access on this serial path, a register array would
+// go to scratch).  s[i] reads, s[i] = v writes; the harness build is a plain array.
+struct DhState {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    uint32_t reg;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return (uint32_t) __builtin_amdgcn_readlane((int) reg, (int) i); }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) {
+        const uint32_t sv = dh_uniform(v), si = dh_uniform(i);         // v_writelane takes value and lane from scalar registers
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(sv), "s"(si) : "m0");   // one SGPR + m0: constant-bus limit
+    }
+    __device__ __forceinline__ void load(const uint32_t* g) { reg = threadIdx.x < DH_DEC_STATE_WORDS ? g[threadIdx.x] : 0u; }
+    __device__ __forceinline__ void store(uint32_t* g) const { if (threadIdx.x < DH_DEC_STATE_WORDS) g[threadIdx.x] = reg; }
+#else
+    uint32_t w[DH_DEC_STATE_WORDS];
+    uint32_t get(uint32_t i) const { return w[i]; }
+    void set(uint32_t i, uint32_t v) { w[i] = v; }
+    void load(const uint32_t* g) { for (int i = 0; i < DH_DEC_STATE_WORDS; i++) w[i] = g[i]; }
+    void store(uint32_t* g) const { for (int i = 0; i < DH_DEC_STATE_WORDS; i++) g[i] = w[i]; }
+#endif
+    struct Ref {
+        DhState* st; uint32_t i;
+        DH_HD operator uint32_t() const { return st->get(i); }
+        DH_HD Ref& operator=(uint32_t v) { st->set(i, v); return *this; }
+        DH_HD Ref& operator=(const Ref& o) { st->set(i, (uint32_t) o); return *this; }
+        DH_HD uint32_t operator++(int) { const uint32_t v = st->get(i); st->set(i, v + 1u); return v; }
+    };
+    DH_HD Ref operator[](uint32_t i) { return Ref{this, i}; }
+    DH_HD Ref operator[](int i) { return Ref{this, (uint32_t) i}; }
+};
+
 struct DhDecCtx {
     const DhDecParams* P;
     const DhFecTables* T;              // LDS-resident prefix of the tables
-    uint32_t* st;
+    DhState* st;
     uint8_t* out; dh_event* ev;
     uint32_t nout, nev, consumed;
     bool overflow;
@@ -136,7 +169,7 @@ DH_HD void dh_emit(DhDecCtx& c, uint8_t type, uint8_t a, uint8_t b, const uint8_
 }
 
 // FramePhase::FramePhase() + Decoder::setPhase (dmr_phase.cpp:49-52, dmr_phase.hpp:51-60, dmr_decoder.cpp:17-23)
-DH_HD void dh_dmr_enter_frame_phase(uint32_t* s) {
+DH_HD void dh_dmr_enter_frame_phase(DhState& s) {
     s[DS_SYNC_COUNT] = 0; s[DS_SLOT] = (uint32_t) -1; s[DS_SLOT_STABILITY] = 0;
     s[DS_SYNC_TYPE0] = s[DS_SYNC_TYPE1] = (uint32_t) -1;
     s[DS_SLOT_SYNC0] = s[DS_SLOT_SYNC1] = 0;
@@ -155,7 +188,6 @@ struct DhDecShared {
     // codes + small syndrome LUTs (everything of DhFecTables in front of the two 16 KiB Golay LUTs): table lookups
     // on the frame path are LDS reads instead of dependent global loads
     uint32_t fec_small[(offsetof(DhFecTables, lut_g208) + 3) / 4];
-    uint32_t state[DH_DEC_STATE_WORDS];   // wave-uniform working copy of the channel state
     DhPlanes planes;                      // bit planes of the current frame (wave-uniform; LDS broadcast reads)
     uint32_t colword[16];
     uint32_t vit_metric[2][64];
@@ -246,7 +278,7 @@ DH_HD bool dh_dmr_embedded_lc(const DhFecTables& T, const uint32_t* data, uint32
 }
 
 DH_HD void dh_dmr_slot_sync_lost(DhDecCtx& c, int slot) {     // dmr_phase.cpp:175-182 == :194-200
-    uint32_t* s = c.st;
+    DhState& s = *c.st;
     int v = (int) s[DS_SLOT_SYNC0 + slot] - 1;
     if (v < 0) {
         v = 0;
@@ -290,7 +322,7 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
     }
     const uint32_t sync_h = (uint32_t) headvote & 0xFFFFFFu, sync_l = (uint32_t) (headvote >> 24) & 0xFFFFFFu;
     const DhFecTables& T = *c.T;          // LDS copy (codes + small LUTs); Golay LUTs via c.P->T
-    uint32_t* s = c.st;
+    DhState& s = *c.st;
     DhDmrFrameResult R; R.to_sync = false; R.voice_out = false; R.want_bptc = false; R.data_type = 0;
 
     // CACH: the 7 TACT bits, first one in the MSB (cach.cpp:7,11-19)
@@ -346,13 +378,14 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
             const uint32_t lcss = (emb >> 9) & 3u; uint8_t cc = (uint8_t) ((emb >> 12) & 15u);
             dh_emit(c, DH_EV_DMR_EMB, (uint8_t) slot, (uint8_t) lcss, &cc, 1);
             uint32_t off = s[DS_EMB_OFF0 + slot];
-            uint32_t* data = s + (slot ? DS_EMB_DATA1 : DS_EMB_DATA0);
+            const uint32_t dbase = slot ? DS_EMB_DATA1 : DS_EMB_DATA0;
             if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
             if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
-                if (off <= 3) { data[off] = frag; off++; }
+                if (off <= 3) { s[dbase + off] = frag; off++; }
             }
             if (lcss == 2) {                                             // LCSS_STOP
                 uint8_t lc[9];
+                const uint32_t data[4] = { s[dbase], s[dbase + 1u], s[dbase + 2u], s[dbase + 3u] };
                 if (dh_dmr_embedded_lc(T, data, off, S, lc)) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
                 off = 0;
             }
@@ -496,28 +529,25 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     DH_DCLK_BEGIN();
     DhDecCtx c;
     c.P = &P; c.T = &dh_lds_tables(S);
-    c.st = P.state + (size_t) ch * P.state_stride;
+    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
+    DhState s; s.load(st_global);
+    c.st = &s;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
     c.nout = 0; c.nev = 0; c.overflow = false;
-    c.consumed = c.st[DS_CONSUMED];
+    c.consumed = s[DS_CONSUMED];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     c.writer = threadIdx.x == 0;
 #else
     c.writer = true;
 #endif
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = S.carry; syms.nc = c.st[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
     syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0;
-    uint32_t phase = c.st[DS_PHASE];
-    // the state words are wave-uniform working copies; lane 0 stores them back at the end
-    uint32_t* const s = S.state;       // every lane stores the same values: no barrier needed for its own reads
-    for (int i = 0; i < DH_DEC_STATE_WORDS; i++) s[i] = c.st[i];
-    uint32_t* const st_global = c.st;
-    c.st = s;
+    uint32_t phase = s[DS_PHASE];
     DH_DCLK(0);
 
     for (;;) {
@@ -583,17 +613,17 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         // sources are LDS (carried part / window), destination is the global carry row: no overlap to worry about
         for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
         if (DH_IS_LANE0(lane)) {
-            s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
-            s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
-            for (int i = 0; i < DH_DEC_STATE_WORDS; i++) st_global[i] = s[i];
-#ifdef DH_PHASE_CLOCKS
-            for (int i = 0; i < 4; i++) st_global[28 + i] += S.clk[i] >> 6;
-#endif
             P.out_count[ch] = c.nout;
             if (P.ev_count) P.ev_count[ch] = c.nev;
             if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
         }
     }
+    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+    s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+#ifdef DH_PHASE_CLOCKS
+    for (int i = 0; i < 4; i++) s[28 + i] = (uint32_t) s[28 + i] + (dh_uniform(S.clk[i]) >> 6);
+#endif
+    s.store(st_global);
     DH_BARRIER();
 }
 
@@ -775,7 +805,7 @@ DH_HD uint8_t dh_ysf_v2_voice_byte(const DhPlanes& p, int base, int byte) {
     return (uint8_t) v;
 }
 
-DH_HD void dh_ysf_enter_frame_phase(uint32_t* s) {
+DH_HD void dh_ysf_enter_frame_phase(DhState& s) {
     s[DS_SYNC_COUNT] = 0; s[DS_HAS_FICH] = 0; s[DS_FICH] = 0; s[DS_EXPECT_SUB] = 0;
 }
 
@@ -798,9 +828,8 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 #else
     c.writer = true;
 #endif
-    uint32_t* const s = S.state;
-    for (int i = 0; i < DH_DEC_STATE_WORDS; i++) s[i] = st_global[i];
-    c.st = s;
+    DhState s; s.load(st_global);
+    c.st = &s;
     c.consumed = s[DS_CONSUMED];
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
     DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
@@ -986,13 +1015,13 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         // sources are LDS (carried part / window), destination is the global carry row: no overlap to worry about
         for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
         if (DH_IS_LANE0(lane)) {
-            s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
-            s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
-            for (int i = 0; i < DH_DEC_STATE_WORDS; i++) st_global[i] = s[i];
             P.out_count[ch] = c.nout;
             if (P.ev_count) P.ev_count[ch] = c.nev;
             if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
         }
     }
+    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+    s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+    s.store(st_global);
     DH_BARRIER();
 }

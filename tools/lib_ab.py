@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""A/B of build variants on the full DMR (or YSF) chain: tools/lib_ab.py dmr variants/lib_a.so variants/lib_b.so ..."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from digiham_amd import api, synth_torch, _capi
+proto = sys.argv[1]
+B = 16384
+x, info = synth_torch.make_batch(torch, torch.device("cuda", 0), proto, B, 132 if proto == "dmr" else 40, seed=1000)
+T = info["samples_per_channel"]
+for path in sys.argv[2:] * 2:
+    ctx = api.Context(lib=_capi.load(path))
+    row = []
+    for split in (True, False):
+        try:
+            eng = api.Engine(B, T, proto=proto, split_stages=split, ctx=ctx)
+        except TypeError:
+            continue
+        eng.timing_enable(8)
+        for _ in range(2): eng.push(x)
+        eng.sync(); eng.timing_read()
+        for _ in range(5): eng.push(x)
+        eng.sync()
+        a, b, c = eng.timing_read()
+        row.append("%s slicer %.2f decoder %.2f" % ("split" if split else "chain", b.mean(), c.mean()))
+        eng.close()
+    print(os.path.basename(path), " | ".join(row), flush=True)
