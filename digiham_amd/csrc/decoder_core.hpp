@@ -124,7 +124,11 @@ struct DhState {
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return (uint32_t) __builtin_amdgcn_readlane((int) reg, (int) i); }
     __device__ __forceinline__ void set(uint32_t i, uint32_t v) {
         const uint32_t sv = dh_uniform(v), si = dh_uniform(i);         // v_writelane takes value and lane from scalar registers
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(sv), "s"(si) : "m0");   // one SGPR + m0: constant-bus limit
+        // gfx9 VOP3 reads at most one SGPR, so the lane select goes through m0; m0 is reserved for the compiler
+        // (a clobber would be ignored), hence saved and restored around the write
+        uint32_t keep;
+        asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+            : "+v"(reg), "=&s"(keep) : "s"(sv), "s"(si));
     }
     __device__ __forceinline__ void load(const uint32_t* g) { reg = threadIdx.x < DH_DEC_STATE_WORDS ? g[threadIdx.x] : 0u; }
     __device__ __forceinline__ void store(uint32_t* g) const { if (threadIdx.x < DH_DEC_STATE_WORDS) g[threadIdx.x] = reg; }
