@@ -262,6 +262,9 @@ struct HipBackend {
     template <int NZ, bool FAST, int PROTO> int go_chain(const DhDspParams& P, const DhDecParams& D) {
         size_t lds = dh_dsp_shared_bytes(10);
         if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
+#ifdef DH_LDS_PAD
+        lds += DH_LDS_PAD;                  // occupancy experiments (tools/build_variant.sh)
+#endif
         hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P, D);
         return launched("k_chain");
     }
