@@ -12,11 +12,15 @@
 #include <csdr/module.hpp>
 #include <csdr/reader.hpp>
 #include <csdr/writer.hpp>
+#include <csdr/ringbuffer.hpp>
 #else
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdio>
+#include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace Csdr {
 
@@ -77,6 +81,55 @@ namespace Csdr {
             }
         protected:
             virtual void process(T* input, U* output, size_t length) = 0;
+    };
+
+    // What the CLI driver needs (src/lib/cli.cpp:10,26-27,102-106): a buffer written by fread() and read by the
+    // module through a RingbufferReader, and a writer that hands every advance() to stdout.  csdr's ring buffer
+    // maps its memory twice to stay contiguous across the wrap; this one keeps a linear buffer and moves the unread
+    // tail to the front when the write position reaches the end -- same contract (contiguous readable and writeable
+    // regions), single reader.
+    template <typename T> class RingbufferReader;
+
+    template <typename T> class Ringbuffer: public Writer<T> {
+        public:
+            explicit Ringbuffer(size_t size): data(size) {}
+            size_t writeable() override { compact(); return data.size() - tail; }
+            T* getWritePointer() override { compact(); return data.data() + tail; }
+            void advance(size_t how_much) override { tail += how_much; }
+        private:
+            friend class RingbufferReader<T>;
+            void compact() {
+                if (head == tail) { head = tail = 0; return; }
+                if (tail == data.size() && head > 0) {
+                    std::memmove(data.data(), data.data() + head, (tail - head) * sizeof(T));
+                    tail -= head; head = 0;
+                }
+            }
+            std::vector<T> data;
+            size_t head = 0, tail = 0;
+    };
+
+    template <typename T> class RingbufferReader: public Reader<T> {
+        public:
+            explicit RingbufferReader(Ringbuffer<T>* buffer): buffer(buffer) {}
+            size_t available() override { return buffer->tail - buffer->head; }
+            T* getReadPointer() override { return buffer->data.data() + buffer->head; }
+            void advance(size_t how_much) override { buffer->head += how_much; }
+        private:
+            Ringbuffer<T>* buffer;
+    };
+
+    template <typename T> class StdoutWriter: public Writer<T> {
+        public:
+            explicit StdoutWriter(size_t size = 262144): data(size) {}
+            size_t writeable() override { return data.size(); }
+            T* getWritePointer() override { return data.data(); }
+            void advance(size_t how_much) override {
+                fwrite(data.data(), sizeof(T), how_much, stdout);
+                fflush(stdout);
+            }
+        private:
+            std::vector<T> data;
     };
 
 }

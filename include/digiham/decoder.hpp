@@ -1,9 +1,10 @@
 // decoder.hpp -- Digiham::Decoder, Digiham::Dmr::Decoder, Digiham::Ysf::Decoder on the MI355X engine
 // (reference: include/decoder.hpp:17-30, include/dmr_decoder.hpp:9-17, include/ysf_decoder.hpp:9-12).
 //
-// Output bytes are the reference's.  The metadata tail of the reference (MetaCollector -> MetaWriter text
-// lines: talker alias, GPS, call signs) is outside this engine; every call the reference would make into its
-// MetaCollector is delivered as a dh_event (FEC-corrected LC / FICH / DCH bytes) to the event callback.
+// Output bytes are the reference's.  Every call the reference's frame parsers make into their MetaCollector
+// arrives from the GPU as a dh_event (FEC-corrected LC / FICH / DCH bytes); with a MetaWriter set, the host-side
+// collectors of dmr_meta.hpp / ysf_meta.hpp replay them into the reference's `k:v;k:v\n` lines.  The raw events
+// are also available through the event callback.
 #pragma once
 
 #include <functional>
@@ -12,17 +13,17 @@
 
 #include "csdr_compat.hpp"
 #include "engine_handle.hpp"
+#include "dmr_meta.hpp"
+#include "ysf_meta.hpp"
 
 #define BUF_SIZE 128
 #define RINGBUFFER_SIZE 1024
 
 namespace Digiham {
 
-    class MetaWriter;   // metadata text serialisation is not part of this engine (see header comment)
-
     class Decoder: public Csdr::Module<unsigned char, unsigned char> {
         public:
-            ~Decoder() override { dh_device_free(dSyms); dh_device_free(dCount); }
+            ~Decoder() override { dh_device_free(dSyms); dh_device_free(dCount); delete metaCollector; }
             bool canProcess() override {
                 std::lock_guard<std::mutex> lock(processMutex);
                 return reader->available() > 0 && writer->writeable() >= maxOutputPerCall;
@@ -40,15 +41,23 @@ namespace Digiham {
                 size_t got = writer->writeable();
                 Amd::check(dh_engine_read_frames(engine->get(), 0, writer->getWritePointer(), &got), "dh_engine_read_frames");
                 writer->advance(got);
-                if (onEvent) {
+                if (onEvent || metaCollector) {
                     events.resize(chunk / 20 + 64);
                     size_t ne = events.size();
                     Amd::check(dh_engine_read_events(engine->get(), 0, events.data(), &ne), "dh_engine_read_events");
-                    for (size_t i = 0; i < ne; i++) onEvent(events[i]);
+                    for (size_t i = 0; i < ne; i++) {
+                        if (metaCollector) metaCollector->consume(events[i]);
+                        if (onEvent) onEvent(events[i]);
+                    }
+                    if (metaCollector) metaCollector->flush();
                 }
             }
-            // reference signature kept for source compatibility; the writer is owned and released, never fed
-            void setMetaWriter(MetaWriter* meta) { (void) meta; }
+            // takes ownership of the writer, as the reference does (src/lib/decoder.cpp:34-40)
+            void setMetaWriter(MetaWriter* meta) {
+                std::lock_guard<std::mutex> lock(processMutex);
+                if (!metaCollector) metaCollector = proto == DH_PROTO_DMR ? (MetaCollector*) new Dmr::MetaCollector() : (MetaCollector*) new Ysf::MetaCollector();
+                metaCollector->setWriter(meta);
+            }
             void setEventCallback(std::function<void(const dh_event&)> cb) { onEvent = std::move(cb); }
         protected:
             explicit Decoder(int proto): proto(proto) {}
@@ -69,6 +78,7 @@ namespace Digiham {
             void* dCount = nullptr;
             std::vector<dh_event> events;
             std::function<void(const dh_event&)> onEvent;
+            MetaCollector* metaCollector = nullptr;
     };
 
     namespace Dmr {
