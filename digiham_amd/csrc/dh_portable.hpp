@@ -32,12 +32,20 @@
 #define DH_WAVE 64
 
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// DH_FOR_LANES_FRESH: the lane id passes through an empty volatile asm, so nothing derived from it (per-lane LDS
+// addresses, lane % 10, 64-bit row pointers) is loop-invariant to the compiler.  Left alone it hoists dozens of such
+// values out of the slicer's per-run loop, across the FIR where every register is taken, spills them to scratch and
+// reloads them with dependent memory round trips inside the latency-bound phases; recomputing them costs a few VALU
+// instructions per phase instead.  Used for the phases inside that loop; everything else uses DH_FOR_LANES.
+static __device__ __forceinline__ int dh_fresh_lane_id_() { int l = (int) threadIdx.x; asm volatile("" : "+v"(l)); return l; }
 #define DH_FOR_LANES(lane) for (int lane = (int) threadIdx.x, dh_once_ = 1; dh_once_; dh_once_ = 0)
+#define DH_FOR_LANES_FRESH(lane) for (int lane = dh_fresh_lane_id_(), dh_once_ = 1; dh_once_; dh_once_ = 0)
 #define DH_BARRIER() __syncthreads()
 #define DH_BALLOT_ACC(mask, pred, lane) (mask) = __ballot((pred) ? 1 : 0)
 #define DH_IS_LANE0(lane) ((lane) == 0)
 #else
 #define DH_FOR_LANES(lane) for (int lane = 0; lane < DH_WAVE; ++lane)
+#define DH_FOR_LANES_FRESH(lane) DH_FOR_LANES(lane)
 #define DH_BARRIER() ((void) 0)
 #define DH_BALLOT_ACC(mask, pred, lane) (mask) |= ((uint64_t) ((pred) ? 1 : 0) << (lane))
 #define DH_IS_LANE0(lane) ((lane) == 0)

@@ -26,6 +26,9 @@
 #define DH_FTILE 1024                // filtered samples produced per FIR pass (64 lanes x 16)
 #define DH_FIR_L 16                  // consecutive outputs per lane
 #define DH_PF_N 5                    // 16-byte prefetch loads per lane covering 1024 + 160 samples
+#ifndef DH_PF_L2
+#define DH_PF_L2 1                   // 1: prefetch the next window into L2 only (no registers held across P4-P6); 0: into registers
+#endif
 #define DH_MAX_NZ 160
 #define DH_MAX_SPS 40
 #define DH_TAIL_MAX 256              // raw samples carried between pushes (>= nz + sps + 2)
@@ -65,25 +68,48 @@ DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYM
 // overwritten in place by the filtered samples of the run.
 #define DH_XPAD(i) ((i) + ((i) >> 4))
 #define DH_SCAN_N 128
+// The LDS block of one wavefront, carved by dh_dsp_carve():
+//   vol_old[128] vol_new[128] tapsf[84] stats[2] (clk[8])   fixed part
+//   var_rb[100 * sps]     variance ring, phase-major: row i holds sample i of the last 100 symbols
+//   xf[...]               raw-sample window during the FIR (padded one word per 16 so that the per-lane sliding
+//                         windows, 16 words apart, hit 32 different banks), then overwritten by the filtered samples
+// Everything that only lives between the window phase (P3) and the next staging (P7) sits INSIDE the window block,
+// which is idle then: the AGC extremes mn / mx (also the scratch of the timing estimate) in its first 256 words
+// (the filtered samples there are dead once P3 has copied them into the ring), the ordered-chain variances behind
+// them, and the mid-symbol sums behind the last filtered sample.  10.1 KB per wavefront for the wide filter at
+// sps 10: 16 wavefronts per CU.
 struct DhDspShared {
-    float xf[DH_XPAD(DH_FTILE + DH_MAX_NZ) + 1];
-    float vol_old[DH_SCAN_N];                          // ring content before the current run (+ identity padding)
-    float vol_new[DH_SCAN_N];                          // entries written by the current run
-    alignas(16) float mn[DH_SCAN_N];                   // AGC window min / max per symbol of the block; after the
-    alignas(16) float mx[DH_SCAN_N];                   // slice (P5) both are scratch for the timing estimate (P6)
-    float sum[DH_VOLUME_RB_SIZE];                      // mid-symbol window sums of the current run
-    double variance[DH_MAX_SPS];
-    uint32_t stats[2];                                 // timing blocks of this push: all / decided by the ordered chain
-#ifdef DH_PHASE_CLOCKS
-    uint32_t clk[8];
-#endif
-    float tapsf[DH_MAX_NZ / 2 + 1];                    // FIR taps (first half + centre)
-    // variance ring follows (sps rows of 100 floats: row i holds sample i of the last 100 symbols), sized at launch
-    alignas(16) float var_rb[4];
+    float* xf;
+    float* vol_old;                                    // ring content before the current run (+ identity padding)
+    float* vol_new;                                    // entries written by the current run
+    float* mn; float* mx;                              // AGC window min / max per symbol of the block
+    float* sum;                                        // mid-symbol window sums of the current run
+    double* variance;                                  // [DH_MAX_SPS] per-phase variances of the ordered chain
+    uint32_t* stats;                                   // timing blocks of this push: all / decided by the ordered chain
+    uint32_t* clk;                                     // DH_PHASE_CLOCKS builds only
+    float* tapsf;                                      // FIR taps (first half + centre)
+    float* var_rb;
 };
 
-DH_HD size_t dh_dsp_shared_bytes(uint32_t sps) {
-    return sizeof(DhDspShared) + sizeof(float) * (size_t) (DH_VARIANCE_SYMBOLS * sps) + 16;
+#define DH_LDS_FIXED_WORDS 352                         // 128 + 128 + 84 + 2 + 8 (+ 2 pad): keeps var_rb 16-byte aligned
+DH_HD uint32_t dh_dsp_xf_words(uint32_t nz) {
+    const uint32_t padded = DH_XPAD(DH_FTILE + nz) + 1u, with_sums = DH_FTILE + 4u + DH_SCAN_N;
+    return ((padded > with_sums ? padded : with_sums) + 3u) & ~3u;
+}
+DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz) {
+    return sizeof(float) * (size_t) (DH_LDS_FIXED_WORDS + DH_VARIANCE_SYMBOLS * sps + dh_dsp_xf_words(nz));
+}
+DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps) {          // base: 16-byte aligned
+    float* f = reinterpret_cast<float*>(base);
+    DhDspShared S;
+    S.vol_old = f; S.vol_new = f + 128; S.tapsf = f + 256;
+    S.stats = reinterpret_cast<uint32_t*>(f + 340); S.clk = S.stats + 2;
+    S.var_rb = f + DH_LDS_FIXED_WORDS;
+    S.xf = S.var_rb + DH_VARIANCE_SYMBOLS * sps;
+    S.mn = S.xf; S.mx = S.xf + DH_SCAN_N;
+    S.variance = reinterpret_cast<double*>(S.xf + 2 * DH_SCAN_N);
+    S.sum = S.xf + DH_FTILE + 4;
+    return S;
 }
 
 // Diagnostic build (-DDH_PHASE_CLOCKS, tools/build_variant.sh): per-phase shader-clock totals of each channel's
@@ -361,7 +387,7 @@ __device__ __forceinline__ float dh_wave_prev(float v, float first) {
 // backwards (lane l takes slots 126-2l and 127-2l), handed back to the owning lanes through LDS (S.mn / S.mx are
 // the exchange buffers: each slot is written once with its suffix value and then overwritten with the result).
 __device__ __forceinline__ void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
-    const int lane = (int) threadIdx.x;
+    const int lane = dh_fresh_lane_id_();
     const uint32_t e0 = 2u * (uint32_t) lane, e1 = e0 + 1u;
     // prefix source: old below k0, new in [k0, k1), identity above
     const float c0 = e0 < k0 ? S.vol_old[e0] : S.vol_new[e0];
@@ -434,6 +460,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
     const float* in_end = P.in + (size_t) (P.n_channels - 1u) * P.in_stride + P.n;    // end of the readable input
 
+    // raw-sample window layout: padded one word per 16 for the FIR's lane-strided reads; plain without an RRC stage
+    // (the samples are then used where they were staged, and the window sums sit right behind them)
+#define DH_XP(e) (NZ > 0 ? DH_XPAD(e) : (e))
     DH_CLK_BEGIN();
     // ---- load carried state
     uint32_t k0 = sth[DH_ST_K];
@@ -495,10 +524,43 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
         // From the second run on, the window was already put there by the previous iteration's prefetch.
         if (staged && staged_p == p) {
+        } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
+            // whole window inside the input buffer: unconditional loads (all in flight together, see the prefetch
+            // below for why that matters), samples past the end of the stream zeroed afterwards
+            const float* src = in + (p - tc);
+            const uint32_t have = dh_min<uint32_t>(DH_FTILE + NZ, nv - p);
+            DH_FOR_LANES_FRESH(lane) {
+                dh_f4 v[DH_PF_N];
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    v[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
+                }
+                if (have >= DH_FTILE + NZ) {
+#pragma unroll
+                    for (int r = 0; r < DH_PF_N; r++) {
+                        const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                        if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XP(e)], v[r]);
+                    }
+                } else {
+                    uint32_t l4 = 4u * (uint32_t) lane;
+                    DH_TO_VGPR(l4);
+#pragma unroll
+                    for (int r = 0; r < DH_PF_N; r++) {
+                        const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
+                        if (e < DH_FTILE + NZ) {
+                            dh_f4 w = v[r];
+                            w.x = e + 0u < have ? w.x : 0.0f; w.y = e + 1u < have ? w.y : 0.0f;
+                            w.z = e + 2u < have ? w.z : 0.0f; w.w = e + 3u < have ? w.w : 0.0f;
+                            dh_store4(&S.xf[DH_XP(e)], w);
+                        }
+                    }
+                }
+            }
         } else if (p >= tc) {
             const float* src = in + (p - tc);
             const uint32_t have = dh_min<uint32_t>(DH_FTILE + NZ, nv - p);
-            DH_FOR_LANES(lane) {
+            DH_FOR_LANES_FRESH(lane) {
                 for (uint32_t e = 4u * (uint32_t) lane; e < DH_FTILE + NZ; e += 4u * DH_WAVE) {
                     dh_f4 v;
                     if (e + 4u <= have) v = dh_load4_unaligned(src + e);
@@ -506,13 +568,13 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         v.x = e + 0u < have ? src[e + 0u] : 0.0f; v.y = e + 1u < have ? src[e + 1u] : 0.0f;
                         v.z = e + 2u < have ? src[e + 2u] : 0.0f; v.w = e + 3u < have ? src[e + 3u] : 0.0f;
                     }
-                    dh_store4(&S.xf[DH_XPAD(e)], v);
+                    dh_store4(&S.xf[DH_XP(e)], v);
                 }
             }
         } else {
-            DH_FOR_LANES(lane) {
+            DH_FOR_LANES_FRESH(lane) {
                 for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
-                    S.xf[DH_XPAD(e)] = p + e < nv ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
+                    S.xf[DH_XP(e)] = p + e < nv ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
             }
         }
         DH_BARRIER();
@@ -529,12 +591,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             float tv[NZ / 2 + 1];
 #pragma unroll
             for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
-            DH_FOR_LANES(lane) {
+            DH_FOR_LANES_FRESH(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need)
                     dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
             }
             DH_BARRIER();
-            DH_FOR_LANES(lane) {
+            DH_FOR_LANES_FRESH(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need) {
                     dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
 #pragma unroll
@@ -549,10 +611,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         DH_CLK(1);
         const float* fbuf = S.xf;
-#define DH_FB(n) fbuf[NZ > 0 ? (n) : DH_XPAD(n)]
+#define DH_FB(n) fbuf[n]
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
-        DH_FOR_LANES(lane) {
+        DH_FOR_LANES_FRESH(lane) {
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
@@ -578,14 +640,29 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const uint32_t p_next = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
         const bool pf_ok = p_next >= tc && p_next < nv;
         const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
+#if !DH_PF_L2
         DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
+#endif
         // Only when the whole window lies inside the input buffer (every run but the last ones of the last
         // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
         // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
         const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
+#if DH_PF_L2
+        // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
+        // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The result register is never
+        // read; it is held (and waited for in P7) only so that nothing else is allocated to it while the load is
+        // in flight.
+        uint32_t pf_touch = 0;
+        if (pf_plain) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            const float* line = in + (p_next - tc) + 32u * threadIdx.x;
+            if (32u * threadIdx.x < DH_FTILE + NZ) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_touch) : "v"(line) : "memory");
+#endif
+        }
+#else
         if (pf_plain) {
             const float* src = in + (p_next - tc);
-            DH_FOR_LANES(lane) {
+            DH_FOR_LANES_FRESH(lane) {
 #pragma unroll
                 for (int r = 0; r < DH_PF_N; r++) {
                     const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
@@ -593,6 +670,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
             }
         }
+#endif
 
         // ---- P4: sliding AGC min/max as two wave scans
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -604,7 +682,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_CLK(3);
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
-        DH_FOR_LANES(lane) {
+        DH_FOR_LANES_FRESH(lane) {
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const float mn = S.mn[k], mx = S.mx[k];
@@ -650,7 +728,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pmax = S.mn + DH_WAVE; float* pd = S.mx;
                 DH_LANE_ARRAY(float, pmean, 1);
-                DH_FOR_LANES(lane) {
+                DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
                         const int i = lane % 10, g = lane / 10;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
@@ -666,7 +744,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     }
                 }
                 DH_BARRIER();
-                DH_FOR_LANES(lane) {
+                DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
                         const int i = lane % 10, g = lane / 10;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
@@ -688,7 +766,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // lanes 0..9 hold one phase each; the others hold neutral values
                 DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
                 uint64_t vote_guard = 0, vote_zero = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
-                DH_FOR_LANES(lane) {
+                DH_FOR_LANES_FRESH(lane) {
                     float l = DH_FLT_MAX, h = DH_FLT_MAX;
                     bool guard = true, zero = false;
                     if (lane < 10) {
@@ -715,7 +793,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 hmin = DH_FLT_MAX;
                 for (int q = 0; q < 10; q++) hmin = dh_fmin_(hmin, hi[q][0]);
 #endif
-                DH_FOR_LANES(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
+                DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
                 const uint32_t ten = 0x3FFu;
                 const uint32_t above = (uint32_t) vote_above & ten;
                 const uint32_t cand = ~above & ten;                 // phases whose interval reaches below hmin
@@ -733,7 +811,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
                 // ring and fetched 16 bytes at a time
                 DH_BARRIER();
-                DH_FOR_LANES(lane) {
+                DH_FOR_LANES_FRESH(lane) {
                     if ((uint32_t) lane < sps) {
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
                         float total = 0.0f;
@@ -755,25 +833,31 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     }
                 }
                 DH_BARRIER();
-                DH_FOR_LANES(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+                DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
                 double vmin = S.variance[0]; uint32_t vmin_pos = 0;
                 for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
                 if (vmin <= 0 || vmin > 5000000) {
                 } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
                 else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
             }
-            DH_FOR_LANES(lane) { if (DH_IS_LANE0(lane)) S.stats[0]++; }
+            DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[0]++; }
         }
 
         DH_CLK(5);
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
-        DH_FOR_LANES(lane) {
+        DH_FOR_LANES_FRESH(lane) {
             for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k];
+#if DH_PF_L2
+            (void) pf_have;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_touch) :: "memory");    // the touch load has landed: its register is free
+#endif
+#else
             if (pf_plain && pf_have >= DH_FTILE + NZ) {         // the usual case: a full window, stored as loaded
 #pragma unroll
                 for (int r = 0; r < DH_PF_N; r++) {
                     const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                    if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XPAD(e)], DH_LA(pf, lane)[r]);
+                    if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XP(e)], DH_LA(pf, lane)[r]);
                 }
             } else if (pf_plain) {                              // last window of the push: zeros beyond the input
                 uint32_t l4 = 4u * (uint32_t) lane;
@@ -785,12 +869,17 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         dh_f4 v = DH_LA(pf, lane)[r];
                         v.x = e + 0u < pf_have ? v.x : 0.0f; v.y = e + 1u < pf_have ? v.y : 0.0f;
                         v.z = e + 2u < pf_have ? v.z : 0.0f; v.w = e + 3u < pf_have ? v.w : 0.0f;
-                        dh_store4(&S.xf[DH_XPAD(e)], v);
+                        dh_store4(&S.xf[DH_XP(e)], v);
                     }
                 }
             }
+#endif
         }
+#if DH_PF_L2
+        staged = false;
+#else
         staged = pf_plain; staged_p = p_next;
+#endif
         DH_BARRIER();
         p = p_next;
         nsym += m;

@@ -39,7 +39,7 @@ int hip_fail(hipError_t e, const char* what) {
 template <int NZ, bool FAST, int SPS>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
+    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
     dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
 }
 
@@ -50,7 +50,10 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(co
 template <int NZ, bool FAST, int PROTO>
 __global__ __launch_bounds__(DH_WAVE, DH_LB) void k_chain(const DhDspParams P, const DhDecParams D) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    dh_rrc_demod_channel<NZ, FAST, 10>(P, blockIdx.x, *reinterpret_cast<DhDspShared*>(dh_smem));
+    {
+        DhDspShared L = dh_dsp_carve(dh_smem, 10u);
+        dh_rrc_demod_channel<NZ, FAST, 10>(P, blockIdx.x, L);
+    }
     __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
     __syncthreads();
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(DH_WAVE, DH_LB) void k_chain(const DhDspParams P, c
 template <int NZ, bool FAST>
 __global__ __launch_bounds__(DH_WAVE, ((NZ > 80 || FAST) ? 2 : DH_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    DhDspShared& S = *reinterpret_cast<DhDspShared*>(dh_smem);
+    DhDspShared S = dh_dsp_carve(dh_smem, 0u);
     dh_rrc_tile<NZ, FAST>(R, blockIdx.y, blockIdx.x, S);
 }
 
@@ -241,7 +244,7 @@ struct HipBackend {
     }
 
     template <int NZ, bool FAST, int SPS> int go_rrc_demod(const DhDspParams& P) {
-        const size_t lds = dh_dsp_shared_bytes(P.sps);
+        const size_t lds = dh_dsp_shared_bytes(P.sps, NZ);
         if (lds > 48 * 1024) {
             if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
                          "hipFuncSetAttribute")) return -1;
@@ -260,7 +263,7 @@ struct HipBackend {
         return -1;
     }
     template <int NZ, bool FAST, int PROTO> int go_chain(const DhDspParams& P, const DhDecParams& D) {
-        size_t lds = dh_dsp_shared_bytes(10);
+        size_t lds = dh_dsp_shared_bytes(10, NZ);
         if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
 #ifdef DH_LDS_PAD
         lds += DH_LDS_PAD;                  // occupancy experiments (tools/build_variant.sh)
@@ -278,7 +281,7 @@ struct HipBackend {
     }
     template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
-        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3(tiles, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(1), stream, R);
+        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3(tiles, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), stream, R);
         return launched("k_rrc_tile");
     }
     int launch_rrc_tiles(const DhRrcParams& R, uint32_t nz, bool fast) {

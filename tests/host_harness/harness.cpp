@@ -43,8 +43,8 @@ struct HostBackend {
     int timing_read(float*, float*, float*, uint32_t* n) { *n = 0; return 0; }
 
     template <int NZ, bool FAST, int SPS> static void run_rrc_demod(const DhDspParams& P) {
-        std::vector<char> lds(dh_dsp_shared_bytes(P.sps) + 64);
-        DhDspShared& S = *reinterpret_cast<DhDspShared*>(lds.data());
+        std::vector<float> lds(dh_dsp_shared_bytes(P.sps, NZ) / sizeof(float));     // exactly the device allocation
+        DhDspShared S = dh_dsp_carve(lds.data(), P.sps);
         for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, S);
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
@@ -57,8 +57,8 @@ struct HostBackend {
         return 0;
     }
     template <int NZ, bool FAST> static void run_rrc_tiles(const DhRrcParams& R) {
-        std::vector<char> lds(dh_dsp_shared_bytes(1) + 64);
-        DhDspShared& S = *reinterpret_cast<DhDspShared*>(lds.data());
+        std::vector<float> lds(dh_dsp_shared_bytes(0, NZ) / sizeof(float));
+        DhDspShared S = dh_dsp_carve(lds.data(), 0);
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
         for (uint32_t ch = 0; ch < R.n_channels; ch++)
             for (uint32_t t = 0; t < tiles; t++) dh_rrc_tile<NZ, FAST>(R, ch, t, S);
