@@ -26,6 +26,7 @@
 #define DH_FTILE 1024                // filtered samples produced per FIR pass (64 lanes x 16)
 #define DH_FIR_L 16                  // consecutive outputs per lane
 #define DH_PF_N 5                    // 16-byte prefetch loads per lane covering 1024 + 160 samples
+#define DH_PF_SINK 512               // word offset inside the window block where the L2-touch loads drop their dwords (64 words)
 #ifndef DH_PF_L2
 #define DH_PF_L2 1                   // 1: prefetch the next window into L2 only (no registers held across P4-P6); 0: into registers
 #endif
@@ -366,7 +367,8 @@ __device__ __forceinline__ float dh_vmax(float a, float b) { float r; asm("v_max
 __device__ __forceinline__ void dh_wave_prefix_minmax(float& mn, float& mx) {
 #define DH_SCAN_STEP(ctrl) \
     "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl "\n\t"
-    asm volatile(DH_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+    asm volatile("s_nop 4\n\t"                 // a VALU write of EXEC just before would need 5 wait states ahead of a DPP op
+                 DH_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
                  DH_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
                  DH_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
                  DH_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
@@ -379,7 +381,7 @@ __device__ __forceinline__ void dh_wave_prefix_minmax(float& mn, float& mx) {
 // value of the previous lane (lane 0 keeps `first`): wave_shr:1
 __device__ __forceinline__ float dh_wave_prev(float v, float first) {
     float r = first;
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(r) : "v"(v));
+    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(r) : "v"(v));
     return r;
 }
 
@@ -434,7 +436,7 @@ inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // minimum of lanes 0..15 (one DPP row), valid in lane 15 and returned wave-uniform: four v_min_f32 with row_shr
 __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
-    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 4\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
@@ -649,14 +651,19 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
 #if DH_PF_L2
         // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
-        // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The result register is never
-        // read; it is held (and waited for in P7) only so that nothing else is allocated to it while the load is
-        // in flight.
-        uint32_t pf_touch = 0;
+        // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The dwords themselves are not
+        // wanted: global_load_lds_dword drops them (lane l -> m0 + 4 l) into a part of the window block that is dead
+        // until the next staging, so no vector register is tied to a load the compiler does not know about.  They
+        // have landed before the next P1 stores anything there (its own, younger loads are waited for first), and
+        // an explicit s_waitcnt follows the loop for the last one.
         if (pf_plain) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
             const float* line = in + (p_next - tc) + 32u * threadIdx.x;
-            if (32u * threadIdx.x < DH_FTILE + NZ) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_touch) : "v"(line) : "memory");
+            const uint32_t sink = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) (S.xf + DH_PF_SINK);
+            uint32_t keep_m0;
+            if (32u * threadIdx.x < DH_FTILE + NZ)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep_m0) : "s"(sink), "v"(line) : "memory");
 #endif
         }
 #else
@@ -849,9 +856,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k];
 #if DH_PF_L2
             (void) pf_have;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_touch) :: "memory");    // the touch load has landed: its register is free
-#endif
 #else
             if (pf_plain && pf_have >= DH_FTILE + NZ) {         // the usual case: a full window, stored as loaded
 #pragma unroll
@@ -889,6 +893,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_CLK(6);
     }
 
+#if DH_PF_L2 && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // a last L2-touch load may still be writing into the window block
+#endif
     // ---- write back state: rings, header, and the raw tail V[p .. nv)
     const uint32_t new_tc = nv - p;                    // = unread filtered samples + NZ
     DH_FOR_LANES(lane) {
