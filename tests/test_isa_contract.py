@@ -1,0 +1,111 @@
+"""The hand-scheduled inline-asm parts of the kernels rely on two things the compiler does not check for us
+(it neither tracks loads issued from inline asm nor inserts hazard wait states inside asm blocks).  This test
+compiles the device code to assembly and verifies them on the generated ISA:
+
+* FIR window reads (dsp_core.hpp: dh_lds_read2 / dh_fir_arrived): between an asm `ds_read2_b32` and the next
+  `s_waitcnt lgkmcnt(0)` no instruction may touch the destination registers (a register-allocator copy or spill
+  there would read data that has not arrived yet);
+* every DPP instruction is at least two instructions (or an s_nop) away from the VALU write of its source;
+* the exact kernels contain no fused multiply-add in the FIR (bit-exactness contract) and
+  the headline kernel uses no scratch.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("isa") / "engine.s")
+    import __graft_entry__ as g
+    flags = [f for f in g.HIP_FLAGS if f not in ("-fPIC", "-shared")]
+    subprocess.run([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(g.CSRC, "engine.hip"), "-o", out],
+                   check=True, cwd=g.CSRC, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    ks = {}
+    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)^\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        ks[m.group(1)] = (m.group(2).splitlines(), m.group(3))
+    assert ks
+    return ks
+
+
+def _regs(operand_text):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(r) for r in re.findall(r"\bv(\d+)\b", operand_text))
+    return regs
+
+
+def _insts(lines):
+    for l in lines:
+        l = l.split(";")[0].strip()
+        if l and not l.startswith(".") and not l.endswith(":"):
+            yield l
+
+
+def test_fir_asm_loads_are_not_touched_before_their_wait(kernels):
+    checked = 0
+    for name, (lines, _) in kernels.items():
+        if "k_chain" not in name and "k_rrc_demod" not in name and "k_rrc_tile" not in name:
+            continue
+        insts = list(_insts(lines))
+        pk = [i for i, l in enumerate(insts) if l.startswith("v_pk_mul_f32") or l.startswith("v_pk_fma_f32")]
+        if not pk:
+            continue
+        lo, hi = pk[0] - 40, pk[-1] + 1
+        pending = {}                                  # register -> index of the load that writes it
+        for i in range(max(lo, 0), hi):
+            l = insts[i]
+            op, _, rest = l.partition(" ")
+            if op == "s_waitcnt" and "lgkmcnt(0)" in rest:
+                pending.clear()
+                continue
+            touched = _regs(rest)
+            bad = touched & set(pending)
+            assert not bad, "%s: `%s` touches v%s while the ds_read2 at #%d is in flight" % (name, l, sorted(bad), pending[min(bad)])
+            if op == "ds_read2_b32":
+                for r in _regs(rest.split(",")[0]):
+                    pending[r] = i
+                checked += 1
+    assert checked > 500                              # 80+ reads in each of the FIR kernels
+
+
+def test_dpp_sources_have_their_wait_states(kernels):
+    seen = 0
+    for name, (lines, _) in kernels.items():
+        insts = list(_insts(lines))
+        for i, l in enumerate(insts):
+            if "_dpp" not in l.split(" ")[0]:
+                continue
+            seen += 1
+            ops = l.partition(" ")[2].split(",")
+            src = _regs(ops[1])                       # src0 is the operand the DPP network reads
+            wait = 0
+            for back in range(i - 1, max(i - 3, -1), -1):
+                p = insts[back]
+                op, _, rest = p.partition(" ")
+                if op == "s_nop":
+                    wait += int(rest.strip()) + 1
+                    continue
+                if wait >= 2:
+                    break
+                if op.startswith("v_") and _regs(rest.split(",")[0]) & src:
+                    raise AssertionError("%s: `%s` reads v%s %d wait state(s) after `%s`" % (name, l, sorted(src), wait, p))
+                wait += 1
+    assert seen > 20
+
+
+def test_exact_kernels_do_not_fuse_and_do_not_spill(kernels):
+    exact = [n for n in kernels if "k_chain" in n and "ILi80ELb0E" in n]
+    assert len(exact) == 2                                            # DMR and YSF
+    for name, (lines, meta) in kernels.items():
+        if name in exact:                                             # exact wide-filter chain kernels
+            body = "\n".join(lines)
+            assert "v_pk_mul_f32" in body and "v_pk_add_f32" in body and "v_pk_fma_f32" not in body
+            assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta), name + " uses scratch"
