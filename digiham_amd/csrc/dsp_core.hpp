@@ -974,22 +974,37 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
     float tv[NZ / 2 + 1];
 #pragma unroll
     for (int i = 0; i <= NZ / 2; i++) { tv[i] = R.taps[i]; DH_TO_VGPR(tv[i]); }
-    // each lane owns 16 consecutive outputs = 64 contiguous bytes of the row: stored straight from registers
+    // Each lane produces 16 consecutive outputs.  Stored straight from registers, one store instruction would touch
+    // 64 separate 64-byte pieces of the row; instead the tile goes through the (now idle) window block and leaves
+    // as four fully coalesced 1 KB stores.
+    DH_LANE_ARRAY(float, fo, DH_FIR_L);
     DH_FOR_LANES(lane) {
-        const uint32_t o0 = (uint32_t) lane * DH_FIR_L;
-        if (o0 < cnt) {
-            float fo[DH_FIR_L];
-            dh_fir_lane<NZ, FAST>(tv, R.gain, R.rgain, R.inv_gain, S.xf, lane, fo);
-            float* dst = out + t0 + o0;
-            if (o0 + DH_FIR_L <= cnt) {
+        if ((uint32_t) lane * DH_FIR_L < cnt) dh_fir_lane<NZ, FAST>(tv, R.gain, R.rgain, R.inv_gain, S.xf, lane, DH_LA(fo, lane));
+    }
+    DH_BARRIER();                                       // every lane has read its window
+    DH_FOR_LANES(lane) {
+        if ((uint32_t) lane * DH_FIR_L < cnt) {
+            dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
 #pragma unroll
-                for (int q = 0; q < DH_FIR_L / 4; q++) {
-                    dh_f4 v; v.x = fo[4 * q]; v.y = fo[4 * q + 1]; v.z = fo[4 * q + 2]; v.w = fo[4 * q + 3];
-                    dh_store4_unaligned(dst + 4 * q, v);
-                }
-            } else {
+            for (int q = 0; q < DH_FIR_L / 4; q++) {
+                dh_f4a v; v.x = DH_LA(fo, lane)[4 * q]; v.y = DH_LA(fo, lane)[4 * q + 1];
+                v.z = DH_LA(fo, lane)[4 * q + 2]; v.w = DH_LA(fo, lane)[4 * q + 3];
+                dst[q] = v;
+            }
+        }
+    }
+    DH_BARRIER();
+    DH_FOR_LANES(lane) {
+        float* dst = out + t0;
 #pragma unroll
-                for (int j = 0; j < DH_FIR_L; j++) if (o0 + (uint32_t) j < cnt) dst[j] = fo[j];
+        for (int r = 0; r < DH_FTILE / (4 * DH_WAVE); r++) {
+            const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+            const dh_f4a v = *reinterpret_cast<const dh_f4a*>(S.xf + e);
+            if (e + 4u <= cnt) { dh_f4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; dh_store4_unaligned(dst + e, w); }
+            else {
+                if (e + 0u < cnt) dst[e + 0u] = v.x;
+                if (e + 1u < cnt) dst[e + 1u] = v.y;
+                if (e + 2u < cnt) dst[e + 2u] = v.z;
             }
         }
     }

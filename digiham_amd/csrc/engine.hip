@@ -31,6 +31,12 @@ int hip_fail(hipError_t e, const char* what) {
 }
 #define HIP_TRY(expr) do { if (hip_fail((expr), #expr)) return DH_EDEVICE; } while (0)
 
+#ifndef DH_TILE_LB
+#define DH_TILE_LB 3
+#endif
+#ifndef DH_TILES_PER_WG
+#define DH_TILES_PER_WG 4
+#endif
 #ifndef DH_LB
 #define DH_LB 3          // minimum waves per SIMD the wide-filter kernels are register-budgeted for
 #endif
@@ -62,10 +68,13 @@ __global__ __launch_bounds__(DH_WAVE, DH_LB) void k_chain(const DhDspParams P, c
 }
 
 template <int NZ, bool FAST>
-__global__ __launch_bounds__(DH_WAVE, ((NZ > 80 || FAST) ? 2 : DH_LB)) void k_rrc_tile(const DhRrcParams R) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_TILE_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared S = dh_dsp_carve(dh_smem, 0u);
-    dh_rrc_tile<NZ, FAST>(R, blockIdx.y, blockIdx.x, S);
+    // DH_TILES_PER_WG consecutive tiles of one channel per wavefront: fewer, longer-lived workgroups
+    const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
+    for (uint32_t t = blockIdx.x * DH_TILES_PER_WG; t < tiles && t < (blockIdx.x + 1u) * DH_TILES_PER_WG; t++)
+        dh_rrc_tile<NZ, FAST>(R, blockIdx.y, t, S);
 }
 
 __global__ __launch_bounds__(DH_WAVE) void k_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz) {
@@ -281,7 +290,7 @@ struct HipBackend {
     }
     template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
-        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3(tiles, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), stream, R);
+        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3((tiles + DH_TILES_PER_WG - 1) / DH_TILES_PER_WG, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), stream, R);
         return launched("k_rrc_tile");
     }
     int launch_rrc_tiles(const DhRrcParams& R, uint32_t nz, bool fast) {
