@@ -695,20 +695,43 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
     const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
     const uint32_t t0 = dh_trellis_out(p0, outbit), t1 = dh_trellis_out(p1, outbit);
     const int src0 = (g << 4) | (int) p0, src1 = src0 | 1;
-    const uint8_t* inrow = S.vit_in[g];
+    // branch metrics as byte tables indexed by the received dibit: byte v = popcount(v ^ t)
+    uint32_t tab0 = 0, tab1 = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < 4; v++) { tab0 |= (uint32_t) __popc(v ^ t0) << (8 * v); tab1 |= (uint32_t) __popc(v ^ t1) << (8 * v); }
+    // The uint8 path metric lives in the TOP byte of a register: adding (branch metric << 24) wraps exactly like the
+    // reference's uint8 arithmetic and unsigned compares see the same order, with no masking.
+    const uint32_t* inw = reinterpret_cast<const uint32_t*>(S.vit_in[g]);       // dibits 4 per byte, first in the MSBs
     uint32_t m = 0;
-    for (int pos = 0; pos < steps; pos++) {
-        const uint32_t in = ((uint32_t) inrow[pos >> 2] >> (2 * (3 - (pos & 3)))) & 3u;
-        const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
-        const uint32_t m0 = (a + (uint32_t) __popc(in ^ t0)) & 0xFFu;
-        const uint32_t m1 = (b + (uint32_t) __popc(in ^ t1)) & 0xFFu;
-        const bool active = pos < mysize;
-        const bool sel = active && (m1 < m0);
-        if (active) m = sel ? m1 : m0;
-        const uint64_t dec = __ballot(sel ? 1 : 0);
-        if (lane == 0) S.vit_dec[pos] = dec;
+    for (int blk = 0; blk * 64 < steps; blk++) {
+        // decisions of 64 steps collect in one register pair, step (64 blk + c) in lane c, written with v_writelane
+        uint32_t dlo = 0, dhi = 0;
+#pragma unroll
+        for (int wq = 0; wq < 4; wq++) {
+            const uint32_t w = inw[blk * 4 + wq];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = wq * 16 + q, pos = blk * 64 + c;
+                if (pos < steps) {
+                    const int sh = 8 * (q >> 2) + 6 - 2 * (q & 3);
+                    const uint32_t sel = ((w >> sh) & 3u) | 0x0C0C0C00u;                   // v_perm selector: byte `dibit`, zeros above
+                    const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
+                    const uint32_t m0 = a + (__builtin_amdgcn_perm(tab0, tab0, sel) << 24);
+                    const uint32_t m1 = b + (__builtin_amdgcn_perm(tab1, tab1, sel) << 24);
+                    const bool active = pos < mysize;
+                    const bool take1 = active && (m1 < m0);
+                    if (active) m = take1 ? m1 : m0;
+                    const uint64_t dec = __ballot(take1 ? 1 : 0);
+                    const uint32_t slo = (uint32_t) dec, shi = (uint32_t) (dec >> 32), sc = (uint32_t) c;
+                    uint32_t keep;
+                    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+                        : "+v"(dlo), "+v"(dhi), "=&s"(keep) : "s"(slo), "s"(shi), "s"(sc));
+                }
+            }
+        }
+        S.vit_dec[blk * 64 + lane] = (uint64_t) dhi << 32 | dlo;
     }
-    S.vit_metric[0][lane] = m;
+    S.vit_metric[0][lane] = m >> 24;
     __syncthreads();
     dh_viterbi_finish(S, sizes, 0);
 }
@@ -899,13 +922,13 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             uint32_t g[4];
             for (int i = 0; i < 4; i++) {
                 g[i] = (uint32_t) S.vit_out[0][i * 3] << 16 | (uint32_t) S.vit_out[0][i * 3 + 1] << 8 | S.vit_out[0][i * 3 + 2];
-                fresh &= dh_block_decode(T.g2412, P.T->lut_g2412, g[i]);
+                fresh &= dh_block_decode_wave<12>(T.g2412, P.T->lut_g2412, g[i]);
             }
             if (fresh) {
                 fich = (g[0] & 0x00FFF000u) << 8 | (g[1] & 0x00FFF000u) >> 4 | (g[2] & 0x00FF0000u) >> 16;
                 const uint32_t checksum = (g[2] & 0x0000F000u) | (g[3] & 0x00FFF000u) >> 12;
                 const uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };
-                fresh = dh_crc16(be, 4) == checksum;
+                fresh = dh_crc16_bytewise(be, 4) == checksum;
                 if (fresh) {
                     s[DS_FICH] = fich; s[DS_HAS_FICH] = 1;
                     dh_emit(c, DH_EV_YSF_FICH, 0, 0, be, 4);
@@ -946,9 +969,9 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                     if (fresh) {                                                    // decodeV2DataChannel (:258-269)
                         const uint8_t* w = S.vit_out[1];
                         const uint32_t checksum = (uint32_t) w[10] << 8 | w[11];
-                        if (dh_crc16(w, 10) == checksum) {
+                        if (dh_crc16_bytewise(w, 10) == checksum) {
                             uint8_t dch[13];
-                            dh_whiten(w, dch, 100);
+                            dh_whiten_packed(w, dch, 100);
                             dh_emit(c, DH_EV_YSF_DCH, (uint8_t) ((fich >> 19) & 7u), 0, dch, 10);
                         }
                     }
@@ -997,9 +1020,9 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 for (int half = 0; half < 2; half++) {
                     const uint8_t* w = S.vit_out[2 + half];
                     const uint32_t checksum = (uint32_t) w[20] << 8 | w[21];
-                    if (dh_crc16(w, 20) == checksum) {
+                    if (dh_crc16_bytewise(w, 20) == checksum) {
                         uint8_t dch[20];
-                        dh_whiten(w, dch, 160);
+                        dh_whiten_packed(w, dch, 160);
                         dh_emit(c, DH_EV_YSF_HEADER_DCH, (uint8_t) half, 0, dch, 20);
                     }
                 }

@@ -138,6 +138,56 @@ DH_HD void dh_whiten(const uint8_t* in, uint8_t* out, int n_bits) {
     }
 }
 
+// The same two functions for the frame decoders, where they run wave-uniformly on a path whose cost is its VALU
+// instruction count: CRC byte-wise through a compile-time table (the bit loop above costs ~4 instructions per BIT),
+// de-whitening as an XOR with the PN9 sequence packed at compile time (it is a constant: fixed seed, whitening.c:8).
+struct DhCrc16Table {
+    uint16_t t[256];
+    constexpr DhCrc16Table(): t() {
+        for (int b = 0; b < 256; b++) {
+            uint32_t crc = (uint32_t) b << 8;
+            for (int i = 0; i < 8; i++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) : (crc << 1);
+            t[b] = (uint16_t) crc;
+        }
+    }
+};
+struct DhPn9Bytes {
+    uint8_t b[24];                                    // 192 whitening bits, first bit in the MSB of b[0]
+    constexpr DhPn9Bytes(): b() {
+        uint32_t wsr = 0x1C9u;
+        for (int k = 0; k < 24; k++) {
+            uint32_t m = 0;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t wb = wsr & 1u, fb = ((wsr >> 4) & 1u) ^ wb;
+                wsr = ((wsr & 0x1FEu) >> 1) | (fb << 8);
+                m = (m << 1) | wb;
+            }
+            b[k] = (uint8_t) m;
+        }
+    }
+};
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+__device__ static constexpr DhCrc16Table dh_crc16_table{};
+__device__ static constexpr DhPn9Bytes dh_pn9_bytes{};
+#else
+static constexpr DhCrc16Table dh_crc16_table{};
+static constexpr DhPn9Bytes dh_pn9_bytes{};
+#endif
+
+DH_HD uint16_t dh_crc16_bytewise(const uint8_t* data, int count) {
+    uint32_t crc = 0;
+    for (int k = 0; k < count; k++) crc = ((crc << 8) & 0xFFFFu) ^ dh_crc16_table.t[((crc >> 8) ^ data[k]) & 0xFFu];
+    return (uint16_t) (~crc & 0xFFFFu);
+}
+
+DH_HD void dh_whiten_packed(const uint8_t* in, uint8_t* out, int n_bits) {     // n_bits <= 192
+    const int nbytes = (n_bits + 7) / 8;
+    for (int b = 0; b < nbytes; b++) {
+        const uint32_t keep = (b * 8 + 8 <= n_bits) ? 0xFFu : (0xFFu << (8 - (n_bits - b * 8))) & 0xFFu;
+        out[b] = (uint8_t) ((in[b] ^ dh_pn9_bytes.b[b]) & keep);
+    }
+}
+
 // rate-1/2 K=5 encoder output of the transition leaving `state` with input `bit`
 // (G1 = 1+D^3+D^4, G2 = 1+D+D^2+D^4; equals the table at src/ysf_decoder/trellis.c:8-25)
 DH_HD uint32_t dh_trellis_out(uint32_t state, uint32_t bit) {
