@@ -200,7 +200,7 @@ struct DhDecShared {
     uint8_t  vit_out[4][24];
     uint8_t  vit_best_metric[4];
 #ifdef DH_PHASE_CLOCKS
-    uint32_t clk[4];
+    uint32_t clk[8];
 #endif
 };
 
@@ -528,7 +528,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared
 
 DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 #ifdef DH_PHASE_CLOCKS
-    DH_FOR_LANES(lane) { if (lane < 4) S.clk[lane] = 0; }
+    DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
 #endif
     DH_DCLK_BEGIN();
     DhDecCtx c;
@@ -843,6 +843,10 @@ DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.c
 
 // One YSF channel, one push.
 DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+#ifdef DH_PHASE_CLOCKS
+    DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
+#endif
+    DH_DCLK_BEGIN();
     const DhFecTables& T = dh_lds_tables(S);
     DhDecCtx c;
     c.P = &P; c.T = &T;
@@ -888,8 +892,10 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         }
         // FramePhase (ysf_phase.cpp:41-172)
         if (!(avail > 480)) break;
+        DH_DCLK(0);
         dh_view_ensure(syms, pos, 512);
         dh_load_planes(syms, pos, total, pl, 8);
+        DH_DCLK(1);
         int sync_count = (int) s[DS_SYNC_COUNT];
         if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
         else if (--sync_count < 0) {
@@ -911,10 +917,12 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             }
         }
         DH_BARRIER();
+        DH_DCLK(2);
         {
             const int sizes1[4] = { 100, 100, 0, 0 };
             dh_viterbi_wave(S, sizes1);
         }
+        DH_DCLK(3);
 
         // FICH: 4 x Golay(24,12) + CRC16 (fich.cpp:24-49)
         uint32_t fich = 0; bool fresh = true;
@@ -936,6 +944,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             }
         }
 
+        DH_DCLK(4);
         if (s[DS_HAS_FICH]) {
             const uint32_t rf = s[DS_FICH];
             const uint32_t frame_type = (rf >> 30) & 3u, data_type = (rf >> 8) & 3u;
@@ -1032,6 +1041,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             }
         }
         DH_BARRIER();
+        DH_DCLK(5);
         pos += 480; c.consumed += 480;
         if (c.overflow) break;
     }
@@ -1049,6 +1059,9 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     }
     s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
     s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+#ifdef DH_PHASE_CLOCKS
+    for (int i = 0; i < 4; i++) s[28 + i] = (uint32_t) s[28 + i] + (dh_uniform(S.clk[2 * i]) >> 6) + ((dh_uniform(S.clk[2 * i + 1]) >> 6) << 16);
+#endif
     s.store(st_global);
     DH_BARRIER();
 }
