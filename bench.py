@@ -39,6 +39,9 @@ WORKLOADS = {
                  "rrc(wide) materialised + gfsk(10), float path (BASELINE configs[1])"),
     "dmr_fast": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=True),
                  "full DMR chain with the FMA FIR (float outputs 1e-6, dibits not guaranteed bit-exact)"),
+    # BASELINE configs[4] per GPU: half the channels DMR, half YSF, one engine (and one launch per push) each
+    "mixed": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
+              "half DMR + half YSF channels, full chains (BASELINE configs[4] per-GPU share)"),
 }
 
 
@@ -98,29 +101,43 @@ def main():
     ctx = api.Context(device=local)
     if args.split_stages:
         kw = dict(kw, split_stages=True)
+    mixed = args.workload == "mixed"
+    if mixed:
+        B = B // 2                          # this many DMR channels + as many YSF channels
+        x = x[:B].contiguous()
+        x2, info2 = synth_torch.make_batch(torch, device, "ysf", B, 40, seed=2000 + 7919 * rank)
+        T2 = info2["samples_per_channel"]
+        eng2 = api.Engine(B, T2, ctx=ctx, **dict(kw, proto="ysf"))
     eng = api.Engine(B, T, ctx=ctx, **kw)
     n_timed = args.steps
     eng.timing_enable(max(n_timed, 1))
 
-    for _ in range(args.warmup):
+    def step():
         eng.push(x)
+        if mixed:
+            eng2.push(x2)
+
+    for _ in range(args.warmup):
+        step()
     eng.sync()
     eng.timing_read()                       # drop warm-up timings
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.push(x)
+        step()
     torch.cuda.synchronize()
     shard.barrier()
     dt = time.perf_counter() - t0
     eng.sync()                              # raises on any output-buffer overflow
+    if mixed:
+        eng2.sync()
     rrc_ms, slicer_ms, dec_ms = eng.timing_read()
     frame_bytes_step = 0
     if kw["proto"] != "none":
         frame_bytes_step = int(eng.frames()[1].sum())          # decoder output of the last step, all channels
 
-    samples = float(B) * T * args.steps
+    samples = float(B) * T * args.steps + (float(B) * T2 * args.steps if mixed else 0.0)
     dt_max, samples_all = shard.reduce_report(dt, samples, device)
 
     # ---- parity spot check on the last step (outside the timed region)
@@ -156,7 +173,7 @@ def main():
         n_gpus = world
         # dominant kernel: fused RRC + slicer (k_rrc_demod); algorithmic bytes per launch =
         # input f32 (4 B/sample) + dibits out (1 B per 10 samples) -- SURVEY.md section 8(d)
-        alg_bytes = B * T * 4.0 + B * (T / 10.0)
+        alg_bytes = B * T * 4.0 + B * (T / 10.0)              # of ONE launch of the dominant kernel (mixed: the DMR engine's)
         if kw.get("keep_filtered"):
             # unfused config 2: the RRC kernel is dominant; 4 B in + 4 B out per sample
             dom_ms = float(np.mean(rrc_ms)) if len(rrc_ms) else float("nan")
@@ -171,14 +188,15 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         fir_flops = B * T * 162.0            # 81 mul + 81 add per sample, unfused
         line = {
-            "metric": "concurrent 48 kS/s DMR channels sustained end-to-end (rrc_filter->gfsk_demodulator->dmr_decoder)"
+            "metric": "concurrent 48 kS/s DMR+YSF channels sustained end-to-end" if mixed else
+                      "concurrent 48 kS/s DMR channels sustained end-to-end (rrc_filter->gfsk_demodulator->dmr_decoder)"
                       if proto == "dmr" else "concurrent 48 kS/s YSF channels sustained end-to-end",
             "value": rate / SAMPLE_RATE, "unit": "channels",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d %s channels/GPU x %.2f s (%d samples) of 48 kS/s FM-discriminator audio, %s"
-                                   % (B, proto.upper(), T / SAMPLE_RATE, T, desc),
+                                   % (2 * B if mixed else B, "DMR+YSF" if mixed else proto.upper(), T / SAMPLE_RATE, T, desc),
                        "channels_per_gpu": B, "samples_per_channel_per_step": T, "sharding": "channels, no collective"},
             "msamples_per_s": rate / 1e6,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -200,6 +218,8 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     eng.close()
+    if mixed:
+        eng2.close()
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         shard.barrier()
