@@ -25,7 +25,10 @@ enum {
     DS_PHASE = 0, DS_SYNC_COUNT = 1, DS_SLOT = 2, DS_SLOT_STABILITY = 3, DS_SYNC_TYPE0 = 4, DS_SYNC_TYPE1 = 5,
     DS_SLOT_SYNC0 = 6, DS_SLOT_SYNC1 = 7, DS_ACTIVE_SLOT = 8, DS_SLOT_FILTER = 9, DS_SUPERFRAME0 = 10,
     DS_SUPERFRAME1 = 11, DS_EMB_OFF0 = 12, DS_EMB_OFF1 = 13, DS_EMB_DATA0 = 14 /*4 words*/, DS_EMB_DATA1 = 18,
-    DS_CONSUMED = 22, DS_CARRY = 23, DS_SLOT_FILTER_DECODER = 24, DS_HAS_FICH = 25, DS_FICH = 26, DS_EXPECT_SUB = 27
+    DS_CONSUMED = 22, DS_CARRY = 23, DS_SLOT_FILTER_DECODER = 24, DS_HAS_FICH = 25, DS_FICH = 26, DS_EXPECT_SUB = 27,
+    // NXDN (Nxdn::FramedPhase, nxdn_phase.hpp:31-40): LICH + 1 (0 = none yet), collected SACCH fragments (bit i),
+    // their bytes 1..4 as big-endian words
+    DS_NX_LICH = 2, DS_NX_HAVE = 3, DS_NX_SACCH0 = 4
 };
 
 struct DhDecParams {
@@ -685,6 +688,7 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // gfx950 forward pass: path metrics stay in registers, the two predecessor metrics come through ds_bpermute
 // (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.
+template <bool NXDN = false>
 __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
     const int lane = (int) threadIdx.x, g = lane >> 4, i = lane & 15;
     int steps = 0;
@@ -719,7 +723,10 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
                     const uint32_t m0 = a + (__builtin_amdgcn_perm(tab0, tab0, sel) << 24);
                     const uint32_t m1 = b + (__builtin_amdgcn_perm(tab1, tab1, sel) << 24);
                     const bool active = pos < mysize;
-                    const bool take1 = active && (m1 < m0);
+                    // NXDN (trellis.cpp:35-60): for the first four steps a state that overlaps the shifting `blocked`
+                    // mask only looks at its k = 0 predecessor
+                    const bool both = !NXDN || pos >= 4 || ((uint32_t) i & ((0xFu << pos) & 0xFu)) == 0u;
+                    const bool take1 = active && both && (m1 < m0);
                     if (active) m = take1 ? m1 : m0;
                     const uint64_t dec = __ballot(take1 ? 1 : 0);
                     const uint32_t slo = (uint32_t) dec, shi = (uint32_t) (dec >> 32), sc = (uint32_t) c;
@@ -737,6 +744,7 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
 }
 #else
 // plain statement of the same recursion for the CPU harness: metrics exchanged through the LDS arrays
+template <bool NXDN = false>
 inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
     int steps = 0;
     for (int g = 0; g < 4; g++) steps = sizes[g] > steps ? sizes[g] : steps;
@@ -754,7 +762,8 @@ inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
                 const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
                 const uint32_t m0 = (S.vit_metric[cur][g * 16 + p0] + (uint32_t) dh_popc32(in ^ dh_trellis_out(p0, outbit))) & 0xFFu;
                 const uint32_t m1 = (S.vit_metric[cur][g * 16 + p1] + (uint32_t) dh_popc32(in ^ dh_trellis_out(p1, outbit))) & 0xFFu;
-                sel = m1 < m0;
+                const bool both = !NXDN || pos >= 4 || ((uint32_t) i & ((0xFu << pos) & 0xFu)) == 0u;     // trellis.cpp:35-60
+                sel = both && (m1 < m0);
                 nm = sel ? m1 : m0;
             }
             S.vit_metric[cur ^ 1][lane] = nm;
@@ -1062,6 +1071,260 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 #ifdef DH_PHASE_CLOCKS
     for (int i = 0; i < 4; i++) s[28 + i] = (uint32_t) s[28 + i] + (dh_uniform(S.clk[2 * i]) >> 6) + ((dh_uniform(S.clk[2 * i + 1]) >> 6) << 16);
 #endif
+    s.store(st_global);
+    DH_BARRIER();
+}
+
+// =============================================================================================
+// NXDN48 (reference: src/nxdn_decoder/nxdn_phase.cpp, lich.cpp, sacch.cpp,
+// facch1.cpp, scrambler.cpp, trellis.cpp)
+// =============================================================================================
+
+// the scrambler sequence of a frame is a constant: it restarts after every sync word (nxdn_phase.cpp:56) and runs
+// over LICH (8), SACCH (30) and the two 72-dibit blocks; bit j belongs to dibit 10 + j of the frame
+struct DhNxdnPn {
+    uint64_t w[3];
+    constexpr DhNxdnPn(): w() {
+        uint32_t sr = 0x0E4u;                                     // scrambler.cpp:9-11
+        for (int j = 0; j < 182; j++) {
+            const uint32_t wb = sr & 1u;
+            w[j >> 6] |= (uint64_t) wb << (j & 63);
+            const uint32_t fb = ((sr >> 4) & 1u) ^ wb;            // :21-23
+            sr = ((sr & 0x1FEu) >> 1) | (fb << 8);
+        }
+    }
+};
+DH_HD uint32_t dh_nxdn_pn(uint32_t j) {
+    constexpr DhNxdnPn pn{};
+    const uint64_t w = j < 64u ? pn.w[0] : j < 128u ? pn.w[1] : pn.w[2];
+    return (uint32_t) (w >> (j & 63u)) & 1u;
+}
+// descrambled dibit `k` of the frame body (k = 0 is the first LICH dibit, frame offset 10)
+DH_HD uint32_t dh_nxdn_dibit(const DhSymView& syms, uint32_t pos, uint32_t k) {
+    return (dh_view_at(syms, pos + 10u + k) & 3u) ^ (dh_nxdn_pn(k) << 1);
+}
+// bit `b` (0 = first) of a run of descrambled dibits starting at body dibit k0: high bit first
+DH_HD uint32_t dh_nxdn_bit(const DhSymView& syms, uint32_t pos, uint32_t k0, uint32_t b) {
+    return (dh_nxdn_dibit(syms, pos, k0 + (b >> 1)) >> (1u - (b & 1u))) & 1u;
+}
+
+constexpr uint32_t DH_NXDN_SYNC_H = dh_sync_plane(0xCDF59ull, 10, 1), DH_NXDN_SYNC_L = dh_sync_plane(0xCDF59ull, 10, 0);   // 3 0 3 1 3 3 1 1 2 1
+
+DH_HD bool dh_nxdn_is_sync_planes(const DhPlanes& p, int start) {   // nxdn_phase.cpp:21: <= 2 bit errors over 10 dibits
+    return dh_popc32(dh_plane_range(p.h, start, 10) ^ DH_NXDN_SYNC_H) + dh_popc32(dh_plane_range(p.l, start, 10) ^ DH_NXDN_SYNC_L) <= 2;
+}
+
+// sacch.cpp:70-84 / facch1.cpp:63-75 on wave-uniform bytes
+DH_HD bool dh_nxdn_crc_ok(const uint8_t* in, int nbits, int width, uint32_t init, uint32_t poly, uint32_t expect) {
+    uint32_t crc = init;
+    const uint32_t top = 1u << (width - 1), mask = ((1u << width) - 1u) & ~1u;
+    for (int i = 0; i < nbits; i++) {
+        const uint32_t cb = ((crc & top) ? 1u : 0u) ^ (((uint32_t) in[i >> 3] >> (7 - (i & 7))) & 1u);
+        if (cb) crc ^= poly;
+        crc = ((crc << 1) & mask) | cb;
+    }
+    return crc == expect;
+}
+
+// One NXDN channel, one push.
+DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+    DhDecCtx c;
+    c.P = &P; c.T = &dh_lds_tables(S);
+    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
+    DhState s; s.load(st_global);
+    c.st = &s;
+    c.out = P.out + (size_t) ch * P.out_stride;
+    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
+    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.consumed = s[DS_CONSUMED];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    c.writer = threadIdx.x == 0;
+#else
+    c.writer = true;
+#endif
+    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    const uint32_t total = syms.nc + syms.nfresh;
+    dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
+    uint32_t pos = 0, phase = s[DS_PHASE];
+
+    for (;;) {
+        const uint32_t avail = total - pos;
+        if (phase == 0) {                                          // SyncPhase (nxdn_phase.cpp:18-30): slide one dibit at a time
+            if (!(avail > 10)) break;
+            DhPlanes& pl = S.planes;
+            dh_view_ensure(syms, pos, 128);
+            dh_load_planes(syms, pos, total, pl, 2);
+            uint64_t hits = 0;
+            DH_FOR_LANES(lane) {
+                const bool valid = avail > (uint32_t) lane && avail - (uint32_t) lane > 10;
+                DH_BALLOT_ACC(hits, valid && dh_nxdn_is_sync_planes(pl, lane), lane);
+            }
+            if (hits) {
+                const uint32_t l = (uint32_t) dh_ffs64(hits);
+                pos += l; c.consumed += l; phase = 1;
+                s[DS_SYNC_COUNT] = 0; s[DS_NX_LICH] = 0; s[DS_NX_HAVE] = 0;      // FramedPhase::FramedPhase()
+                for (int i = 0; i < 4; i++) s[DS_NX_SACCH0 + i] = 0;
+            } else {
+                const uint32_t adv = dh_min<uint32_t>(64u, avail - 10u);
+                pos += adv; c.consumed += adv;
+            }
+            continue;
+        }
+        // FramedPhase::process (nxdn_phase.cpp:43-170)
+        if (!(avail > 192)) break;
+        dh_view_ensure(syms, pos, 256);
+        // one vote: lanes 0..9 bit 1 of the sync dibits, 10..19 their bit 0, 20..27 the descrambled LICH bits
+        uint64_t headvote = 0;
+        DH_FOR_LANES(lane) {
+            const uint32_t l = (uint32_t) lane;
+            bool b = false;
+            if (l < 10u) b = ((dh_view_at(syms, pos + l) >> 1) & 1u) != 0;
+            else if (l < 20u) b = (dh_view_at(syms, pos + l - 10u) & 1u) != 0;
+            else if (l < 28u) b = ((dh_nxdn_dibit(syms, pos, l - 20u) >> 1) & 1u) != 0;       // lich.cpp:10-12
+            DH_BALLOT_ACC(headvote, b, lane);
+        }
+        int sync_count = (int) s[DS_SYNC_COUNT];
+        const uint32_t sh = (uint32_t) headvote & 0x3FFu, sl = (uint32_t) (headvote >> 10) & 0x3FFu;
+        if (dh_popc32(sh ^ DH_NXDN_SYNC_H) + dh_popc32(sl ^ DH_NXDN_SYNC_L) <= 2) { if (++sync_count > 6) sync_count = 6; }
+        else if (--sync_count < 0) {
+            dh_emit(c, DH_EV_NXDN_META_RESET, 0, 0, nullptr, 0);
+            phase = 0; continue;
+        }
+        s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+        uint32_t used = 18;                                        // sync + LICH
+
+        // LICH: bit i of the vote = lich_bits[i]; parity over the first four (lich.cpp:14-24)
+        const uint32_t lb = (uint32_t) (headvote >> 20) & 0xFFu;
+        if ((uint32_t) (dh_popc32(lb & 0xFu) & 1) == ((lb >> 7) & 1u)) {
+            const uint32_t lich = dh_brev32(lb & 0x7Fu) >> 25;     // lich_bits[0] is the MSB
+            s[DS_NX_LICH] = lich + 1u;
+            const uint8_t b = (uint8_t) lich;
+            dh_emit(c, DH_EV_NXDN_LICH, 0, 0, &b, 1);
+        }
+        const uint32_t have_lich = s[DS_NX_LICH];
+        const uint32_t lich = have_lich - 1u;
+        if (have_lich != 0u && ((lich >> 5) & 3u) != 0u /* RCCH */ && ((lich >> 3) & 3u) != 1u /* UDCH */) {
+            const uint32_t option = (lich >> 1) & 3u;
+            const bool want_sacch = ((lich >> 3) & 3u) == 2u;      // SACCH superframe
+            const bool f0 = ((option >> 1) & 1u) == 0u, f1 = (option & 1u) == 0u;     // block i is a FACCH1
+            // Viterbi inputs: codeword 0 = SACCH (60 -> 72 bits), codewords 1 / 2 = the two FACCH1 blocks (144 -> 192 bits);
+            // every lane assembles one byte of an inflated codeword straight from the symbols
+            DH_FOR_LANES(lane) {
+                const int l = lane;
+                if (l < 9) {                                        // sacch.cpp:45-68
+                    uint32_t v = 0;
+                    for (int t = 0; t < 8; t++) {
+                        const int i = l * 8 + t;
+                        uint32_t x = 0;
+                        if ((i + 1) % 6 != 0) {
+                            const int o = i - (i + 1) / 6;          // position among the 60 transmitted bits
+                            const int inpos = (o % 12) * 5 + o / 12;
+                            x = dh_nxdn_bit(syms, pos, 8u, (uint32_t) inpos);
+                        }
+                        v = (v << 1) | x;
+                    }
+                    S.vit_in[0][l] = (uint8_t) v;
+                } else if (l >= 16 && l < 64) {                     // facch1.cpp:39-61
+                    const int blk = (l - 16) / 24, by = (l - 16) % 24;
+                    uint32_t v = 0;
+                    for (int t = 0; t < 8; t++) {
+                        const int i = by * 8 + t;
+                        uint32_t x = 0;
+                        if ((i - 1) % 4 != 0) {
+                            const int o = i - (i + 2) / 4;          // bits 1, 5, 9, ... are punctured
+                            const int inpos = (o % 16) * 9 + o / 16;
+                            x = dh_nxdn_bit(syms, pos, 38u + 72u * (uint32_t) blk, (uint32_t) inpos);
+                        }
+                        v = (v << 1) | x;
+                    }
+                    S.vit_in[1 + blk][by] = (uint8_t) v;
+                }
+            }
+            DH_BARRIER();
+            {
+                const int sizes[4] = { want_sacch ? 36 : 0, f0 ? 96 : 0, f1 ? 96 : 0, 0 };
+                if (want_sacch || f0 || f1) dh_viterbi_wave<true>(S, sizes);
+            }
+            if (want_sacch) {
+                const uint8_t* w = S.vit_out[0];
+                uint8_t sacch[5];
+                for (int i = 0; i < 5; i++) sacch[i] = (uint8_t) dh_uniform(w[i]);
+                if (dh_nxdn_crc_ok(sacch, 26, 6, 0x3Fu, 0x13u, sacch[3] & 0x3Fu)) {
+                    const uint32_t index = ((uint32_t) sacch[0] >> 6) ^ 3u;
+                    dh_emit(c, DH_EV_NXDN_SACCH, (uint8_t) index, 0, sacch, 5);
+                    uint32_t have = s[DS_NX_HAVE];
+                    if (!(index > 0u && !((have >> (index - 1u)) & 1u))) {        // SacchSuperframeCollector::push (sacch.cpp:90-98)
+                        have |= 1u << index;
+                        s[DS_NX_SACCH0 + index] = (uint32_t) sacch[1] << 24 | (uint32_t) sacch[2] << 16 | (uint32_t) sacch[3] << 8 | sacch[4];
+                    }
+                    if (have == 0xFu) {                                           // getSuperframe (:116-131): 4 x 18 bits
+                        uint8_t sf[9];
+                        uint64_t acc = 0; int nacc = 0, ob = 0;
+                        for (int i = 0; i < 4; i++) {
+                            acc = (acc << 18) | ((uint32_t) s[DS_NX_SACCH0 + i] >> 14); nacc += 18;
+                            while (nacc >= 8) { sf[ob++] = (uint8_t) (acc >> (nacc - 8)); nacc -= 8; }
+                        }
+                        dh_emit(c, DH_EV_NXDN_SACCH_SF, 0, 0, sf, 9);
+                        have = 0;
+                    }
+                    s[DS_NX_HAVE] = have;
+                }
+            }
+            used += 30;
+            bool released = false;
+            for (int i = 0; i < 2 && !released; i++) {
+                if ((option >> (1 - i)) & 1u) {                                   // voice (nxdn_phase.cpp:136-150)
+                    if (sync_count >= 1) {
+                        dh_emit(c, DH_EV_NXDN_SYNC_VOICE, 0, 0, nullptr, 0);
+                        if (P.out_cap - c.nout < 18) { c.overflow = true; break; }
+                        uint8_t* o = c.out + c.nout;
+                        DH_FOR_LANES(lane) {
+                            if (lane < 18) {
+                                uint32_t v = 0;
+                                for (int q = 0; q < 4; q++) v = (v << 2) | dh_nxdn_dibit(syms, pos, 38u + 72u * (uint32_t) i + 4u * (uint32_t) lane + (uint32_t) q);
+                                o[lane] = (uint8_t) v;
+                            }
+                        }
+                        c.nout += 18;
+                    }
+                } else {                                                          // FACCH1 (:151-165)
+                    const uint8_t* w = S.vit_out[1 + i];
+                    uint8_t f[12];
+                    for (int k = 0; k < 12; k++) f[k] = (uint8_t) dh_uniform(w[k]);
+                    if (dh_nxdn_crc_ok(f, 80, 12, 0xFFFu, 0x407u, (uint32_t) f[10] << 4 | (uint32_t) f[11] >> 4)) {
+                        dh_emit(c, DH_EV_NXDN_FACCH1, (uint8_t) i, 0, f, 12);
+                        if ((f[0] & 0x3Fu) == 0x08u) {                            // TX_RELEASE: back to SyncPhase, block not consumed
+                            dh_emit(c, DH_EV_NXDN_META_RESET, 0, 1, nullptr, 0);
+                            released = true;
+                            break;
+                        }
+                    }
+                }
+                used += 72;
+            }
+            DH_BARRIER();
+            if (released) phase = 0;
+        } else {
+            used += 174;
+        }
+        pos += used; c.consumed += used;
+        if (c.overflow) break;
+    }
+
+    const uint32_t rem = total - pos;
+    dh_view_ensure(syms, pos, rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX);
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
+        if (DH_IS_LANE0(lane)) {
+            P.out_count[ch] = c.nout;
+            if (P.ev_count) P.ev_count[ch] = c.nev;
+            if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
+        }
+    }
+    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+    s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
     s.store(st_global);
     DH_BARRIER();
 }

@@ -301,6 +301,106 @@ def ysf_stream(seed, n_frames, mode="vd2", lead_in=53):
     return np.array(out, np.uint8)
 
 
+# ----------------------------------------------------------------------------- NXDN48
+NXDN_SYNC = [3, 0, 3, 1, 3, 3, 1, 1, 2, 1]         # decoder: nxdn_phase.cpp:15-16
+
+
+def nxdn_scramble(dibits):
+    """decoder: scrambler.cpp:9-25 (its own inverse): PN output 1 flips the high bit of the dibit."""
+    sr = 0x0E4
+    out = []
+    for d in dibits:
+        wb = sr & 1
+        out.append((int(d) & 3) ^ (wb << 1))
+        wb = ((sr >> 4) & 1) ^ wb
+        sr = ((sr & 0x1FE) >> 1) | (wb << 8)
+    return out
+
+
+def nxdn_lich_dibits(lich7):
+    """7-bit LICH + parity over its 4 MSBs, one bit per dibit on the high bit (decoder: lich.cpp:5-31)."""
+    bits = _bits_of(lich7, 7)
+    bits.append(bits[0] ^ bits[1] ^ bits[2] ^ bits[3])
+    return [(b << 1) | 1 for b in bits]
+
+
+def _nxdn_crc(bits, width, init, poly):
+    """decoder: sacch.cpp:70-84 (CRC-6) / facch1.cpp:63-75 (CRC-12)."""
+    crc = init
+    mask = (1 << width) - 1
+    for b in bits:
+        cb = ((crc >> (width - 1)) & 1) ^ b
+        if cb:
+            crc ^= poly
+        crc = ((crc << 1) & (mask & ~1)) | cb
+    return _bits_of(crc, width)
+
+
+def _nxdn_channel_encode(info_bits, crc_bits, punct, rows, cols):
+    bits = list(info_bits) + list(crc_bits) + [0, 0, 0, 0]
+    coded = [b for d in trellis_encode_bits(bits) for b in ((d >> 1) & 1, d & 1)]
+    kept = [b for i, b in enumerate(coded) if not punct(i)]
+    tx = [0] * len(kept)
+    for i in range(rows):                       # decoder de-interleaves out[k * rows + i] = in[i * cols + k]
+        for k in range(cols):
+            tx[i * cols + k] = kept[k * rows + i]
+    return bits_to_dibits(tx)
+
+
+def nxdn_sacch_dibits(structure, ran, data18):
+    """One SACCH fragment: 2 bit structure (3 - index), 6 bit RAN, 18 data bits -> 30 dibits (decoder: sacch.cpp:24-84)."""
+    info = _bits_of(3 - structure, 2) + _bits_of(ran, 6) + list(data18)
+    return _nxdn_channel_encode(info, _nxdn_crc(info, 6, 0x3F, 0x13), lambda i: (i + 1) % 6 == 0, 12, 5)
+
+
+def nxdn_facch1_dibits(info80):
+    """80 information bits -> 72 dibits (decoder: facch1.cpp:8-75)."""
+    info = list(info80)
+    return _nxdn_channel_encode(info, _nxdn_crc(info, 12, 0xFFF, 0x407), lambda i: (i - 1) % 4 == 0, 16, 9)
+
+
+def nxdn_vcall_bits(call_type, src, dst):
+    """72 bits of a VCALL layer-3 message as the decoder reads them (sacch.cpp:133-152): message type 0x01 in the low
+    6 bits of byte 0, call type in the top 3 bits of byte 2, source in bytes 3-4, destination in bytes 5-6."""
+    msg = bytes([0x01, 0x00, (call_type & 7) << 5, (src >> 8) & 255, src & 255, (dst >> 8) & 255, dst & 255, 0, 0])
+    return bytes_to_bits(msg)
+
+
+def nxdn_frame(rng, lich7, sacch_dibits, blocks):
+    """sync + scrambled (LICH, SACCH, two 72-dibit blocks): 192 dibits (decoder: nxdn_phase.cpp:43-170)."""
+    body = nxdn_lich_dibits(lich7) + list(sacch_dibits) + list(blocks[0]) + list(blocks[1])
+    assert len(body) == 182
+    return NXDN_SYNC + nxdn_scramble(body)
+
+
+def nxdn_stream(seed, n_frames, lead_in=29, src=None, dst=None):
+    """Calls of voice frames (LICH: RDCH, SACCH superframe, both blocks voice) carrying a VCALL in the SACCH superframe,
+    opened by a frame whose blocks are FACCH1 (VCALL) and closed by one with TX_RELEASE, noise in between."""
+    rng = np.random.default_rng(seed)
+    out = list(rng.integers(0, 4, lead_in))
+    n = 0
+    while n < n_frames:
+        s = int(rng.integers(1, 65535)) if src is None else src
+        t = int(rng.integers(1, 65535)) if dst is None else dst
+        vcall = nxdn_vcall_bits(1 if s & 1 else 4, s, t)
+        ran = int(rng.integers(0, 64))
+        fa = nxdn_facch1_dibits(vcall + [0] * 8)
+        frames = [(0x50, 0, [fa, fa])]
+        for i in range(int(rng.integers(9, 17))):
+            voice = [list(rng.integers(0, 4, 72)), list(rng.integers(0, 4, 72))]
+            frames.append((0x56, i & 3, voice))
+        rel = nxdn_facch1_dibits(bytes_to_bits(bytes([0x08])) + [0] * 72)
+        frames.append((0x50, 0, [rel, rel]))
+        for lich, idx, blocks in frames:
+            if n >= n_frames:
+                break
+            sac = nxdn_sacch_dibits(idx, ran, vcall[18 * idx:18 * idx + 18])
+            out += nxdn_frame(rng, lich, sac, blocks)
+            n += 1
+        out += list(rng.integers(0, 4, int(rng.integers(15, 60))))
+    return np.array(out, np.uint8)
+
+
 # ----------------------------------------------------------------------------- waveform
 LEVELS = np.array([1.0, 3.0, -1.0, -3.0], np.float32) / 3.0      # dibit 0,1,2,3 (gfsk_demodulator.cpp:90-104)
 

@@ -95,7 +95,7 @@ typedef struct dh_engine dh_engine;
 
 enum { DH_RRC_NONE = 0, DH_RRC_WIDE = 1, DH_RRC_NARROW = 2 };
 enum { DH_DEMOD_NONE = 0, DH_DEMOD_FSK2 = 2, DH_DEMOD_GFSK4 = 4 };
-enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2 };
+enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3 };
 
 /* flags */
 #define DH_FLAG_FAST_FIR        0x1   /* FMA FIR: float outputs within 1e-6 of the reference, dibits NOT guaranteed bit-exact */
@@ -134,7 +134,11 @@ enum {
     DH_EV_DMR_SYNC = 1, DH_EV_DMR_SLOT_RESET = 2, DH_EV_DMR_META_RESET = 3, DH_EV_DMR_LC = 4,
     DH_EV_DMR_SOFT_RESET = 5, DH_EV_DMR_BPTC = 6, DH_EV_DMR_SLOTTYPE = 7, DH_EV_DMR_EMB = 8,
     DH_EV_YSF_FICH = 16, DH_EV_YSF_MODE = 17, DH_EV_YSF_DCH = 18, DH_EV_YSF_HEADER_DCH = 19,
-    DH_EV_YSF_META_RESET = 20
+    DH_EV_YSF_META_RESET = 20,
+    /* NXDN48 (src/nxdn_decoder/nxdn_phase.cpp): LICH byte; SACCH fragment (a = structure index, 5 bytes); complete SACCH
+     * superframe (9 bytes); setSync("voice"); FACCH1 (a = block, 12 bytes); MetaCollector::reset (b = 0 sync loss, 1 TX_RELEASE) */
+    DH_EV_NXDN_LICH = 32, DH_EV_NXDN_SACCH = 33, DH_EV_NXDN_SACCH_SF = 34, DH_EV_NXDN_SYNC_VOICE = 35,
+    DH_EV_NXDN_FACCH1 = 36, DH_EV_NXDN_META_RESET = 37
 };
 
 int  dh_engine_create(const dh_engine_config* cfg, dh_engine** out);

@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { PROTO_DMR = 1, PROTO_YSF = 2 };
+enum { PROTO_DMR = 1, PROTO_YSF = 2, PROTO_NXDN = 3 };
 enum { PH_SYNC = 0, PH_FRAME = 1 };
 
 /* ---- DMR constants: src/dmr_decoder/dmr_phase.hpp:6-12,25-33 */
@@ -63,6 +63,9 @@ struct orc_decoder {
     uint8_t slot_filter, superframe_counter[2];
     /* Ysf::FramePhase (ysf_phase.hpp:53-56) */
     int has_running_fich; uint32_t running_fich; int expect_sub_frame;
+    /* Nxdn::FramedPhase (nxdn_phase.hpp:31-40): syncCount shares sync_count; lich < 0 = nullptr;
+     * SacchSuperframeCollector (sacch.hpp:37-46): collected[i] != nullptr <=> bit i of sacch_have */
+    int lich; uint8_t sacch_have; uint8_t sacch_data[4][4];
 };
 
 static void emit(orc_decoder* d, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, uint8_t len) {
@@ -101,6 +104,12 @@ orc_decoder* orc_dmr_new(void) {
 orc_decoder* orc_ysf_new(void) {
     orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
     d->proto = PROTO_YSF; d->phase = PH_SYNC;
+    return d;
+}
+
+orc_decoder* orc_nxdn_new(void) {
+    orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
+    d->proto = PROTO_NXDN; d->phase = PH_SYNC; d->lich = -1;
     return d;
 }
 
@@ -490,6 +499,99 @@ static int ysf_frame(orc_decoder* d, const uint8_t* p) {
     return 0;
 }
 
+/* ================================================================== NXDN */
+/* nxdn_phase.hpp:12-15, nxdn_phase.cpp:15-16 */
+#define NXDN_SYNC_SIZE 10
+#define NXDN_FRAME_SIZE 192
+static const uint8_t nxdn_sync[NXDN_SYNC_SIZE] = { 3, 0, 3, 1, 3, 3, 1, 1, 2, 1 };
+/* lich.hpp:5-27, types.hpp:1-3 */
+enum { NXDN_RF_RCCH = 0, NXDN_USC_UDCH = 1, NXDN_USC_SACCH_SF = 2, NXDN_MSG_TX_RELEASE = 0x08, NXDN_MSG_IDLE = 0x10 };
+
+static void enter_nxdn_framed_phase(orc_decoder* d) {           /* FramedPhase::FramedPhase(), nxdn_phase.cpp:32-35 */
+    d->sync_count = 0; d->lich = -1; d->sacch_have = 0;
+    memset(d->sacch_data, 0, sizeof(d->sacch_data));
+}
+
+/* FramedPhase::process (nxdn_phase.cpp:43-170).  Returns the symbols consumed; *to_sync = 1 when the phase falls
+ * back to SyncPhase (sync lost: nothing consumed; TX_RELEASE: the FACCH1 block itself is not consumed, :155-159). */
+static size_t nxdn_frame(orc_decoder* d, const uint8_t* p, int* to_sync) {
+    *to_sync = 0;
+    if (orc_hamming_distance(p, nxdn_sync, NXDN_SYNC_SIZE) <= 2) {
+        if (++d->sync_count > 6) d->sync_count = 6;
+    } else if (--d->sync_count < 0) {
+        emit(d, ORC_EV_NXDN_META_RESET, 0, 0, NULL, 0);
+        *to_sync = 1;
+        return 0;
+    }
+    size_t pos = NXDN_SYNC_SIZE;
+    uint16_t sr = 0x0E4;                                        /* scrambler->reset(), scrambler.cpp:9-11 */
+    uint8_t lich_descrambled[8];
+    orc_nxdn_scramble(&sr, p + pos, lich_descrambled, 8);
+    pos += 8;
+    const int new_lich = orc_nxdn_lich_parse(lich_descrambled);
+    if (new_lich >= 0) {
+        d->lich = new_lich;
+        const uint8_t b = (uint8_t) new_lich;
+        emit(d, ORC_EV_NXDN_LICH, 0, 0, &b, 1);
+    }
+    if (d->lich >= 0 && ((d->lich >> 5) & 3) != NXDN_RF_RCCH && ((d->lich >> 3) & 3) != NXDN_USC_UDCH) {
+        uint8_t sacch_descrambled[30];
+        orc_nxdn_scramble(&sr, p + pos, sacch_descrambled, 30);
+        if (((d->lich >> 3) & 3) == NXDN_USC_SACCH_SF) {
+            uint8_t sacch[5];
+            if (orc_nxdn_sacch_parse(sacch_descrambled, sacch)) {
+                const int index = (sacch[0] >> 6) ^ 3;                       /* Sacch::getStructureIndex, sacch.cpp:16-18 */
+                emit(d, ORC_EV_NXDN_SACCH, (uint8_t) index, 0, sacch, 5);
+                /* SacchSuperframeCollector::push (sacch.cpp:90-98) */
+                if (!(index > 0 && !(d->sacch_have & (1u << (index - 1))))) {
+                    d->sacch_have |= (uint8_t) (1u << index);
+                    memcpy(d->sacch_data[index], sacch + 1, 4);
+                }
+                if (d->sacch_have == 0xF) {                                  /* isComplete + getSuperframe (:109-131) */
+                    uint8_t sf[9];
+                    memset(sf, 0, 9);
+                    for (int i = 0; i < 4; i++) for (int k = 0; k < 18; k++) {
+                        const int outpos = i * 18 + k;
+                        sf[outpos / 8] |= (uint8_t) (((d->sacch_data[i][k / 8] >> (7 - k % 8)) & 1u) << (7 - outpos % 8));
+                    }
+                    emit(d, ORC_EV_NXDN_SACCH_SF, 0, 0, sf, 9);
+                    d->sacch_have = 0;                                       /* sacchCollector->reset() */
+                }
+            }
+        }
+        pos += 30;
+        const unsigned option = (unsigned) (d->lich >> 1) & 3u;
+        for (int i = 0; i < 2; i++) {
+            uint8_t voice_descrambled[72];
+            orc_nxdn_scramble(&sr, p + pos, voice_descrambled, 72);
+            if ((option >> (1 - i)) & 1u) {
+                if (d->sync_count >= 1) {
+                    emit(d, ORC_EV_NXDN_SYNC_VOICE, 0, 0, NULL, 0);
+                    if (d->out_cap - d->out_n < 18) { d->overflow = 1; return pos; }
+                    uint8_t* o = d->out + d->out_n;
+                    memset(o, 0, 18);
+                    for (int k = 0; k < 72; k++) o[k / 4] |= (uint8_t) ((voice_descrambled[k] & 3u) << (6 - ((k % 4) * 2)));
+                    d->out_n += 18;
+                }
+            } else {
+                uint8_t facch1[12];
+                if (orc_nxdn_facch1_parse(voice_descrambled, facch1)) {
+                    emit(d, ORC_EV_NXDN_FACCH1, (uint8_t) i, 0, facch1, 12);
+                    if ((facch1[0] & 0x3F) == NXDN_MSG_TX_RELEASE) {
+                        emit(d, ORC_EV_NXDN_META_RESET, 0, 1, NULL, 0);
+                        *to_sync = 1;
+                        return pos;
+                    }
+                }
+            }
+            pos += 72;
+        }
+    } else {
+        pos += 174;
+    }
+    return pos;
+}
+
 /* ============================================ Digiham::Decoder main loop */
 /* `while (canProcess()) process()` with canProcess = available > required
  * (src/lib/decoder.cpp:21-32; cli.cpp:29-33) */
@@ -512,6 +614,19 @@ size_t orc_decoder_process(orc_decoder* d, const uint8_t* in, size_t n,
                 if (!(avail > DMR_FRAME_SIZE)) break;                        /* :61-63 */
                 if (dmr_frame(d, p)) d->phase = PH_SYNC;
                 else { pos += DMR_FRAME_SIZE; d->consumed += DMR_FRAME_SIZE; }
+            }
+        } else if (d->proto == PROTO_NXDN) {
+            if (d->phase == PH_SYNC) {
+                if (!(avail > NXDN_SYNC_SIZE)) break;                        /* nxdn_phase.hpp:23 */
+                if (orc_hamming_distance(p, nxdn_sync, NXDN_SYNC_SIZE) <= 2) {  /* nxdn_phase.cpp:18-30 */
+                    d->phase = PH_FRAME; enter_nxdn_framed_phase(d);
+                } else { pos++; d->consumed++; }
+            } else {
+                if (!(avail > NXDN_FRAME_SIZE)) break;                       /* nxdn_phase.hpp:33 */
+                int to_sync;
+                const size_t used = nxdn_frame(d, p, &to_sync);
+                pos += used; d->consumed += used;
+                if (to_sync) d->phase = PH_SYNC;
             }
         } else {
             if (d->phase == PH_SYNC) {

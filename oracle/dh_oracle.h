@@ -105,11 +105,25 @@ enum {
     ORC_EV_YSF_DCH         = 18, /* a=frame number payload=10 bytes                ysf_phase.cpp:258-269 */
     ORC_EV_YSF_HEADER_DCH  = 19, /* a=0 (CSD1) / 1 (CSD2) payload=20 bytes         ysf_phase.cpp:145,152 */
     ORC_EV_YSF_META_RESET  = 20, /* b=0 sync loss, 1 header, 2 terminator          ysf_phase.cpp:50,141,163 */
+    ORC_EV_NXDN_LICH       = 32, /* payload[0]=7-bit LICH (parity ok)                nxdn_phase.cpp:66-71 */
+    ORC_EV_NXDN_SACCH      = 33, /* a=structure index payload=5 bytes (CRC ok)       nxdn_phase.cpp:112-114 */
+    ORC_EV_NXDN_SACCH_SF   = 34, /* payload=9 bytes: a complete SACCH superframe     nxdn_phase.cpp:115-121 */
+    ORC_EV_NXDN_SYNC_VOICE = 35, /* MetaCollector::setSync("voice")                  nxdn_phase.cpp:141 */
+    ORC_EV_NXDN_FACCH1     = 36, /* a=block (0/1) payload=12 bytes (CRC ok)          nxdn_phase.cpp:152-154 */
+    ORC_EV_NXDN_META_RESET = 37, /* b=0 sync loss, 1 TX_RELEASE                      nxdn_phase.cpp:51,157 */
 };
+
+/* ----------------------------------------------------------------- nxdn.c */
+void orc_nxdn_scramble(uint16_t* shift_register, const uint8_t* input, uint8_t* output, size_t len);
+int orc_nxdn_lich_parse(const uint8_t* raw8);                       /* -1 or the 7-bit LICH */
+unsigned orc_nxdn_trellis_decode(const uint8_t* input, uint8_t* output, size_t len_bits);
+int orc_nxdn_sacch_parse(const uint8_t* dibits30, uint8_t* out5);
+int orc_nxdn_facch1_parse(const uint8_t* dibits72, uint8_t* out12);
 
 typedef struct orc_decoder orc_decoder;
 orc_decoder* orc_dmr_new(void);
 orc_decoder* orc_ysf_new(void);
+orc_decoder* orc_nxdn_new(void);
 void orc_decoder_free(orc_decoder*);
 void orc_dmr_set_slot_filter(orc_decoder*, uint8_t filter);
 /* streaming: consumes symbols from in[0..n); returns symbols consumed.  Output
@@ -128,7 +142,7 @@ typedef struct {
     int levels;     /* 4 gfsk, 2 fsk, 0 = no demod */
     int invert;
     unsigned sps;
-    int proto;      /* 0 none, 1 DMR, 2 YSF */
+    int proto;      /* 0 none, 1 DMR, 2 YSF, 3 NXDN */
     int slot_filter;
 } orc_chain_cfg;
 

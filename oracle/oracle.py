@@ -69,6 +69,13 @@ def _declare(L):
     L.orc_dvfilter_process.argtypes = [vp, vp, vp, C.c_size_t]
     L.orc_dmr_new.restype = vp
     L.orc_ysf_new.restype = vp
+    L.orc_nxdn_new.restype = vp
+    L.orc_nxdn_trellis_decode.restype = C.c_uint
+    L.orc_nxdn_trellis_decode.argtypes = [vp, vp, C.c_size_t]
+    L.orc_nxdn_scramble.argtypes = [vp, vp, vp, C.c_size_t]
+    L.orc_nxdn_lich_parse.argtypes = [vp]
+    L.orc_nxdn_sacch_parse.argtypes = [vp, vp]
+    L.orc_nxdn_facch1_parse.argtypes = [vp, vp]
     L.orc_decoder_free.argtypes = [vp]
     L.orc_dmr_set_slot_filter.argtypes = [vp, C.c_uint8]
     L.orc_decoder_process.restype = C.c_size_t
@@ -240,7 +247,7 @@ class Decoder:
     """Streaming Dmr::Decoder / Ysf::Decoder; returns (output bytes, events) per call."""
 
     def __init__(self, proto):
-        self._h = lib().orc_dmr_new() if proto == "dmr" else lib().orc_ysf_new()
+        self._h = {"dmr": lib().orc_dmr_new, "ysf": lib().orc_ysf_new, "nxdn": lib().orc_nxdn_new}[proto]()
         self._tail = np.zeros(0, np.uint8)
 
     def set_slot_filter(self, f):
@@ -292,3 +299,65 @@ def chain(x, rrc=1, levels=4, invert=False, sps=10, proto=1, slot_filter=3, thre
         raise RuntimeError("orc_chain_run failed: %d" % rc)
     return {"filtered": filt, "syms": syms, "sym_count": sym_count, "out": out, "out_count": out_count,
             "events": ev, "event_count": ev_count}
+
+
+# ------------------------------------------------------------------ NXDN frame elements
+_REF_NXDN = None
+
+
+def ref_nxdn():
+    """oracle/_ref/libdigiham_ref_nxdn.so: the reference's own scrambler / LICH / SACCH / FACCH1 / trellis classes."""
+    global _REF_NXDN
+    if _REF_NXDN is None:
+        so = os.path.join(_HERE, "_ref", "libdigiham_ref_nxdn.so")
+        if not os.path.exists(so):
+            return None
+        L = C.CDLL(so)
+        vp = C.c_void_p
+        L.ref_nxdn_scramble.argtypes = [vp, vp, C.c_size_t]
+        L.ref_nxdn_lich_parse.argtypes = [vp]
+        L.ref_nxdn_trellis_decode.restype = C.c_uint
+        L.ref_nxdn_trellis_decode.argtypes = [vp, vp, C.c_size_t]
+        L.ref_nxdn_sacch_parse.argtypes = [vp, vp]
+        L.ref_nxdn_facch1_parse.argtypes = [vp, vp]
+        _REF_NXDN = L
+    return _REF_NXDN
+
+
+def nxdn_scramble(dibits, which="oracle"):
+    """Scrambler from its reset state over a run of dibits (scrambler.cpp:9-25)."""
+    d = np.ascontiguousarray(dibits, np.uint8)
+    out = np.zeros_like(d)
+    if which == "ref":
+        ref_nxdn().ref_nxdn_scramble(_p(d), _p(out), d.size)
+    else:
+        sr = C.c_uint16(0x0E4)
+        lib().orc_nxdn_scramble(C.byref(sr), _p(d), _p(out), d.size)
+    return out
+
+
+def nxdn_lich(dibits8, which="oracle"):
+    d = np.ascontiguousarray(dibits8, np.uint8)
+    return (ref_nxdn().ref_nxdn_lich_parse if which == "ref" else lib().orc_nxdn_lich_parse)(_p(d))
+
+
+def nxdn_trellis(packed, len_bits, which="oracle"):
+    d = np.ascontiguousarray(packed, np.uint8)
+    out = np.zeros((len_bits + 15) // 16, np.uint8)
+    fn = ref_nxdn().ref_nxdn_trellis_decode if which == "ref" else lib().orc_nxdn_trellis_decode
+    metric = fn(_p(d), _p(out), len_bits)
+    return out, int(metric)
+
+
+def nxdn_sacch(dibits30, which="oracle"):
+    d = np.ascontiguousarray(dibits30, np.uint8)
+    out = np.zeros(5, np.uint8)
+    ok = (ref_nxdn().ref_nxdn_sacch_parse if which == "ref" else lib().orc_nxdn_sacch_parse)(_p(d), _p(out))
+    return bool(ok), out
+
+
+def nxdn_facch1(dibits72, which="oracle"):
+    d = np.ascontiguousarray(dibits72, np.uint8)
+    out = np.zeros(12, np.uint8)
+    ok = (ref_nxdn().ref_nxdn_facch1_parse if which == "ref" else lib().orc_nxdn_facch1_parse)(_p(d), _p(out))
+    return bool(ok), out
