@@ -15,6 +15,7 @@
 #include "engine_handle.hpp"
 #include "dmr_meta.hpp"
 #include "ysf_meta.hpp"
+#include "nxdn_meta.hpp"
 
 #define BUF_SIZE 128
 #define RINGBUFFER_SIZE 1024
@@ -55,7 +56,9 @@ namespace Digiham {
             // takes ownership of the writer, as the reference does (src/lib/decoder.cpp:34-40)
             void setMetaWriter(MetaWriter* meta) {
                 std::lock_guard<std::mutex> lock(processMutex);
-                if (!metaCollector) metaCollector = proto == DH_PROTO_DMR ? (MetaCollector*) new Dmr::MetaCollector() : (MetaCollector*) new Ysf::MetaCollector();
+                if (!metaCollector) metaCollector = proto == DH_PROTO_DMR ? (MetaCollector*) new Dmr::MetaCollector()
+                                                  : proto == DH_PROTO_YSF ? (MetaCollector*) new Ysf::MetaCollector()
+                                                  : (MetaCollector*) new Nxdn::MetaCollector();
                 metaCollector->setWriter(meta);
             }
             void setEventCallback(std::function<void(const dh_event&)> cb) { onEvent = std::move(cb); }
@@ -71,7 +74,8 @@ namespace Digiham {
             unsigned char slotFilter = 3;
         private:
             static constexpr size_t chunk = 16384;
-            // a call may emit one voice payload per 144-symbol burst (DMR, 27 bytes) or 95 bytes per 480-symbol frame (YSF)
+            // a call may emit one voice payload per 144-symbol burst (DMR, 27 bytes), 95 bytes per 480-symbol frame (YSF)
+            // or 36 bytes per 192-symbol frame (NXDN): 27 / 144 is the densest
             static constexpr size_t maxOutputPerCall = (chunk + 512) / 144 * 27 + 128;
             int proto;
             void* dSyms = nullptr;
@@ -100,6 +104,15 @@ namespace Digiham {
         class Decoder: public Digiham::Decoder {
             public:
                 Decoder(): Digiham::Decoder(DH_PROTO_YSF) {}
+        };
+
+    }
+
+    namespace Nxdn {
+
+        class Decoder: public Digiham::Decoder {          // include/nxdn_decoder.hpp:9-14
+            public:
+                Decoder(): Digiham::Decoder(DH_PROTO_NXDN) {}
         };
 
     }

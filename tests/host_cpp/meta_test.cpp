@@ -8,11 +8,14 @@
 
 #include "digiham/dmr_meta.hpp"
 #include "digiham/ysf_meta.hpp"
+#include "digiham/nxdn_meta.hpp"
 
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
-    Digiham::MetaCollector* c = std::string(argv[1]) == "dmr" ? (Digiham::MetaCollector*) new Digiham::Dmr::MetaCollector()
-                                                              : (Digiham::MetaCollector*) new Digiham::Ysf::MetaCollector();
+    const std::string proto = argv[1];
+    Digiham::MetaCollector* c = proto == "dmr" ? (Digiham::MetaCollector*) new Digiham::Dmr::MetaCollector()
+                              : proto == "ysf" ? (Digiham::MetaCollector*) new Digiham::Ysf::MetaCollector()
+                              : (Digiham::MetaCollector*) new Digiham::Nxdn::MetaCollector();
     c->setWriter(new Digiham::FileMetaWriter(fdopen(1, "w")));
     uint32_t n;
     while (fread(&n, sizeof(n), 1, stdin) == 1) {

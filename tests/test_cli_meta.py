@@ -15,7 +15,7 @@ import pytest
 from digiham_amd import api, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOLS = ["rrc_filter", "gfsk_demodulator", "fsk_demodulator", "digitalvoice_filter", "dmr_decoder", "ysf_decoder"]
+TOOLS = ["rrc_filter", "gfsk_demodulator", "fsk_demodulator", "digitalvoice_filter", "dmr_decoder", "ysf_decoder", "nxdn_decoder"]
 
 
 def _ev(type_, a=0, b=0, payload=b""):
@@ -74,6 +74,20 @@ def test_ysf_meta_lines(tmp_path):
     ]
 
 
+def test_nxdn_meta_lines(tmp_path):
+    exe = _meta_test(tmp_path)
+    vcall = bytes([0x01, 0x00, 0x20, 0x12, 0x34, 0x00, 0x63, 0, 0])         # conference call 0x1234 -> 99
+    evs = [[_ev(35), _ev(35), _ev(34, 0, 0, vcall)], [_ev(34, 0, 0, vcall), _ev(37, 0, 1)]]
+    got = subprocess.run([exe, "nxdn"], input=_batches(evs), capture_output=True, check=True).stdout.decode().splitlines()
+    assert got == [
+        "protocol:NXDN;sync:voice",
+        "protocol:NXDN;sync:voice;type:conference",
+        "protocol:NXDN;source:4660;sync:voice;type:conference",
+        "destination:99;protocol:NXDN;source:4660;sync:voice;type:conference",
+        "protocol:NXDN",
+    ]
+
+
 def _build_tools(tmp_path, gpu):
     if gpu:
         subprocess.run(["make", "-C", os.path.join(ROOT, "cli"), "-s"], check=True)
@@ -90,18 +104,24 @@ def _build_tools(tmp_path, gpu):
 
 
 @pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
-@pytest.mark.parametrize("proto", ["dmr", "ysf"])
+@pytest.mark.parametrize("proto", ["dmr", "ysf", "nxdn"])
 def test_cli_pipe_like_the_example_scripts(oracle, tmp_path, proto, gpu):
     """examples/dmr-decoder.sh:19-23 / ysf-decoder.sh: rrc_filter | gfsk_demodulator | <proto>_decoder --fifo <meta>."""
     bindir = _build_tools(tmp_path, gpu)
-    s = synth.dmr_stream(73, 30, two_slots=False) if proto == "dmr" else synth.ysf_stream(71, 8)
-    x = synth.impair(synth.shape(s), 7, snr_db=24, dc=0.02, delay=3)
+    if proto == "nxdn":                                                   # examples/nxdn48-decoder.sh:19-23
+        from digiham_amd import _taps
+        s = synth.nxdn_stream(75, 16, src=4660, dst=99)
+        x = synth.impair(synth.shape(s, sps=20, taps=_taps.narrow()), 7, snr_db=24, dc=0.02, delay=3)
+    else:
+        s = synth.dmr_stream(73, 30, two_slots=False) if proto == "dmr" else synth.ysf_stream(71, 8)
+        x = synth.impair(synth.shape(s), 7, snr_db=24, dc=0.02, delay=3)
     inp, meta, out = tmp_path / "in.f32", tmp_path / "meta.txt", tmp_path / "out.bin"
     x.astype(np.float32).tofile(inp)
-    cmd = "%s/rrc_filter < %s | %s/gfsk_demodulator | %s/%s_decoder --fifo %s > %s" % (bindir, inp, bindir, bindir, proto, meta, out)
+    opts = ("-n", "-s 20") if proto == "nxdn" else ("", "")
+    cmd = "%s/rrc_filter %s < %s | %s/gfsk_demodulator %s | %s/%s_decoder --fifo %s > %s" % (bindir, opts[0], inp, bindir, opts[1], bindir, proto, meta, out)
     subprocess.run(["bash", "-o", "pipefail", "-c", cmd], check=True, stderr=subprocess.DEVNULL)
     # reference output for the same dibits: the tools consume their whole input, the oracle stops sps+1 samples early
-    ref = oracle.chain(x[None, :], proto=1 if proto == "dmr" else 2)
+    ref = oracle.chain(x[None, :], proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
     got = np.fromfile(out, np.uint8)
     want = ref["out"][0, :ref["out_count"][0]]
     assert len(want) > 0 and len(got) >= len(want) and (got[:len(want)] == want).all()
@@ -114,8 +134,10 @@ def test_cli_pipe_like_the_example_scripts(oracle, tmp_path, proto, gpu):
         lc = api.parse_lc(bytes(lcs[0]["payload"][:9]))
         assert any("source:%d;" % lc["source"] in l and "target:%d;type:group" % lc["target"] in l and "slot:%d" % lcs[0]["a"] in l
                    for l in lines), lines
-    else:
+    elif proto == "ysf":
         assert any("mode:DN;protocol:YSF" in l for l in lines), lines
+    else:
+        assert "destination:99;protocol:NXDN;source:4660;sync:voice;type:individual" in lines, lines
 
 
 def test_cli_tools_fail_loudly_without_a_device():
