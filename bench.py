@@ -39,10 +39,17 @@ WORKLOADS = {
                  "rrc(wide) materialised + gfsk(10), float path (BASELINE configs[1])"),
     "dmr_fast": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=True),
                  "full DMR chain with the FMA FIR (float outputs 1e-6, dibits not guaranteed bit-exact)"),
+    # narrow RRC -> gfsk -s 20 -> nxdn_decoder (examples/nxdn48-decoder.sh)
+    "nxdn_full": ("nxdn", dict(rrc="narrow", demod="gfsk", sps=20, proto="nxdn"),
+                  "full chain rrc(narrow)->gfsk(20)->nxdn_decoder (NXDN48)"),
     # BASELINE configs[4] per GPU: half the channels DMR, half YSF, one engine (and one launch per push) each
     "mixed": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
               "half DMR + half YSF channels, full chains (BASELINE configs[4] per-GPU share)"),
 }
+
+
+def oracle_kw(proto):
+    return dict(proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
 
 
 def cpu_baseline(x_host_fn, proto, budget_s=12.0):
@@ -52,14 +59,14 @@ def cpu_baseline(x_host_fn, proto, budget_s=12.0):
     probe = x_host_fn(1)
     n = probe.shape[1]
     t0 = time.perf_counter()
-    O.chain(probe[:, : min(n, 96000)], proto=1 if proto == "dmr" else 2, threads=1)
+    O.chain(probe[:, : min(n, 96000)], threads=1, **oracle_kw(proto))
     per_sample = (time.perf_counter() - t0) / min(n, 96000)
     # size the sample for ~budget_s of wall time with every core busy
     chans = max(cores, int(budget_s / (per_sample * n) * cores))
     chans = min(chans, 16384)
     x = x_host_fn(chans)
     t0 = time.perf_counter()
-    O.chain(x, proto=1 if proto == "dmr" else 2, threads=cores)
+    O.chain(x, threads=cores, **oracle_kw(proto))
     dt = time.perf_counter() - t0
     rate = x.size / dt
     return {"value": rate / SAMPLE_RATE, "unit": "channels", "msamples_per_s": rate / 1e6,
@@ -95,8 +102,8 @@ def main():
 
     proto, kw, desc = WORKLOADS[args.workload]
     B = args.channels
-    units = args.units or (132 if proto == "dmr" else 40)
-    x, info = synth_torch.make_batch(torch, device, proto, B, units, seed=1000 + 7919 * rank)
+    units = args.units or {"dmr": 132, "ysf": 40, "nxdn": 50}[proto]
+    x, info = synth_torch.make_batch(torch, device, proto, B, units, seed=1000 + 7919 * rank, sps=kw["sps"])
     T = info["samples_per_channel"]
     ctx = api.Context(device=local)
     if args.split_stages:
@@ -157,7 +164,7 @@ def main():
             for b in range(nv):
                 got_s[b].append(s[b, :sc[b]].copy()); got_f[b].append(f[b, :fc[b]].copy())
         xh = np.tile(xs.cpu().numpy(), (1, reps))
-        ref = O.chain(xh, proto=1 if proto == "dmr" else 2, threads=min(nv, os.cpu_count() or 1))
+        ref = O.chain(xh, threads=min(nv, os.cpu_count() or 1), **oracle_kw(proto))
         ok = True
         for b in range(nv):
             gs, gf = np.concatenate(got_s[b]), np.concatenate(got_f[b])
@@ -186,11 +193,12 @@ def main():
             if chained:
                 alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        fir_flops = B * T * 162.0            # 81 mul + 81 add per sample, unfused
+        taps = {"wide": 81, "narrow": 161}[kw["rrc"]]
+        fir_flops = B * T * 2.0 * taps       # one mul + one add per tap and sample, unfused
         line = {
             "metric": "concurrent 48 kS/s DMR+YSF channels sustained end-to-end" if mixed else
                       "concurrent 48 kS/s DMR channels sustained end-to-end (rrc_filter->gfsk_demodulator->dmr_decoder)"
-                      if proto == "dmr" else "concurrent 48 kS/s YSF channels sustained end-to-end",
+                      if proto == "dmr" else "concurrent 48 kS/s %s channels sustained end-to-end" % proto.upper(),
             "value": rate / SAMPLE_RATE, "unit": "channels",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -202,7 +210,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "co_limit": {"what": "fp32 VALU (81-tap FIR, unfused mul+add for bit-exactness)",
+                         "co_limit": {"what": "fp32 VALU (%d-tap FIR, unfused mul+add for bit-exactness)" % taps,
                                       "achieved_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops": 157.3}},
             "stage_ms": {"rrc": float(np.mean(rrc_ms)) if len(rrc_ms) else None,
                          "slicer": float(np.mean(slicer_ms)) if len(slicer_ms) else None,

@@ -16,6 +16,8 @@ def periodic_streams(proto, n_units, U, seed=1000):
     for u in range(U):
         if proto == "dmr":
             s = synth.dmr_stream(seed + u, n_units, two_slots=(u % 2 == 0), lead_in=0)
+        elif proto == "nxdn":
+            s = synth.nxdn_stream(seed + u, n_units, lead_in=0)
         else:
             s = synth.ysf_stream(seed + u, n_units, mode="vd2", lead_in=0)
         out.append(s)
@@ -33,7 +35,7 @@ def make_batch(torch, device, proto, B, n_units, U=64, seed=1000, sps=10, amplit
     lv = torch.tensor(synth.LEVELS, device=device)[torch.from_numpy(syms.astype(np.int64)).to(device)]      # [U][S]
     imp = torch.zeros((U, T), dtype=torch.float32, device=device)
     imp[:, ::sps] = lv
-    g = _taps.wide().astype(np.float64)
+    g = (_taps.narrow() if proto == "nxdn" else _taps.wide()).astype(np.float64)
     g = (g / g.sum() * sps).astype(np.float32)
     gp = torch.zeros(T, dtype=torch.float32, device=device)
     gp[:len(g)] = torch.from_numpy(g).to(device)
@@ -43,7 +45,7 @@ def make_batch(torch, device, proto, B, n_units, U=64, seed=1000, sps=10, amplit
     x = torch.empty((B, T), dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    burst = 144 * sps if proto == "dmr" else 480 * sps
+    burst = {"dmr": 144, "ysf": 480, "nxdn": 192}[proto] * sps
     for c0 in range(0, B, chunk):
         c1 = min(B, c0 + chunk)
         for ch in range(c0, c1):
