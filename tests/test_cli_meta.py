@@ -74,6 +74,28 @@ def test_ysf_meta_lines(tmp_path):
     ]
 
 
+def test_ysf_gps_from_the_data_frames(tmp_path):
+    """V/D2 data frames 6 and 7 carry DT1 / DT2; a short-GPS command gives lat / lon (data.cpp:72-87, gps.cpp:5-82)."""
+    exe = _meta_test(tmp_path)
+    dt = bytearray(20)
+    dt[1:4] = bytes([0x22, 0x62, 0x5F])                                   # COMMAND_SHORT_GPS
+    dt[4] = 0x28
+    dt[5:14] = bytes([0x34, 0x38, 0x31, 0x52, 0x33, 0x34, 0x27, 0x30, 0x4E])
+    dt[18] = 0x03
+    dt[19] = sum(dt[:19]) & 0xFF
+    f = np.float32
+    lat = f(f(f(f(f(48) + f(1) / f(6)) + f(2) / f(60)) + f(3) / f(600)) + f(4) / f(6000))
+    lon = f(f(f(11) + f(20) / f(60)) + f(50) / f(6000))
+    evs = [[_ev(17, 0, 2), _ev(18, 6, 0, bytes(dt[:10])), _ev(18, 7, 0, bytes(dt[10:]))], [_ev(18, 0, 0, b"CQCQCQ    ")], [_ev(20, 0, 2)]]
+    got = subprocess.run([exe, "ysf"], input=_batches(evs), capture_output=True, check=True).stdout.decode().splitlines()
+    assert got == [
+        "mode:DN;protocol:YSF",
+        "lat:%f;lon:%f;mode:DN;protocol:YSF" % (lat, lon),
+        "lat:%f;lon:%f;mode:DN;protocol:YSF;target:CQCQCQ" % (lat, lon),
+        "protocol:YSF",
+    ]
+
+
 def test_nxdn_meta_lines(tmp_path):
     exe = _meta_test(tmp_path)
     vcall = bytes([0x01, 0x00, 0x20, 0x12, 0x34, 0x00, 0x63, 0, 0])         # conference call 0x1234 -> 99
