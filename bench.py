@@ -48,6 +48,24 @@ WORKLOADS = {
 }
 
 
+def profiled_traffic(workload, channels, T):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    KiB, per-dispatch average; MI355X_MICROARCH.md) -- bench.py cannot collect counters itself.  Only for the
+    configuration those passes were run on (tools/profile_gpu.sh: the default workload)."""
+    path = os.path.join(ROOT, "profiles", "r01_h_chain_pmc.txt")
+    if workload != "dmr_full" or channels != 16384 or T != 190080 or not os.path.exists(path):
+        return None, None
+    fetch = write = None
+    for line in open(path):
+        if "k_chain" in line and " FETCH_SIZE " in line:
+            fetch = float(line.split("avg=")[1].split()[0])
+        if "k_chain" in line and " WRITE_SIZE " in line:
+            write = float(line.split("avg=")[1].split()[0])
+    if fetch is None or write is None:
+        return None, None
+    return fetch * 2.0 * 1024.0 + write * 1024.0, "profiles/r01_h_chain_pmc.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)"
+
+
 def oracle_kw(proto):
     return dict(proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
 
@@ -193,6 +211,7 @@ def main():
             if chained:
                 alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_src = profiled_traffic(args.workload, B, T) if dom_name == "k_chain" else (None, None)
         taps = {"wide": 81, "narrow": 161}[kw["rrc"]]
         fir_flops = B * T * 2.0 * taps       # one mul + one add per tap and sample, unfused
         line = {
@@ -208,7 +227,7 @@ def main():
                        "channels_per_gpu": B, "samples_per_channel_per_step": T, "sharding": "channels, no collective"},
             "msamples_per_s": rate / 1e6,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "co_limit": {"what": "fp32 VALU (%d-tap FIR, unfused mul+add for bit-exactness)" % taps,
                                       "achieved_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops": 157.3}},
