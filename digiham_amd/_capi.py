@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdigiham_amd.so")
 DH_OK, DH_EINVAL, DH_ENOMEM, DH_EDEVICE, DH_ENODEV, DH_ECAPACITY = 0, -1, -2, -3, -4, -5
 RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2}
 DEMOD = {"none": 0, None: 0, "fsk": 2, "fsk2": 2, "gfsk": 4, "gfsk4": 4}
-PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3}
+PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3, "pocsag": 4}
 FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED_TIMING, FLAG_SPLIT_STAGES = 1, 2, 4, 8, 16, 32
 
 
@@ -41,7 +41,7 @@ def declare(L, lenient=False):
         "dh_copy_to_host": [vp, vp, sz], "dh_copy_to_device": [vp, vp, sz],
         "dh_hamming_7_4": [vp, vp, sz, vp], "dh_hamming_13_9": [vp, vp, sz, vp], "dh_hamming_15_11": [vp, vp, sz, vp],
         "dh_hamming_16_11": [vp, vp, sz, vp], "dh_quadratic_residue": [vp, vp, sz, vp],
-        "dh_golay_20_8": [vp, vp, sz, vp], "dh_golay_24_12": [vp, vp, sz, vp],
+        "dh_golay_20_8": [vp, vp, sz, vp], "dh_golay_24_12": [vp, vp, sz, vp], "dh_bch_31_21": [vp, vp, sz, vp],
         "dh_bptc_196_96": [vp, vp, vp, sz, vp],
         "dh_trellis": [vp, sz, C.c_int, vp, sz, vp, sz, vp],
         "dh_crc16": [vp, sz, C.c_int, vp, sz, vp],
@@ -78,7 +78,7 @@ def declare(L, lenient=False):
 EXPORTED_SYMBOLS = [
     "dh_version", "dh_last_error", "dh_device_count", "dh_device_alloc", "dh_device_free", "dh_copy_to_host",
     "dh_copy_to_device", "dh_hamming_7_4", "dh_hamming_13_9", "dh_hamming_15_11", "dh_hamming_16_11",
-    "dh_quadratic_residue", "dh_golay_20_8", "dh_golay_24_12", "dh_bptc_196_96", "dh_trellis", "dh_crc16",
+    "dh_quadratic_residue", "dh_golay_20_8", "dh_golay_24_12", "dh_bch_31_21", "dh_bptc_196_96", "dh_trellis", "dh_crc16",
     "dh_whitening", "dh_dvfilter_s16", "dh_debug_div_gain", "dh_engine_create", "dh_engine_destroy", "dh_engine_reset",
     "dh_engine_set_slot_filter", "dh_engine_push", "dh_engine_push_host", "dh_engine_push_symbols",
     "dh_engine_filtered", "dh_engine_symbols", "dh_engine_frames", "dh_engine_events", "dh_engine_read_symbols",

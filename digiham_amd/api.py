@@ -16,7 +16,7 @@ EVENT_DTYPE = np.dtype([("sym_index", "<u4"), ("type", "u1"), ("a", "u1"), ("b",
                         ("payload", "u1", (24,))])
 
 _CODES = {"hamming_7_4": np.uint8, "hamming_13_9": np.uint16, "hamming_15_11": np.uint16,
-          "hamming_16_11": np.uint16, "quadratic_residue": np.uint16, "golay_20_8": np.uint32, "golay_24_12": np.uint32}
+          "hamming_16_11": np.uint16, "quadratic_residue": np.uint16, "golay_20_8": np.uint32, "golay_24_12": np.uint32, "bch_31_21": np.uint32}
 
 
 class TorchCudaMemory:

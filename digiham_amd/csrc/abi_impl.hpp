@@ -22,7 +22,7 @@ static_assert(sizeof(dh_event) == 32, "dh_event layout");
 
 struct dh_engine { dh::Engine<DH_BACKEND> impl; };
 
-enum { DH_CODE_H74 = 0, DH_CODE_H139, DH_CODE_H1511, DH_CODE_H1611, DH_CODE_QR, DH_CODE_G208, DH_CODE_G2412 };
+enum { DH_CODE_H74 = 0, DH_CODE_H139, DH_CODE_H1511, DH_CODE_H1611, DH_CODE_QR, DH_CODE_G208, DH_CODE_G2412, DH_CODE_BCH3121 };
 
 extern "C" {
 
@@ -42,6 +42,7 @@ int dh_hamming_16_11(uint16_t* w, uint8_t* ok, size_t n, void* s) { return dh_be
 int dh_quadratic_residue(uint16_t* w, uint8_t* ok, size_t n, void* s) { return dh_be_fec_block(DH_CODE_QR, w, ok, n, s); }
 int dh_golay_20_8(uint32_t* w, uint8_t* ok, size_t n, void* s) { return dh_be_fec_block(DH_CODE_G208, w, ok, n, s); }
 int dh_golay_24_12(uint32_t* w, uint8_t* ok, size_t n, void* s) { return dh_be_fec_block(DH_CODE_G2412, w, ok, n, s); }
+int dh_bch_31_21(uint32_t* w, uint8_t* ok, size_t n, void* s) { return dh_be_fec_block(DH_CODE_BCH3121, w, ok, n, s); }
 int dh_bptc_196_96(const uint8_t* in, uint8_t* out, uint8_t* ok, size_t n, void* s) {
     if ((!in || !out || !ok) && n) return DH_EINVAL;
     return dh_be_bptc(in, out, ok, n, s);

@@ -19,7 +19,7 @@
 #include "../../include/digiham_amd.h"     // dh_event, DH_EV_*
 
 #define DH_SYM_CARRY_MAX 512          // symbols a decoder may leave unread between pushes (<= 480)
-#define DH_DEC_STATE_WORDS 32
+#define DH_DEC_STATE_WORDS 64
 
 enum {
     DS_PHASE = 0, DS_SYNC_COUNT = 1, DS_SLOT = 2, DS_SLOT_STABILITY = 3, DS_SYNC_TYPE0 = 4, DS_SYNC_TYPE1 = 5,
@@ -28,7 +28,10 @@ enum {
     DS_CONSUMED = 22, DS_CARRY = 23, DS_SLOT_FILTER_DECODER = 24, DS_HAS_FICH = 25, DS_FICH = 26, DS_EXPECT_SUB = 27,
     // NXDN (Nxdn::FramedPhase, nxdn_phase.hpp:31-40): LICH + 1 (0 = none yet), collected SACCH fragments (bit i),
     // their bytes 1..4 as big-endian words
-    DS_NX_LICH = 2, DS_NX_HAVE = 3, DS_NX_SACCH0 = 4
+    DS_NX_LICH = 2, DS_NX_HAVE = 3, DS_NX_SACCH0 = 4,
+    // POCSAG (Pocsag::CodewordPhase, pocsag_phase.hpp:27-36, and its Message, message.hpp:11-23): codeword counter,
+    // message present, address, type, bit / char position, 80 content bytes (little-endian words)
+    DS_PC_COUNTER = 2, DS_PC_HAS = 3, DS_PC_ADDR = 4, DS_PC_TYPE = 5, DS_PC_POS = 6, DS_PC_CONTENT = 32
 };
 
 struct DhDecParams {
@@ -1310,6 +1313,193 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             used += 174;
         }
         pos += used; c.consumed += used;
+        if (c.overflow) break;
+    }
+
+    const uint32_t rem = total - pos;
+    dh_view_ensure(syms, pos, rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX);
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
+        if (DH_IS_LANE0(lane)) {
+            P.out_count[ch] = c.nout;
+            if (P.ev_count) P.ev_count[ch] = c.nev;
+            if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
+        }
+    }
+    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+    s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+    s.store(st_global);
+    DH_BARRIER();
+}
+
+// =============================================================================================
+// POCSAG (reference: src/pocsag_decoder/pocsag_phase.cpp, codeword.cpp, message.cpp, bch_31_21.c;
+// examples/pocsag-decoder.sh: fsk_demodulator -i -s 40 | pocsag_decoder).  Input symbols are bits.
+// =============================================================================================
+#define DH_POCSAG_SYNC 0x7CD215D8u          // pocsag_phase.hpp:15, first bit in the MSB
+#define DH_POCSAG_IDLE 0x7A89C197u          // codeword.hpp:23
+
+// the 32 symbols at `pos`, one per lane: `word` has symbol 0 in its MSB with any non-zero symbol as 1 (codeword.cpp:12:
+// `input[i] && 1`); `dist` is hamming_distance() against the sync word (bit 0 differs, or bit 1 is set)
+DH_HD void dh_pocsag_take32(const DhSymView& syms, uint32_t pos, uint32_t& word, int& dist) {
+    uint64_t nz = 0, b0 = 0, b1 = 0;
+    DH_FOR_LANES(lane) {
+        uint32_t v = 0;
+        if (lane < 32) v = dh_view_at(syms, pos + (uint32_t) lane);
+        DH_BALLOT_ACC(nz, v != 0u, lane);
+        DH_BALLOT_ACC(b0, (v & 1u) != 0u, lane);
+        DH_BALLOT_ACC(b1, (v & 2u) != 0u, lane);
+    }
+    word = dh_brev32((uint32_t) nz);
+    dist = dh_popc32(dh_brev32((uint32_t) b0) ^ DH_POCSAG_SYNC) + dh_popc32((uint32_t) b1);
+}
+
+// Message::serialize with the StringSerializer (message.cpp:17-25, meta.cpp:8-17): `address:<n>;message:<text>\n`
+DH_HD void dh_pocsag_serialize(DhDecCtx& c, DhState& s, DhDecShared& S) {
+    if (!s[DS_PC_HAS] || (uint32_t) s[DS_PC_POS] == 0u) return;
+    uint8_t* line = &S.vit_in[0][0];                      // 192 bytes of scratch, unused by this protocol
+    uint32_t n = 0;
+    const char* a = "address:";
+    for (int i = 0; i < 8; i++) line[n++] = (uint8_t) a[i];
+    char num[12]; int nn = 0; uint32_t v = s[DS_PC_ADDR];
+    do { num[nn++] = (char) ('0' + v % 10u); v /= 10u; } while (v);
+    while (nn) line[n++] = (uint8_t) num[--nn];
+    const char* m = ";message:";
+    for (int i = 0; i < 9; i++) line[n++] = (uint8_t) m[i];
+    for (uint32_t i = 0; i < 80u; i++) {
+        const uint32_t ch = ((uint32_t) s[DS_PC_CONTENT + (i >> 2)] >> (8u * (i & 3u))) & 0xFFu;
+        if (ch == 0u) break;                              // std::string(content) ends at the first NUL
+        line[n++] = (uint8_t) ch;
+    }
+    line[n++] = (uint8_t) '\n';
+    if (c.P->out_cap - c.nout < n) { c.overflow = true; return; }
+    DH_BARRIER();
+    uint8_t* o = c.out + c.nout;
+    DH_FOR_LANES(lane) { for (uint32_t j = (uint32_t) lane; j < n; j += DH_WAVE) o[j] = line[j]; }
+    DH_BARRIER();
+    c.nout += n;
+}
+
+// Message::append (message.cpp:27-72)
+DH_HD void dh_pocsag_append(DhState& s, uint32_t data) {
+    const uint32_t type = s[DS_PC_TYPE];
+    uint32_t pos = s[DS_PC_POS];
+    if (type == 3u) {
+        if (pos + 20u < 80u * 7u) {
+            for (int i = 0; i < 20; i++) {
+                const uint32_t bit = (data >> (19 - i)) & 1u, ch = pos / 7u;
+                s[DS_PC_CONTENT + (ch >> 2)] = (uint32_t) s[DS_PC_CONTENT + (ch >> 2)] | (bit << (pos % 7u)) << (8u * (ch & 3u));
+                pos++;
+            }
+        }
+    } else if (type == 0u) {
+        if (pos + 5u < 80u) {
+            for (int i = 0; i < 5; i++) {
+                uint32_t ch = 0;
+                const uint32_t base = (uint32_t) (4 - i) * 4u;
+                for (int k = 0; k < 4; k++) ch |= ((data >> (base + (uint32_t) k)) & 1u) << (3 - k);
+                const char tail[6] = { '*', 'U', ' ', '-', ')', '(' };
+                ch = ch < 0xAu ? '0' + ch : (uint32_t) tail[ch - 0xAu];
+                s[DS_PC_CONTENT + (pos >> 2)] = (uint32_t) s[DS_PC_CONTENT + (pos >> 2)] | ch << (8u * (pos & 3u));
+                pos++;
+            }
+        }
+    }
+    s[DS_PC_POS] = pos;
+}
+
+DH_HD void dh_pocsag_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+    DhDecCtx c;
+    c.P = &P; c.T = &dh_lds_tables(S);
+    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
+    DhState s; s.load(st_global);
+    c.st = &s;
+    c.out = P.out + (size_t) ch * P.out_stride;
+    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
+    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.consumed = s[DS_CONSUMED];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    c.writer = threadIdx.x == 0;
+#else
+    c.writer = true;
+#endif
+    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    const uint32_t total = syms.nc + syms.nfresh;
+    dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
+    uint32_t pos = 0, phase = s[DS_PHASE];
+
+    for (;;) {
+        const uint32_t avail = total - pos;
+        if (!(avail > 32)) break;                                  // both phases need 32 bits (pocsag_phase.cpp:14,34)
+        if (phase == 0) {                                          // SyncPhase (:18-28): slide bit by bit
+            DhPlanes& pl = S.planes;
+            dh_view_ensure(syms, pos, 128);
+            dh_load_planes(syms, pos, total, pl, 2);
+            uint64_t hits = 0;
+            DH_FOR_LANES(lane) {
+                const bool valid = avail > (uint32_t) lane && avail - (uint32_t) lane > 32;
+                const uint32_t l = dh_plane_range(pl.l, lane, 32), h = dh_plane_range(pl.h, lane, 32);
+                DH_BALLOT_ACC(hits, valid && dh_popc32(dh_brev32(l) ^ DH_POCSAG_SYNC) + dh_popc32(h) <= 3, lane);
+            }
+            if (hits) {
+                const uint32_t l = (uint32_t) dh_ffs64(hits);
+                pos += l + 32u; c.consumed += l + 32u; phase = 1;
+                s[DS_SYNC_COUNT] = 1; s[DS_PC_COUNTER] = 0; s[DS_PC_HAS] = 0;         // CodewordPhase members (pocsag_phase.hpp:31-34)
+            } else {
+                const uint32_t adv = dh_min<uint32_t>(64u, avail - 32u);
+                pos += adv; c.consumed += adv;
+            }
+            continue;
+        }
+        // CodewordPhase::process (pocsag_phase.cpp:38-92)
+        dh_view_ensure(syms, pos, 64);
+        uint32_t word; int dist;
+        dh_pocsag_take32(syms, pos, word, dist);
+        uint32_t counter = s[DS_PC_COUNTER];
+        if (counter >= 16u) {
+            int sync_count = (int) s[DS_SYNC_COUNT];
+            if (dist <= 3) { if (sync_count++ > 2) sync_count = 2; }
+            else if (sync_count-- < 0) {
+                dh_pocsag_serialize(c, s, S);
+                s[DS_PC_HAS] = 0;
+                phase = 0;
+                continue;
+            }
+            s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+            s[DS_PC_COUNTER] = 0;
+        } else {
+            // Codeword::parse (codeword.cpp:9-32)
+            uint32_t payload = word >> 1;
+            bool ok = dh_block_decode_wave<10>(c.T->bch3121, P.T->lut_bch3121, payload);
+            const uint32_t cw = (word & 1u) | (payload << 1);
+            if (ok && (dh_popc32(cw) & 1)) ok = false;
+            if (ok) {
+                const uint8_t be[4] = { (uint8_t) (cw >> 24), (uint8_t) (cw >> 16), (uint8_t) (cw >> 8), (uint8_t) cw };
+                dh_emit(c, DH_EV_POCSAG_CODEWORD, (uint8_t) counter, 0, be, 4);
+                if (cw == DH_POCSAG_IDLE) {
+                    dh_pocsag_serialize(c, s, S);
+                    s[DS_PC_HAS] = 0;
+                } else if ((cw >> 31) == 0u) {                     // address codeword
+                    dh_pocsag_serialize(c, s, S);
+                    s[DS_PC_HAS] = 0;
+                    const uint32_t type = (cw >> 11) & 3u;
+                    if (type == 1u || type == 3u) {
+                        s[DS_PC_HAS] = 1;
+                        s[DS_PC_ADDR] = (((cw >> 13) & 0x3FFFFu) << 3) | (counter / 2u);
+                        s[DS_PC_TYPE] = type; s[DS_PC_POS] = 0;
+                        for (int i = 0; i < 20; i++) s[DS_PC_CONTENT + i] = 0;
+                    }
+                } else if (s[DS_PC_HAS]) {
+                    dh_pocsag_append(s, (cw >> 11) & 0xFFFFFu);
+                }
+            } else {
+                s[DS_PC_HAS] = 0;
+            }
+            s[DS_PC_COUNTER] = counter + 1u;
+        }
+        pos += 32u; c.consumed += 32u;
         if (c.overflow) break;
     }
 

@@ -42,7 +42,7 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     if (c.n_channels == 0 || c.max_samples == 0) return DH_EINVAL;
     if (c.rrc < DH_RRC_NONE || c.rrc > DH_RRC_NARROW) return DH_EINVAL;
     if (c.demod != DH_DEMOD_NONE && c.demod != DH_DEMOD_FSK2 && c.demod != DH_DEMOD_GFSK4) return DH_EINVAL;
-    if (c.proto < DH_PROTO_NONE || c.proto > DH_PROTO_NXDN) return DH_EINVAL;
+    if (c.proto < DH_PROTO_NONE || c.proto > DH_PROTO_POCSAG) return DH_EINVAL;
     if (c.demod != DH_DEMOD_NONE && (c.sps < 3 || c.sps > DH_MAX_SPS)) return DH_EINVAL;
     if (c.demod == DH_DEMOD_NONE && c.rrc == DH_RRC_NONE && c.proto == DH_PROTO_NONE) return DH_EINVAL;
     L.B = c.n_channels; L.max_samples = c.max_samples; L.sps = c.demod ? c.sps : 1;
@@ -60,6 +60,7 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     if (L.proto == DH_PROTO_DMR) { L.out_cap = (max_syms / 144 + 1) * 27; L.ev_cap = (max_syms / 144 + 1) * 4 + 8; }
     else if (L.proto == DH_PROTO_YSF) { L.out_cap = (max_syms / 480 + 1) * 95; L.ev_cap = (max_syms / 480 + 1) * 5 + 8; }
     else if (L.proto == DH_PROTO_NXDN) { L.out_cap = (max_syms / 192 + 1) * 36; L.ev_cap = (max_syms / 192 + 1) * 7 + 8; }
+    else if (L.proto == DH_PROTO_POCSAG) { L.out_cap = max_syms / 2 + 256; L.ev_cap = max_syms / 32 + 8; }
     else { L.out_cap = 0; L.ev_cap = 0; }
     L.out_cap = round_up(L.out_cap, 64);
     return DH_OK;

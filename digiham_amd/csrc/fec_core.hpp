@@ -18,7 +18,7 @@ struct DhCode {
 };
 
 struct DhFecTables {
-    DhCode h74, h139, h1511, h1611, qr, g208, g2412;
+    DhCode h74, h139, h1511, h1611, qr, g208, g2412, bch3121;
     uint8_t  lut_h74[8];
     uint16_t lut_h139[16];
     uint16_t lut_h1511[16];
@@ -26,6 +26,7 @@ struct DhFecTables {
     uint16_t lut_qr[512];
     uint32_t lut_g208[4096];
     uint32_t lut_g2412[4096];
+    uint32_t lut_bch3121[1024];
 };
 
 // syndrome in the reference's bit order: first parity-check row ends up in the MSB

@@ -46,6 +46,20 @@ inline void build_lut(const DhCode& c, int t, LutT* lut, int lut_size) {
     }
 }
 
+// cyclic code from its generator polynomial: parity-check row `row`, bit j = coefficient (r-1-row) of x^j mod g
+// (BCH(31,21): g = x^10+x^9+x^8+x^6+x^5+x^3+1, CCIR 584; gives the rows listed at src/pocsag_decoder/bch_31_21.c:3-14)
+inline void build_cyclic_code(DhCode& c, int n, int k, uint32_t gen) {
+    c.n = n; c.k = k;
+    const int r = n - k;
+    for (int row = 0; row < 12; row++) c.h[row] = 0;
+    uint32_t rem = 1;
+    for (int j = 0; j < n; j++) {
+        for (int row = 0; row < r; row++) if ((rem >> (r - 1 - row)) & 1u) c.h[row] |= 1u << j;
+        rem <<= 1;
+        if (rem & (1u << r)) rem ^= gen;
+    }
+}
+
 inline void build_fec_tables(DhFecTables& T) {
     static const uint16_t P_H74[4] = { 0x5, 0x7, 0x6, 0x3 };
     static const uint16_t P_H139[9] = { 0xF, 0xE, 0x7, 0xA, 0x5, 0xB, 0xC, 0x6, 0x3 };
@@ -67,6 +81,8 @@ inline void build_fec_tables(DhFecTables& T) {
     build_lut(T.qr, 2, T.lut_qr, 512);
     build_lut(T.g208, 3, T.lut_g208, 4096);
     build_lut(T.g2412, 3, T.lut_g2412, 4096);
+    build_cyclic_code(T.bch3121, 31, 21, 0x769u);
+    build_lut(T.bch3121, 2, T.lut_bch3121, 1024);
 }
 
 }  // namespace dh

@@ -61,6 +61,7 @@ DH_HD void dh_fec_block_item(const DhFecTables& T, int code, void* words, uint8_
         case 4: { uint32_t w = ((uint16_t*) words)[i]; r = dh_block_decode(T.qr, T.lut_qr, w); ((uint16_t*) words)[i] = (uint16_t) w; break; }
         case 5: { uint32_t w = ((uint32_t*) words)[i]; r = dh_block_decode(T.g208, T.lut_g208, w); ((uint32_t*) words)[i] = w; break; }
         case 6: { uint32_t w = ((uint32_t*) words)[i]; r = dh_block_decode(T.g2412, T.lut_g2412, w); ((uint32_t*) words)[i] = w; break; }
+        case 7: { uint32_t w = ((uint32_t*) words)[i]; r = dh_block_decode(T.bch3121, T.lut_bch3121, w); ((uint32_t*) words)[i] = w; break; }
     }
     ok[i] = r ? 1 : 0;
 }

@@ -401,6 +401,86 @@ def nxdn_stream(seed, n_frames, lead_in=29, src=None, dst=None):
     return np.array(out, np.uint8)
 
 
+# ----------------------------------------------------------------------------- POCSAG
+POCSAG_SYNC = 0x7CD215D8          # decoder: pocsag_phase.hpp:15
+POCSAG_IDLE = 0x7A89C197          # decoder: codeword.hpp:23
+
+
+def bch_31_21_encode(data21):
+    """Systematic BCH(31,21), generator x^10+x^9+x^8+x^6+x^5+x^3+1 (decoder: bch_31_21.c:3-14)."""
+    w = (data21 & 0x1FFFFF) << 10
+    r = w
+    for j in range(30, 9, -1):
+        if r & (1 << j):
+            r ^= 0x769 << (j - 10)
+    return w | (r & 0x3FF)
+
+
+def pocsag_codeword(data21):
+    """21 information bits -> 32-bit codeword with even parity (decoder: codeword.cpp:9-32)."""
+    w = bch_31_21_encode(data21) << 1
+    return w | (bin(w).count("1") & 1)
+
+
+def pocsag_alpha_payloads(text):
+    """7-bit characters, LSB first, cut into 20-bit message payloads (decoder: message.cpp:29-38)."""
+    bits = [(ord(c) >> k) & 1 for c in text for k in range(7)]
+    bits += [0] * (-len(bits) % 20)
+    return [int("".join(map(str, bits[i:i + 20])), 2) for i in range(0, len(bits), 20)]
+
+
+def pocsag_batches(messages):
+    """messages: list of (address 21 bit, function, text).  Returns the codewords of as many batches as needed; every
+    message starts in the frame its address selects (address & 7), idle codewords fill the rest."""
+    words = []
+    for address, function, text in messages:
+        frame = address & 7
+        while (len(words) % 16) // 2 != frame or len(words) % 2:
+            words.append(POCSAG_IDLE)
+        words.append(pocsag_codeword(((address >> 3) & 0x3FFFF) << 2 | (function & 3)))
+        for pl in pocsag_alpha_payloads(text):
+            words.append(pocsag_codeword(1 << 20 | pl))
+        words.append(POCSAG_IDLE)
+    words += [POCSAG_IDLE] * (-len(words) % 16)
+    return words
+
+
+def pocsag_stream(seed, n_messages, lead_in=37):
+    """Transmissions of preamble + batches carrying random alphanumeric pages, noise bits in between."""
+    rng = np.random.default_rng(seed)
+    out = list(rng.integers(0, 2, lead_in))
+    sent = []
+    n = 0
+    while n < n_messages:
+        msgs = []
+        for _ in range(int(rng.integers(1, 4))):
+            if n >= n_messages:
+                break
+            text = "".join(chr(int(c)) for c in rng.integers(32, 127, int(rng.integers(3, 40))))
+            msgs.append((int(rng.integers(8, 1 << 21)), 3, text))
+            n += 1
+        sent += msgs
+        words = pocsag_batches(msgs)
+        bits = [1, 0] * 288
+        for i in range(0, len(words), 16):
+            for w in [POCSAG_SYNC] + words[i:i + 16]:
+                bits += _bits_of(w, 32)
+        # the decoder keeps its batch grid for three more batches after a transmission ends (pocsag_phase.cpp:40-52), so a
+        # transmission that follows sooner is missed: mostly long gaps, sometimes a short one
+        gap = int(rng.integers(1750, 1900)) if rng.random() < 0.8 else int(rng.integers(40, 600))
+        out += bits + list(rng.integers(0, 2, gap))
+    return np.array(out, np.uint8), sent
+
+
+def fsk_shape(bits, sps=40, amplitude=0.4, invert=False):
+    """Two-level FSK discriminator audio: bit 1 above the centre (below with `invert`, as POCSAG is received:
+    examples/pocsag-decoder.sh, fsk_demodulator -i), lightly low-passed edges."""
+    lv = np.where(np.asarray(bits) > 0, 1.0, -1.0) * (-1.0 if invert else 1.0)
+    x = np.repeat(lv, sps)
+    k = np.ones(max(sps // 8, 1)) / max(sps // 8, 1)
+    return (amplitude * np.convolve(x, k, mode="same")).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------- waveform
 LEVELS = np.array([1.0, 3.0, -1.0, -3.0], np.float32) / 3.0      # dibit 0,1,2,3 (gfsk_demodulator.cpp:90-104)
 

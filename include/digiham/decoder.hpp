@@ -56,6 +56,7 @@ namespace Digiham {
             // takes ownership of the writer, as the reference does (src/lib/decoder.cpp:34-40)
             void setMetaWriter(MetaWriter* meta) {
                 std::lock_guard<std::mutex> lock(processMutex);
+                if (proto == DH_PROTO_POCSAG) { delete meta; return; }        // no collector: the writer is released (decoder.cpp:34-38)
                 if (!metaCollector) metaCollector = proto == DH_PROTO_DMR ? (MetaCollector*) new Dmr::MetaCollector()
                                                   : proto == DH_PROTO_YSF ? (MetaCollector*) new Ysf::MetaCollector()
                                                   : (MetaCollector*) new Nxdn::MetaCollector();
@@ -75,8 +76,8 @@ namespace Digiham {
         private:
             static constexpr size_t chunk = 16384;
             // a call may emit one voice payload per 144-symbol burst (DMR, 27 bytes), 95 bytes per 480-symbol frame (YSF)
-            // or 36 bytes per 192-symbol frame (NXDN): 27 / 144 is the densest
-            static constexpr size_t maxOutputPerCall = (chunk + 512) / 144 * 27 + 128;
+            // or 36 bytes per 192-symbol frame (NXDN); a POCSAG page line can take up to about half a byte per input bit
+            static constexpr size_t maxOutputPerCall = chunk / 2 + 512;      // POCSAG lines are the densest output
             int proto;
             void* dSyms = nullptr;
             void* dCount = nullptr;
@@ -104,6 +105,23 @@ namespace Digiham {
         class Decoder: public Digiham::Decoder {
             public:
                 Decoder(): Digiham::Decoder(DH_PROTO_YSF) {}
+        };
+
+    }
+
+    namespace Pocsag {
+
+        // include/pocsag_decoder.hpp: the decoded pages are the OUTPUT of this module (`address:<n>;message:<text>\n` lines
+        // from its serializer on the writer), there is no metadata side channel
+        class Decoder: public Digiham::Decoder {
+            public:
+                Decoder(): Digiham::Decoder(DH_PROTO_POCSAG) {}
+                explicit Decoder(Serializer* serializer): Decoder() {
+                    // the engine writes the reference's StringSerializer format; another serializer cannot be honoured
+                    StringSerializer* s = dynamic_cast<StringSerializer*>(serializer);
+                    if (s == nullptr) { delete serializer; throw std::invalid_argument("Digiham::Pocsag::Decoder: only the StringSerializer format is available"); }
+                    delete s;
+                }
         };
 
     }

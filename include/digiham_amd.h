@@ -66,6 +66,8 @@ int dh_quadratic_residue(uint16_t* d_words, uint8_t* d_ok, size_t n, void* strea
 int dh_golay_20_8(uint32_t* d_words, uint8_t* d_ok, size_t n, void* stream);
 /* bool golay_24_12(uint32_t*)     src/ysf_decoder/golay_24_12.c:2401-2415 */
 int dh_golay_24_12(uint32_t* d_words, uint8_t* d_ok, size_t n, void* stream);
+/* bool bch_31_21(uint32_t*)       src/pocsag_decoder/bch_31_21.c:545-561 (31-bit words, up to 2 errors) */
+int dh_bch_31_21(uint32_t* d_words, uint8_t* d_ok, size_t n, void* stream);
 /* bool bptc_196_96(uint8_t payload[25], uint8_t output[12])  src/dmr_decoder/bptc_196_96.c:5-59
  * d_in [n][25] -> d_out [n][12] (zero-filled when ok == 0) */
 int dh_bptc_196_96(const uint8_t* d_in, uint8_t* d_out, uint8_t* d_ok, size_t n, void* stream);
@@ -95,7 +97,7 @@ typedef struct dh_engine dh_engine;
 
 enum { DH_RRC_NONE = 0, DH_RRC_WIDE = 1, DH_RRC_NARROW = 2 };
 enum { DH_DEMOD_NONE = 0, DH_DEMOD_FSK2 = 2, DH_DEMOD_GFSK4 = 4 };
-enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3 };
+enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3, DH_PROTO_POCSAG = 4 };
 
 /* flags */
 #define DH_FLAG_FAST_FIR        0x1   /* FMA FIR: float outputs within 1e-6 of the reference, dibits NOT guaranteed bit-exact */
@@ -138,7 +140,9 @@ enum {
     /* NXDN48 (src/nxdn_decoder/nxdn_phase.cpp): LICH byte; SACCH fragment (a = structure index, 5 bytes); complete SACCH
      * superframe (9 bytes); setSync("voice"); FACCH1 (a = block, 12 bytes); MetaCollector::reset (b = 0 sync loss, 1 TX_RELEASE) */
     DH_EV_NXDN_LICH = 32, DH_EV_NXDN_SACCH = 33, DH_EV_NXDN_SACCH_SF = 34, DH_EV_NXDN_SYNC_VOICE = 35,
-    DH_EV_NXDN_FACCH1 = 36, DH_EV_NXDN_META_RESET = 37
+    DH_EV_NXDN_FACCH1 = 36, DH_EV_NXDN_META_RESET = 37,
+    /* POCSAG (src/pocsag_decoder/pocsag_phase.cpp:56-57): a = position in the batch, payload = BCH-corrected codeword (big endian) */
+    DH_EV_POCSAG_CODEWORD = 48
 };
 
 int  dh_engine_create(const dh_engine_config* cfg, dh_engine** out);

@@ -8,6 +8,7 @@
 #define FN_QR orc_quadratic_residue
 #define FN_GOLAY_20_8 orc_golay_20_8
 #define FN_GOLAY_24_12 orc_golay_24_12
+#define FN_BCH_31_21 orc_bch_31_21
 #define FN_BPTC orc_bptc_196_96
 #define FN_TRELLIS orc_decode_trellis
 #define FN_CRC16 orc_crc16_checksum

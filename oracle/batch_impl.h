@@ -17,6 +17,7 @@ void BATCH(hamming_16_11)(uint16_t* d, uint8_t* ok, size_t n) { for (size_t i = 
 void BATCH(quadratic_residue)(uint16_t* d, uint8_t* ok, size_t n) { for (size_t i = 0; i < n; i++) ok[i] = FN_QR(&d[i]); }
 void BATCH(golay_20_8)(uint32_t* d, uint8_t* ok, size_t n) { for (size_t i = 0; i < n; i++) ok[i] = FN_GOLAY_20_8(&d[i]); }
 void BATCH(golay_24_12)(uint32_t* d, uint8_t* ok, size_t n) { for (size_t i = 0; i < n; i++) ok[i] = FN_GOLAY_24_12(&d[i]); }
+void BATCH(bch_31_21)(uint32_t* d, uint8_t* ok, size_t n) { for (size_t i = 0; i < n; i++) ok[i] = FN_BCH_31_21(&d[i]); }
 
 /* in [n][25] -> out [n][12] (left untouched = caller-zeroed on failure), ok[n] */
 void BATCH(bptc_196_96)(const uint8_t* in, uint8_t* out, uint8_t* ok, size_t n) {

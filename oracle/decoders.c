@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { PROTO_DMR = 1, PROTO_YSF = 2, PROTO_NXDN = 3 };
+enum { PROTO_DMR = 1, PROTO_YSF = 2, PROTO_NXDN = 3, PROTO_POCSAG = 4 };
 enum { PH_SYNC = 0, PH_FRAME = 1 };
 
 /* ---- DMR constants: src/dmr_decoder/dmr_phase.hpp:6-12,25-33 */
@@ -66,6 +66,8 @@ struct orc_decoder {
     /* Nxdn::FramedPhase (nxdn_phase.hpp:31-40): syncCount shares sync_count; lich < 0 = nullptr;
      * SacchSuperframeCollector (sacch.hpp:37-46): collected[i] != nullptr <=> bit i of sacch_have */
     int lich; uint8_t sacch_have; uint8_t sacch_data[4][4];
+    /* Pocsag::CodewordPhase (pocsag_phase.hpp:27-36; syncCount shares sync_count) + its Message (message.hpp:11-23) */
+    int codeword_counter, has_message; uint32_t msg_address; uint8_t msg_type; int msg_pos; char msg_content[80];
 };
 
 static void emit(orc_decoder* d, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, uint8_t len) {
@@ -110,6 +112,12 @@ orc_decoder* orc_ysf_new(void) {
 orc_decoder* orc_nxdn_new(void) {
     orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
     d->proto = PROTO_NXDN; d->phase = PH_SYNC; d->lich = -1;
+    return d;
+}
+
+orc_decoder* orc_pocsag_new(void) {
+    orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
+    d->proto = PROTO_POCSAG; d->phase = PH_SYNC;
     return d;
 }
 
@@ -592,6 +600,104 @@ static size_t nxdn_frame(orc_decoder* d, const uint8_t* p, int* to_sync) {
     return pos;
 }
 
+/* ================================================================ POCSAG */
+/* pocsag_phase.hpp:8,15; codeword.hpp:5-6,23; message.hpp:8 */
+#define POCSAG_SYNC_SIZE 32
+#define POCSAG_CODEWORD_SIZE 32
+#define POCSAG_CODEWORDS_PER_SYNC 16
+#define POCSAG_MAX_MESSAGE_LENGTH 80
+static const uint8_t pocsag_sync[32] = { 0,1,1,1,1,1,0,0,1,1,0,1,0,0,1,0,0,0,0,1,0,1,0,1,1,1,0,1,1,0,0,0 };
+#define POCSAG_IDLE 0x7A89C197u
+
+/* Message::serialize (message.cpp:17-25) with the StringSerializer (meta.cpp:8-17): `address:<n>;message:<text>\n`,
+ * the text ending at its first NUL */
+static void pocsag_serialize(orc_decoder* d) {
+    if (!d->has_message || d->msg_pos == 0) return;
+    char line[160];
+    size_t n = 0;
+    const char* a = "address:";
+    memcpy(line + n, a, 8); n += 8;
+    char num[16]; int nn = 0; uint32_t v = d->msg_address;
+    do { num[nn++] = (char) ('0' + v % 10); v /= 10; } while (v);
+    while (nn) line[n++] = num[--nn];
+    memcpy(line + n, ";message:", 9); n += 9;
+    for (int i = 0; i < POCSAG_MAX_MESSAGE_LENGTH && d->msg_content[i]; i++) line[n++] = d->msg_content[i];
+    line[n++] = '\n';
+    if (d->out_cap - d->out_n < n) { d->overflow = 1; return; }
+    memcpy(d->out + d->out_n, line, n);
+    d->out_n += n;
+}
+
+/* Message::append (message.cpp:27-72) */
+static void pocsag_append(orc_decoder* d, uint32_t data) {
+    switch (d->msg_type) {
+        case 3:
+            if (d->msg_pos + 20 < POCSAG_MAX_MESSAGE_LENGTH * 7) {
+                for (int i = 0; i < 20; i++) {
+                    const unsigned bit = (data >> (19 - i)) & 1u;
+                    d->msg_content[d->msg_pos / 7] |= (char) (bit << (d->msg_pos % 7));
+                    d->msg_pos++;
+                }
+            }
+            break;
+        case 0:
+            if (d->msg_pos + 5 < POCSAG_MAX_MESSAGE_LENGTH) {
+                static const char tail[6] = { '*', 'U', ' ', '-', ')', '(' };
+                for (int i = 0; i < 5; i++) {
+                    char c = 0;
+                    const unsigned base = (unsigned) (4 - i) * 4;
+                    for (int k = 0; k < 4; k++) c |= (char) (((data >> (base + k)) & 1u) << (3 - k));
+                    c = c < 0xA ? (char) ('0' + c) : tail[c - 0xA];
+                    d->msg_content[d->msg_pos++] = c;
+                }
+            }
+            break;
+    }
+}
+
+static void pocsag_drop_message(orc_decoder* d) { d->has_message = 0; }
+
+/* CodewordPhase::process (pocsag_phase.cpp:38-92).  Returns the bits consumed; *to_sync = 1 on fall-back to SyncPhase. */
+static size_t pocsag_step(orc_decoder* d, const uint8_t* p, int* to_sync) {
+    *to_sync = 0;
+    if (d->codeword_counter >= POCSAG_CODEWORDS_PER_SYNC) {
+        if (orc_hamming_distance(p, pocsag_sync, POCSAG_SYNC_SIZE) <= 3) {
+            if (d->sync_count++ > 2) d->sync_count = 2;
+        } else if (d->sync_count-- < 0) {
+            pocsag_serialize(d);
+            *to_sync = 1;
+            return 0;
+        }
+        d->codeword_counter = 0;
+        return POCSAG_SYNC_SIZE;
+    }
+    uint32_t cw;
+    if (orc_pocsag_codeword_parse(p, &cw)) {
+        const uint8_t be[4] = { (uint8_t) (cw >> 24), (uint8_t) (cw >> 16), (uint8_t) (cw >> 8), (uint8_t) cw };
+        emit(d, ORC_EV_POCSAG_CODEWORD, (uint8_t) d->codeword_counter, 0, be, 4);
+        if (cw == POCSAG_IDLE) {                                   /* codeword.cpp:36-38 */
+            pocsag_serialize(d);
+            pocsag_drop_message(d);
+        } else if ((cw >> 31) == 0) {                              /* address codeword (:45-47) */
+            pocsag_serialize(d);
+            pocsag_drop_message(d);
+            const uint8_t type = (uint8_t) ((cw >> 11) & 3u);      /* getFunctionBits (:54-56) */
+            if (type == 1 || type == 3) {
+                d->has_message = 1;
+                d->msg_address = (((cw >> 13) & 0x3FFFFu) << 3) | (uint32_t) (d->codeword_counter / 2);
+                d->msg_type = type; d->msg_pos = 0;
+                memset(d->msg_content, 0, sizeof(d->msg_content));
+            }
+        } else if (d->has_message) {
+            pocsag_append(d, (cw >> 11) & 0xFFFFFu);               /* getPayload (:40-43) */
+        }
+    } else {
+        pocsag_drop_message(d);
+    }
+    d->codeword_counter++;
+    return POCSAG_CODEWORD_SIZE;
+}
+
 /* ============================================ Digiham::Decoder main loop */
 /* `while (canProcess()) process()` with canProcess = available > required
  * (src/lib/decoder.cpp:21-32; cli.cpp:29-33) */
@@ -614,6 +720,20 @@ size_t orc_decoder_process(orc_decoder* d, const uint8_t* in, size_t n,
                 if (!(avail > DMR_FRAME_SIZE)) break;                        /* :61-63 */
                 if (dmr_frame(d, p)) d->phase = PH_SYNC;
                 else { pos += DMR_FRAME_SIZE; d->consumed += DMR_FRAME_SIZE; }
+            }
+        } else if (d->proto == PROTO_POCSAG) {
+            if (!(avail > POCSAG_SYNC_SIZE)) break;                          /* both phases need 32 (pocsag_phase.cpp:14,34) */
+            if (d->phase == PH_SYNC) {
+                if (orc_hamming_distance(p, pocsag_sync, POCSAG_SYNC_SIZE) <= 3) {   /* :18-28 */
+                    pos += POCSAG_SYNC_SIZE; d->consumed += POCSAG_SYNC_SIZE;
+                    d->phase = PH_FRAME;
+                    d->sync_count = 1; d->codeword_counter = 0; d->has_message = 0;  /* pocsag_phase.hpp:31-34 */
+                } else { pos++; d->consumed++; }
+            } else {
+                int to_sync;
+                const size_t used = pocsag_step(d, p, &to_sync);
+                pos += used; d->consumed += used;
+                if (to_sync) { d->phase = PH_SYNC; d->has_message = 0; }
             }
         } else if (d->proto == PROTO_NXDN) {
             if (d->phase == PH_SYNC) {

@@ -111,7 +111,14 @@ enum {
     ORC_EV_NXDN_SYNC_VOICE = 35, /* MetaCollector::setSync("voice")                  nxdn_phase.cpp:141 */
     ORC_EV_NXDN_FACCH1     = 36, /* a=block (0/1) payload=12 bytes (CRC ok)          nxdn_phase.cpp:152-154 */
     ORC_EV_NXDN_META_RESET = 37, /* b=0 sync loss, 1 TX_RELEASE                      nxdn_phase.cpp:51,157 */
+    ORC_EV_POCSAG_CODEWORD = 48, /* a=position in the batch payload=corrected word, big endian  pocsag_phase.cpp:56-57 */
 };
+
+/* --------------------------------------------------------------- pocsag.c */
+bool orc_bch_31_21(uint32_t* data);
+uint32_t orc_bch_31_21_encode(uint32_t data21);
+uint32_t orc_bch_31_21_row(int k);
+int orc_pocsag_codeword_parse(const uint8_t* input32, uint32_t* out);
 
 /* ----------------------------------------------------------------- nxdn.c */
 void orc_nxdn_scramble(uint16_t* shift_register, const uint8_t* input, uint8_t* output, size_t len);
@@ -124,6 +131,7 @@ typedef struct orc_decoder orc_decoder;
 orc_decoder* orc_dmr_new(void);
 orc_decoder* orc_ysf_new(void);
 orc_decoder* orc_nxdn_new(void);
+orc_decoder* orc_pocsag_new(void);
 void orc_decoder_free(orc_decoder*);
 void orc_dmr_set_slot_filter(orc_decoder*, uint8_t filter);
 /* streaming: consumes symbols from in[0..n); returns symbols consumed.  Output
@@ -142,7 +150,7 @@ typedef struct {
     int levels;     /* 4 gfsk, 2 fsk, 0 = no demod */
     int invert;
     unsigned sps;
-    int proto;      /* 0 none, 1 DMR, 2 YSF, 3 NXDN */
+    int proto;      /* 0 none, 1 DMR, 2 YSF, 3 NXDN, 4 POCSAG */
     int slot_filter;
 } orc_chain_cfg;
 

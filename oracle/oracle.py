@@ -70,6 +70,9 @@ def _declare(L):
     L.orc_dmr_new.restype = vp
     L.orc_ysf_new.restype = vp
     L.orc_nxdn_new.restype = vp
+    L.orc_pocsag_new.restype = vp
+    L.orc_bch_31_21_encode.restype = C.c_uint32
+    L.orc_bch_31_21_encode.argtypes = [C.c_uint32]
     L.orc_nxdn_trellis_decode.restype = C.c_uint
     L.orc_nxdn_trellis_decode.argtypes = [vp, vp, C.c_size_t]
     L.orc_nxdn_scramble.argtypes = [vp, vp, vp, C.c_size_t]
@@ -99,7 +102,7 @@ def _p(a):
 # ------------------------------------------------------------------ FEC (batch)
 _WORD = {"hamming_7_4": np.uint8, "hamming_13_9": np.uint16, "hamming_15_11": np.uint16,
          "hamming_16_11": np.uint16, "quadratic_residue": np.uint16,
-         "golay_20_8": np.uint32, "golay_24_12": np.uint32}
+         "golay_20_8": np.uint32, "golay_24_12": np.uint32, "bch_31_21": np.uint32}
 
 
 def _impl(which):
@@ -247,7 +250,7 @@ class Decoder:
     """Streaming Dmr::Decoder / Ysf::Decoder; returns (output bytes, events) per call."""
 
     def __init__(self, proto):
-        self._h = {"dmr": lib().orc_dmr_new, "ysf": lib().orc_ysf_new, "nxdn": lib().orc_nxdn_new}[proto]()
+        self._h = {"dmr": lib().orc_dmr_new, "ysf": lib().orc_ysf_new, "nxdn": lib().orc_nxdn_new, "pocsag": lib().orc_pocsag_new}[proto]()
         self._tail = np.zeros(0, np.uint8)
 
     def set_slot_filter(self, f):

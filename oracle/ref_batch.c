@@ -16,6 +16,7 @@ bool hamming_16_11(uint16_t* data);
 bool quadratic_residue(uint16_t* data);
 bool golay_20_8(uint32_t* data);
 bool golay_24_12(uint32_t* data);
+bool bch_31_21(uint32_t* data);                     /* src/pocsag_decoder/bch_31_21.h */
 bool bptc_196_96(uint8_t* payload, uint8_t* output);
 uint8_t decode_trellis(uint8_t* input, uint8_t size, uint8_t* output);
 uint16_t crc16_checksum(uint8_t* data, int count);
@@ -29,6 +30,7 @@ unsigned int hamming_distance(uint8_t* a, uint8_t* b, size_t size);
 #define FN_QR quadratic_residue
 #define FN_GOLAY_20_8 golay_20_8
 #define FN_GOLAY_24_12 golay_24_12
+#define FN_BCH_31_21 bch_31_21
 #define FN_BPTC bptc_196_96
 #define FN_TRELLIS decode_trellis
 #define FN_CRC16 crc16_checksum

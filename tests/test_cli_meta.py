@@ -15,7 +15,7 @@ import pytest
 from digiham_amd import api, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOLS = ["rrc_filter", "gfsk_demodulator", "fsk_demodulator", "digitalvoice_filter", "dmr_decoder", "ysf_decoder", "nxdn_decoder"]
+TOOLS = ["rrc_filter", "gfsk_demodulator", "fsk_demodulator", "digitalvoice_filter", "dmr_decoder", "ysf_decoder", "nxdn_decoder", "pocsag_decoder"]
 
 
 def _ev(type_, a=0, b=0, payload=b""):
@@ -160,6 +160,24 @@ def test_cli_pipe_like_the_example_scripts(oracle, tmp_path, proto, gpu):
         assert any("mode:DN;protocol:YSF" in l for l in lines), lines
     else:
         assert "destination:99;protocol:NXDN;source:4660;sync:voice;type:individual" in lines, lines
+
+
+@pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
+def test_pocsag_pipe_like_the_example_script(oracle, tmp_path, gpu):
+    """examples/pocsag-decoder.sh: fsk_demodulator -i -s 40 | pocsag_decoder; the pages are the decoder's stdout."""
+    bindir = _build_tools(tmp_path, gpu)
+    bits, sent = synth.pocsag_stream(31, 3)
+    x = synth.impair(synth.fsk_shape(bits, sps=40, invert=True), 5, snr_db=22, dc=0.03)
+    inp, out = tmp_path / "in.f32", tmp_path / "out.txt"
+    x.astype(np.float32).tofile(inp)
+    cmd = "%s/fsk_demodulator -i -s 40 < %s | %s/pocsag_decoder > %s" % (bindir, inp, bindir, out)
+    subprocess.run(["bash", "-o", "pipefail", "-c", cmd], check=True, stderr=subprocess.DEVNULL)
+    ref = oracle.chain(x[None, :], rrc=0, levels=2, invert=True, sps=40, proto=4)
+    want = ref["out"][0, :ref["out_count"][0]]
+    got = np.fromfile(out, np.uint8)
+    assert len(want) > 0 and len(got) >= len(want) and (got[:len(want)] == want).all()
+    lines = bytes(got).decode("latin1").split("\n")
+    assert any(("address:%d;message:%s" % (a, t)) in lines for a, f, t in sent)
 
 
 def test_cli_tools_fail_loudly_without_a_device():
