@@ -42,6 +42,9 @@ WORKLOADS = {
     # narrow RRC -> gfsk -s 20 -> nxdn_decoder (examples/nxdn48-decoder.sh)
     "nxdn_full": ("nxdn", dict(rrc="narrow", demod="gfsk", sps=20, proto="nxdn"),
                   "full chain rrc(narrow)->gfsk(20)->nxdn_decoder (NXDN48)"),
+    # examples/dstar-decoder.sh: fsk_demodulator -s 10 | dstar_decoder (no RRC stage on this path)
+    "dstar_full": ("dstar", dict(rrc="none", demod="fsk", sps=10, proto="dstar"),
+                   "full chain fsk(10)->dstar_decoder (D-Star)"),
     # BASELINE configs[4] per GPU: half the channels DMR, half YSF, one engine (and one launch per push) each
     "mixed": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
               "half DMR + half YSF channels, full chains (BASELINE configs[4] per-GPU share)"),
@@ -67,6 +70,8 @@ def profiled_traffic(workload, channels, T):
 
 
 def oracle_kw(proto):
+    if proto == "dstar":
+        return dict(proto=5, rrc=0, levels=2, sps=10)
     return dict(proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
 
 
@@ -91,7 +96,7 @@ def cpu_baseline(x_host_fn, proto, budget_s=12.0):
             "msamples_per_s_per_core": rate / 1e6 / cores, "single_thread_msamples_per_s": 1e-6 / per_sample,
             "cores": cores, "kind": "port",
             "sample": "%d channels x %d samples of the same synthetic workload through oracle/ (scalar C restatement of "
-                      "rrc_filter|gfsk_demodulator|%s_decoder, bit-exact with the GPU path), %d pthreads, %.1f s wall"
+                      "[rrc_filter|]g/fsk_demodulator|%s_decoder, bit-exact with the GPU path), %d pthreads, %.1f s wall"
                       % (chans, x.shape[1], proto, cores, dt)}
 
 
@@ -120,7 +125,7 @@ def main():
 
     proto, kw, desc = WORKLOADS[args.workload]
     B = args.channels
-    units = args.units or {"dmr": 132, "ysf": 40, "nxdn": 50}[proto]
+    units = args.units or {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198}[proto]
     x, info = synth_torch.make_batch(torch, device, proto, B, units, seed=1000 + 7919 * rank, sps=kw["sps"])
     T = info["samples_per_channel"]
     ctx = api.Context(device=local)
@@ -212,7 +217,7 @@ def main():
                 alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = profiled_traffic(args.workload, B, T) if dom_name == "k_chain" else (None, None)
-        taps = {"wide": 81, "narrow": 161}[kw["rrc"]]
+        taps = {"wide": 81, "narrow": 161, "none": 0}[kw["rrc"]]
         fir_flops = B * T * 2.0 * taps       # one mul + one add per tap and sample, unfused
         line = {
             "metric": "concurrent 48 kS/s DMR+YSF channels sustained end-to-end" if mixed else

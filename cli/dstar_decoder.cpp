@@ -1,0 +1,18 @@
+// dstar_decoder -- bits in (fsk_demodulator -s 10), 9-byte AMBE voice frames out, metadata lines to --fifo
+// (reference: src/dstar_decoder/dstar_cli.cpp, examples/dstar-decoder.sh)
+#include "digiham/cli.hpp"
+#include "digiham/dstar_decoder.hpp"
+
+namespace {
+    class Cli: public Digiham::DecoderCli {
+        protected:
+            std::string getName() override { return "dstar_decoder"; }
+            Csdr::Module<unsigned char, unsigned char>* buildModule() override {
+                auto module = new Digiham::DStar::Decoder();
+                if (metaWriter) module->setMetaWriter(metaWriter);
+                return module;
+            }
+    };
+}
+
+int main(int argc, char** argv) { Cli runner; return runner.main(argc, argv); }

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdigiham_amd.so")
 DH_OK, DH_EINVAL, DH_ENOMEM, DH_EDEVICE, DH_ENODEV, DH_ECAPACITY = 0, -1, -2, -3, -4, -5
 RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2}
 DEMOD = {"none": 0, None: 0, "fsk": 2, "fsk2": 2, "gfsk": 4, "gfsk4": 4}
-PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3, "pocsag": 4}
+PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3, "pocsag": 4, "dstar": 5}
 FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED_TIMING, FLAG_SPLIT_STAGES = 1, 2, 4, 8, 16, 32
 
 

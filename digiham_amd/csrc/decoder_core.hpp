@@ -19,6 +19,8 @@
 #include "../../include/digiham_amd.h"     // dh_event, DH_EV_*
 
 #define DH_SYM_CARRY_MAX 512          // symbols a decoder may leave unread between pushes (<= 480)
+#define DH_DSTAR_CARRY_MAX 704        // D-Star: the header phase waits for more than 660 bits (dstar_phase.hpp:52)
+DH_HD uint32_t dh_carry_max(int proto) { return proto == DH_PROTO_DSTAR ? DH_DSTAR_CARRY_MAX : DH_SYM_CARRY_MAX; }
 #define DH_DEC_STATE_WORDS 64
 
 enum {
@@ -31,7 +33,11 @@ enum {
     DS_NX_LICH = 2, DS_NX_HAVE = 3, DS_NX_SACCH0 = 4,
     // POCSAG (Pocsag::CodewordPhase, pocsag_phase.hpp:27-36, and its Message, message.hpp:11-23): codeword counter,
     // message present, address, type, bit / char position, 80 content bytes (little-endian words)
-    DS_PC_COUNTER = 2, DS_PC_HAS = 3, DS_PC_ADDR = 4, DS_PC_TYPE = 5, DS_PC_POS = 6, DS_PC_CONTENT = 32
+    DS_PC_COUNTER = 2, DS_PC_HAS = 3, DS_PC_ADDR = 4, DS_PC_TYPE = 5, DS_PC_POS = 6, DS_PC_CONTENT = 32,
+    // D-Star (DStar::VoicePhase, dstar_phase.hpp:67-77): frameCount, collected_data (2 x 3 bytes), messageBlocks,
+    // headerCount, message (20 bytes, little-endian words), header (41 bytes)
+    DS_DT_FRAME = 2, DS_DT_COLLECT0 = 3, DS_DT_COLLECT1 = 4, DS_DT_BLOCKS = 5, DS_DT_HCOUNT = 6, DS_DT_MESSAGE = 8,
+    DS_DT_HEADER = 32
 };
 
 struct DhDecParams {
@@ -1515,6 +1521,323 @@ DH_HD void dh_pocsag_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) 
     }
     s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
     s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+    s.store(st_global);
+    DH_BARRIER();
+}
+
+// =============================================================================================
+// D-Star (reference: src/dstar_decoder/dstar_phase.cpp, header.cpp, scrambler.cpp, crc.cpp;
+// examples/dstar-decoder.sh: fsk_demodulator -s 10 | dstar_decoder).  Input symbols are bits; the output is the 9-byte
+// AMBE voice frames.  A voice frame (96 bits) is two plane words and a handful of scalar integer operations; the radio
+// header's 4-state Viterbi runs on the SCALAR unit (its inputs go through readfirstlane), leaving the vector ALUs to
+// the other wavefronts of the SIMD.
+// =============================================================================================
+constexpr uint32_t dh_bits_lsb(const char* bits, int from, int cnt) {      // "0110.." -> character from+i in bit i
+    uint32_t r = 0;
+    for (int i = 0; i < cnt; i++) r |= (uint32_t) (bits[from + i] == '1') << i;
+    return r;
+}
+// dstar_phase.hpp:18-41
+#define DH_DSTAR_HEADER_SYNC dh_bits_lsb("010101010111011001010000", 0, 24)
+#define DH_DSTAR_VOICE_SYNC  dh_bits_lsb("101010101011010001101000", 0, 24)
+#define DH_DSTAR_TERM_LO     dh_bits_lsb("101010101010101010101010101010100001001101011110", 0, 24)
+#define DH_DSTAR_TERM_HI     dh_bits_lsb("101010101010101010101010101010100001001101011110", 24, 24)
+
+// the scrambler's whitening sequence from its reset state (scrambler.cpp:7-21, scrambler.hpp:13): bit n in w[n / 32]
+struct DhDstarPn {
+    uint32_t w[21];
+    constexpr DhDstarPn(): w() {
+        uint32_t sr = 0x7Fu;
+        for (int n = 0; n < 660; n++) {
+            const uint32_t wb = (sr & 1u) ^ ((sr >> 3) & 1u);
+            w[n >> 5] |= wb << (n & 31);
+            sr = ((sr & 0x7Eu) >> 1) | (wb << 6);
+        }
+    }
+};
+DH_HD uint32_t dh_dstar_pn(uint32_t n) {
+    constexpr DhDstarPn pn{};
+    return (pn.w[n >> 5] >> (n & 31u)) & 1u;
+}
+
+// Crc::isCrcValid's checksum (crc.cpp:6-23) over `len` bytes delivered by get(i)
+template <typename Get> DH_HD uint32_t dh_dstar_crc(Get get, uint32_t len) {
+    uint32_t checksum = 0xFFFFu;
+    for (uint32_t k = 0; k < len; k++) {
+        const uint32_t byte = get(k);
+        for (int i = 0; i < 8; i++) {
+            checksum ^= (byte >> i) & 1u;
+            checksum = (checksum & 1u) ? (checksum >> 1) ^ 0x8408u : checksum >> 1;
+        }
+    }
+    return checksum ^ 0xFFFFu;
+}
+
+// LDS scratch of the header decoder, carved from S.carry (D-Star keeps its carried bits in S.vit_dec instead)
+struct DhDstarScratch { uint64_t dbits[11]; uint32_t dec[44]; uint32_t out[12]; };
+static_assert(sizeof(DhDstarScratch) <= DH_SYM_CARRY_MAX, "D-Star header scratch");
+
+// Header::parseFromHeader (header.cpp:24-58) on the 660 bits at `pos`: true when the path metric is <= 10 and the CRC
+// holds; the 41 header bytes are then in X.out (little-endian words)
+DH_HD bool dh_dstar_header_parse(const DhSymView& syms, uint32_t pos, DhDstarScratch& X) {
+    // descramble + de-interleave (header.cpp:26-30, :60-72): de-interleaved bit idx = 24 k + i comes from received
+    // bit i * 28 + k (i < 12) or 12 + i * 27 + k; 64 bits per vote
+    for (uint32_t c = 0; c < 11u; c++) {
+        uint64_t m = 0;
+        DH_FOR_LANES(lane) {
+            const uint32_t idx = c * 64u + (uint32_t) lane;
+            uint32_t bit = 0;
+            if (idx < 660u) {
+                const uint32_t k = idx / 24u, i = idx % 24u;
+                const uint32_t src = i < 12u ? i * 28u + k : 12u + i * 27u + k;
+                bit = (dh_view_at(syms, pos + src) & 1u) ^ dh_dstar_pn(src);
+            }
+            DH_BALLOT_ACC(m, bit != 0u, lane);
+        }
+        X.dbits[c] = m;
+    }
+    DH_BARRIER();
+    // Header::viterbi_decode (:86-150) as add-compare-select + decision bits + traceback: the reference carries the
+    // four survivor byte strings instead, which is the same path under the same tie rules (k = 0 wins ties, the
+    // lowest end state wins).  State i = (newest bit << 1) | previous bit; predecessor ((i << 1) & 2) | k.
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    for (uint32_t blk = 0; blk < 11u; blk++) {                     // 32 trellis steps per 64-bit word
+        const uint64_t word = X.dbits[blk];
+        uint32_t lo = dh_uniform((uint32_t) word), hi = dh_uniform((uint32_t) (word >> 32));
+        const uint32_t steps = blk < 10u ? 32u : 10u;
+        for (uint32_t g = 0; g < 4u; g++) {
+          uint32_t dw = 0;
+          const uint32_t half = g < 2u ? lo : hi;
+          for (uint32_t qq = 0; qq < 8u; qq++) {
+            const uint32_t q = g * 8u + qq;
+            if (q >= steps) break;
+            const uint32_t pair = (half >> (2u * (q & 15u))) & 3u;
+            const uint32_t t = ((pair & 1u) << 1) | (pair >> 1);  // in_transition: first bit is the high one (:95)
+            // hamming distance of t against the branch words 00 / 11 / 10 / 01 (trellis_transitions, :79-84)
+            const uint32_t h00 = (t & 1u) + (t >> 1), h11 = 2u - h00, h10 = (t & 1u) + (1u - (t >> 1)), h01 = 2u - h10;
+            // new state 0: from 0 (out 00) or 1 (out 11); 1: from 2 (10) or 3 (01); 2: from 0 (11) or 1 (00); 3: from 2 (01) or 3 (10)
+            const uint32_t a0 = m0 + h00, b0 = m1 + h11, a1 = m2 + h10, b1 = m3 + h01;
+            const uint32_t a2 = m0 + h11, b2 = m1 + h00, a3 = m2 + h01, b3 = m3 + h10;
+            const uint32_t s0 = b0 < a0, s1 = b1 < a1, s2 = b2 < a2, s3 = b3 < a3;
+            m0 = s0 ? b0 : a0; m1 = s1 ? b1 : a1; m2 = s2 ? b2 : a2; m3 = s3 ? b3 : a3;
+            dw |= (s0 | (s1 << 1) | (s2 << 2) | (s3 << 3)) << (4u * qq);
+          }
+          X.dec[blk * 4u + g] = dw;
+        }
+    }
+    DH_BARRIER();
+    uint32_t state = 0, best = m0;
+    if (m1 < best) { best = m1; state = 1; }
+    if (m2 < best) { best = m2; state = 2; }
+    if (m3 < best) { best = m3; state = 3; }
+    for (int blk = 10; blk >= 0; blk--) {
+        const int steps = blk < 10 ? 32 : 10;
+        uint32_t ow = 0;
+        for (int g = 3; g >= 0; g--) {
+            const uint32_t dw = dh_uniform(X.dec[(uint32_t) (blk * 4 + g)]);
+            for (int qq = 7; qq >= 0; qq--) {
+                const int q = g * 8 + qq;
+                if (q >= steps) continue;
+                ow |= (state >> 1) << q;                           // output bit pos in bit pos % 8 of byte pos / 8 (:98-103)
+                state = ((state << 1) & 2u) | ((dw >> (4u * (uint32_t) qq + state)) & 1u);
+            }
+        }
+        X.out[blk] = ow;
+    }
+    DH_BARRIER();
+    if (best > 10u) return false;
+    const uint32_t* out = X.out;
+    const uint32_t crc = dh_dstar_crc([out](uint32_t k) { return (dh_uniform(out[k >> 2]) >> (8u * (k & 3u))) & 0xFFu; }, 39u);
+    const uint32_t got = ((X.out[9] >> 24) & 0xFFu) | ((X.out[10] & 0xFFu) << 8);     // bytes 39, 40 (:54)
+    return crc == dh_uniform(got);
+}
+
+// MetaCollector::setFromHeader as two events; get(k) delivers header byte k
+template <typename Get> DH_HD void dh_dstar_emit_header(DhDecCtx& c, Get get, uint8_t source) {
+    uint8_t part[24];
+    for (uint32_t i = 0; i < 24u; i++) part[i] = (uint8_t) get(i);
+    dh_emit(c, DH_EV_DSTAR_HEADER, 0, source, part, 24);
+    for (uint32_t i = 0; i < 17u; i++) part[i] = (uint8_t) get(24u + i);
+    dh_emit(c, DH_EV_DSTAR_HEADER, 1, source, part, 17);
+}
+
+// the two VoicePhase constructors (dstar_phase.cpp:60-70, dstar_phase.hpp:71-76)
+DH_HD void dh_dstar_enter_voice(DhDecCtx& c, DhState& s, bool after_header) {
+    s[DS_DT_FRAME] = after_header ? 21u : 0u;
+    s[DS_SYNC_COUNT] = after_header ? 1u : 0u;
+    s[DS_DT_COLLECT0] = 0; s[DS_DT_COLLECT1] = 0; s[DS_DT_BLOCKS] = 0; s[DS_DT_HCOUNT] = 0;
+    for (int i = 0; i < 5; i++) s[DS_DT_MESSAGE + i] = 0;
+    for (int i = 0; i < 11; i++) s[DS_DT_HEADER + i] = 0;
+    dh_emit(c, DH_EV_DSTAR_VOICE_START, 0, after_header ? 1 : 0, nullptr, 0);
+}
+
+// n (<= 5) bytes of `data` (byte 0 in the low bits) into the byte string kept in state words base.., at byte offset off
+DH_HD void dh_dstar_put_bytes(DhState& s, uint32_t base, uint32_t off, uint64_t data, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t at = off + i, w = base + (at >> 2), sh = 8u * (at & 3u);
+        s[w] = ((uint32_t) s[w] & ~(0xFFu << sh)) | ((uint32_t) ((data >> (8u * i)) & 0xFFu) << sh);
+    }
+}
+
+DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+    DhDecCtx c;
+    c.P = &P; c.T = &dh_lds_tables(S);
+    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
+    DhState s; s.load(st_global);
+    c.st = &s;
+    c.out = P.out + (size_t) ch * P.out_stride;
+    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
+    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.consumed = s[DS_CONSUMED];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    c.writer = threadIdx.x == 0;
+#else
+    c.writer = true;
+#endif
+    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
+    uint8_t* const lds_carry = reinterpret_cast<uint8_t*>(S.vit_dec);          // 1536 bytes, no K=5 Viterbi in this protocol
+    static_assert(sizeof(S.vit_dec) >= DH_DSTAR_CARRY_MAX, "D-Star carry");
+    DhDstarScratch& X = *reinterpret_cast<DhDstarScratch*>(S.carry);
+    DhSymView syms; syms.carry = lds_carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
+    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    const uint32_t total = syms.nc + syms.nfresh;
+    DH_FOR_LANES(lane) { for (uint32_t j = (uint32_t) lane; j < syms.nc; j += DH_WAVE) lds_carry[j] = carry_buf[j]; }
+    DH_BARRIER();
+    uint32_t pos = 0, phase = s[DS_PHASE];
+    DhPlanes& pl = S.planes;
+
+    for (;;) {
+        const uint32_t avail = total - pos;
+        if (phase == 0) {                                          // SyncPhase (dstar_phase.cpp:17-34): slide bit by bit
+            if (!(avail > 24)) break;
+            dh_view_ensure(syms, pos, 128);
+            dh_load_planes(syms, pos, total, pl, 2);
+            uint64_t hh = 0, hv = 0;
+            DH_FOR_LANES(lane) {
+                const bool valid = avail > (uint32_t) lane && avail - (uint32_t) lane > 24;
+                const uint32_t l = dh_plane_range(pl.l, lane, 24), h = dh_plane_range(pl.h, lane, 24);
+                const bool header = valid && dh_popc32(l ^ DH_DSTAR_HEADER_SYNC) + dh_popc32(h) <= 2;
+                const bool voice = valid && !header && dh_popc32(l ^ DH_DSTAR_VOICE_SYNC) + dh_popc32(h) <= 1;
+                DH_BALLOT_ACC(hh, header, lane);
+                DH_BALLOT_ACC(hv, voice, lane);
+            }
+            if (hh | hv) {
+                const uint32_t l = (uint32_t) dh_ffs64(hh | hv);
+                pos += l + 24u; c.consumed += l + 24u;
+                if ((hh >> l) & 1ull) phase = 2;                   // HeaderPhase
+                else { phase = 1; dh_dstar_enter_voice(c, s, false); }
+            } else {
+                const uint32_t adv = dh_min<uint32_t>(64u, avail - 24u);
+                pos += adv; c.consumed += adv;
+            }
+            continue;
+        }
+        if (phase == 2) {                                          // HeaderPhase (dstar_phase.cpp:36-57)
+            if (!(avail > 660)) break;
+            dh_view_ensure(syms, pos, 660);
+            if (!dh_dstar_header_parse(syms, pos, X)) { pos += 1u; c.consumed += 1u; phase = 0; continue; }
+            pos += 660u; c.consumed += 660u;
+            if (!((X.out[0] >> 7) & 1u)) {                         // isVoice (header.cpp:150-152)
+                const uint32_t* out = X.out;
+                dh_dstar_emit_header(c, [out](uint32_t k) { return (out[k >> 2] >> (8u * (k & 3u))) & 0xFFu; }, 0);
+                phase = 1; dh_dstar_enter_voice(c, s, true);
+            } else phase = 0;
+            if (c.overflow) break;
+            continue;
+        }
+        // VoicePhase::process (dstar_phase.cpp:76-139)
+        if (!(avail > 120)) break;
+        dh_view_ensure(syms, pos, 128);
+        dh_load_planes(syms, pos, total, pl, 2);
+        int sync_count = (int) s[DS_SYNC_COUNT];
+        if (sync_count >= 1) {
+            if (c.P->out_cap - c.nout < 9u) { c.overflow = true; break; }
+            uint8_t* o = c.out + c.nout;
+            DH_FOR_LANES(lane) { if (lane < 9) o[lane] = (uint8_t) dh_plane_range(pl.l, 8 * lane, 8); }
+            c.nout += 9u;
+        }
+        const uint32_t d0 = dh_plane_range(pl.l, 72, 24), d0h = dh_plane_range(pl.h, 72, 24);
+        const uint32_t d1 = dh_plane_range(pl.l, 96, 24), d1h = dh_plane_range(pl.h, 96, 24);
+        if (dh_popc32(d0 ^ DH_DSTAR_TERM_LO) + dh_popc32(d0h) + dh_popc32(d1 ^ DH_DSTAR_TERM_HI) + dh_popc32(d1h) <= 1 ||
+            dh_popc32(d0 ^ DH_DSTAR_TERM_HI) + dh_popc32(d0h) <= 1) {
+            dh_emit(c, DH_EV_DSTAR_META_RESET, 0, 0, nullptr, 0);
+            pos += 120u; c.consumed += 120u; phase = 0;
+            if (c.overflow) break;
+            continue;
+        }
+        uint32_t frame_count = s[DS_DT_FRAME];
+        if (frame_count >= 20u) {                                  // isSyncDue
+            bool lost = false;
+            if (dh_popc32(d0 ^ DH_DSTAR_VOICE_SYNC) + dh_popc32(d0h) > 1) {
+                if (--sync_count < 0) lost = true;
+            } else {
+                if (++sync_count > 3) sync_count = 3;
+                if (sync_count > 1) dh_emit(c, DH_EV_DSTAR_SYNC_VOICE, 0, 0, nullptr, 0);
+            }
+            if (lost) {
+                dh_emit(c, DH_EV_DSTAR_META_RESET, 0, 1, nullptr, 0);
+                pos += 96u; c.consumed += 96u; phase = 0;
+                if (c.overflow) break;
+                continue;
+            }
+            s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+            // parseFrameData (:205-216) + resetFrames (:145-151)
+            if ((uint32_t) s[DS_DT_BLOCKS] == 0xFu) {
+                uint8_t msg[20];
+                for (uint32_t i = 0; i < 20u; i++) msg[i] = (uint8_t) ((uint32_t) s[DS_DT_MESSAGE + (i >> 2)] >> (8u * (i & 3u)));
+                dh_emit(c, DH_EV_DSTAR_MESSAGE, 0, 0, msg, 20);
+            }
+            if ((uint32_t) s[DS_DT_HCOUNT] == 41u) {
+                DhState* sp = &s;
+                auto get = [sp](uint32_t k) { return ((uint32_t) (*sp)[DS_DT_HEADER + (k >> 2)] >> (8u * (k & 3u))) & 0xFFu; };
+                const uint32_t crc = dh_dstar_crc(get, 39u);
+                if (crc == (get(39u) | (get(40u) << 8))) dh_dstar_emit_header(c, get, 1);
+            }
+            dh_emit(c, DH_EV_DSTAR_FRAME_SYNC, 0, 0, nullptr, 0);
+            s[DS_DT_FRAME] = 0; s[DS_DT_BLOCKS] = 0; s[DS_DT_HCOUNT] = 0;
+            for (int i = 0; i < 5; i++) s[DS_DT_MESSAGE + i] = 0;
+            for (int i = 0; i < 11; i++) s[DS_DT_HEADER + i] = 0;
+        } else {
+            constexpr DhDstarPn pn{};
+            const uint32_t x = d0 ^ (pn.w[0] & 0xFFFFFFu);          // scrambler->reset() + 24 bits, packed LSB first (:120-129)
+            // collectDataFrame (:153-203)
+            if ((frame_count & 1u) == 0u) s[DS_DT_COLLECT0] = x;
+            else {
+                s[DS_DT_COLLECT1] = x;
+                const uint32_t c0 = s[DS_DT_COLLECT0];
+                const uint32_t mini = c0 & 0xFFu, n = mini & 0x0Fu;
+                const uint64_t data = (uint64_t) (c0 >> 8) | ((uint64_t) x << 16);       // collected_data[1..5]
+                if ((mini >> 4) == 0x4u) {
+                    if (n <= 3u) { dh_dstar_put_bytes(s, DS_DT_MESSAGE, n * 5u, data, 5u); s[DS_DT_BLOCKS] = (uint32_t) s[DS_DT_BLOCKS] | (1u << n); }
+                } else if ((mini >> 4) == 0x5u) {
+                    const uint32_t hc = s[DS_DT_HCOUNT];
+                    if (n <= 5u && hc + n <= 41u) { dh_dstar_put_bytes(s, DS_DT_HEADER, hc, data, n); s[DS_DT_HCOUNT] = hc + n; }
+                } else if ((mini >> 4) == 0x3u) {
+                    if (n <= 5u) {
+                        uint8_t b[5];
+                        for (uint32_t i = 0; i < 5u; i++) b[i] = (uint8_t) (data >> (8u * i));
+                        dh_emit(c, DH_EV_DSTAR_SIMPLE, 0, 0, b, (int) n);
+                    }
+                }
+            }
+            s[DS_DT_FRAME] = frame_count + 1u;
+        }
+        pos += 96u; c.consumed += 96u;
+        if (c.overflow) break;
+    }
+
+    const uint32_t rem = total - pos;
+    dh_view_ensure(syms, pos, rem < DH_DSTAR_CARRY_MAX ? rem : DH_DSTAR_CARRY_MAX);
+    DH_FOR_LANES(lane) {
+        for (uint32_t j = lane; j < rem && j < DH_DSTAR_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
+        if (DH_IS_LANE0(lane)) {
+            P.out_count[ch] = c.nout;
+            if (P.ev_count) P.ev_count[ch] = c.nev;
+            if ((c.overflow || rem > DH_DSTAR_CARRY_MAX) && P.overflow) *P.overflow = 1u;
+        }
+    }
+    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+    s[DS_CARRY] = rem < DH_DSTAR_CARRY_MAX ? rem : DH_DSTAR_CARRY_MAX;
     s.store(st_global);
     DH_BARRIER();
 }

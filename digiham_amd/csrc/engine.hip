@@ -102,6 +102,11 @@ __global__ __launch_bounds__(DH_WAVE) void k_pocsag(const DhDecParams P) {
     dh_pocsag_channel(P, blockIdx.x, S);
 }
 
+__global__ __launch_bounds__(DH_WAVE) void k_dstar(const DhDecParams P) {
+    __shared__ DhDecShared S;
+    dh_dstar_channel(P, blockIdx.x, S);
+}
+
 __global__ void k_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < B) dh_init_state_channel(dsp_state, state_words, tail0, dec_state, slot_filter, ch);
@@ -316,7 +321,8 @@ struct HipBackend {
         if (proto == DH_PROTO_DMR) hipLaunchKernelGGL(k_dmr, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
         else if (proto == DH_PROTO_YSF) hipLaunchKernelGGL(k_ysf, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
         else if (proto == DH_PROTO_NXDN) hipLaunchKernelGGL(k_nxdn, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
-        else hipLaunchKernelGGL(k_pocsag, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
+        else if (proto == DH_PROTO_POCSAG) hipLaunchKernelGGL(k_pocsag, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
+        else hipLaunchKernelGGL(k_dstar, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
         return launched("k_decoder");
     }
     int launch_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {

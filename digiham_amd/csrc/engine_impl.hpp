@@ -42,7 +42,7 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     if (c.n_channels == 0 || c.max_samples == 0) return DH_EINVAL;
     if (c.rrc < DH_RRC_NONE || c.rrc > DH_RRC_NARROW) return DH_EINVAL;
     if (c.demod != DH_DEMOD_NONE && c.demod != DH_DEMOD_FSK2 && c.demod != DH_DEMOD_GFSK4) return DH_EINVAL;
-    if (c.proto < DH_PROTO_NONE || c.proto > DH_PROTO_POCSAG) return DH_EINVAL;
+    if (c.proto < DH_PROTO_NONE || c.proto > DH_PROTO_DSTAR) return DH_EINVAL;
     if (c.demod != DH_DEMOD_NONE && (c.sps < 3 || c.sps > DH_MAX_SPS)) return DH_EINVAL;
     if (c.demod == DH_DEMOD_NONE && c.rrc == DH_RRC_NONE && c.proto == DH_PROTO_NONE) return DH_EINVAL;
     L.B = c.n_channels; L.max_samples = c.max_samples; L.sps = c.demod ? c.sps : 1;
@@ -56,11 +56,12 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     L.sym_cap = L.demod ? (L.max_samples + DH_TAIL_MAX) / (L.sps - 1) + 4 : L.max_samples;
     L.sym_stride = round_up(L.sym_cap, 64);
     L.state_words = round_up(dh_state_words(L.sps), 16);
-    const uint32_t max_syms = DH_SYM_CARRY_MAX + L.sym_cap;
+    const uint32_t max_syms = dh_carry_max(L.proto) + L.sym_cap;
     if (L.proto == DH_PROTO_DMR) { L.out_cap = (max_syms / 144 + 1) * 27; L.ev_cap = (max_syms / 144 + 1) * 4 + 8; }
     else if (L.proto == DH_PROTO_YSF) { L.out_cap = (max_syms / 480 + 1) * 95; L.ev_cap = (max_syms / 480 + 1) * 5 + 8; }
     else if (L.proto == DH_PROTO_NXDN) { L.out_cap = (max_syms / 192 + 1) * 36; L.ev_cap = (max_syms / 192 + 1) * 7 + 8; }
     else if (L.proto == DH_PROTO_POCSAG) { L.out_cap = max_syms / 2 + 256; L.ev_cap = max_syms / 32 + 8; }
+    else if (L.proto == DH_PROTO_DSTAR) { L.out_cap = (max_syms / 96 + 1) * 9; L.ev_cap = max_syms / 32 + 16; }
     else { L.out_cap = 0; L.ev_cap = 0; }
     L.out_cap = round_up(L.out_cap, 64);
     return DH_OK;
@@ -125,7 +126,7 @@ struct Engine {
         if (L.demod) DH_ALLOC(syms, uint8_t, B * L.sym_stride);
         if (L.proto) {
             DH_ALLOC(dec_state, uint32_t, B * DH_DEC_STATE_WORDS);
-            DH_ALLOC(sym_carry, uint8_t, B * DH_SYM_CARRY_MAX);
+            DH_ALLOC(sym_carry, uint8_t, B * dh_carry_max(L.proto));
             DH_ALLOC(frames, uint8_t, B * (size_t) L.out_cap);
             DH_ALLOC(frame_count, uint32_t, B);
             DH_ALLOC(ev_count, uint32_t, B);
@@ -156,7 +157,7 @@ struct Engine {
     int reset() {
         int rc = be.zero(overflow, sizeof(uint32_t) * 16);
         rc |= be.zero(sym_count, sizeof(uint32_t) * L.B);
-        if (sym_carry) rc |= be.zero(sym_carry, (size_t) L.B * DH_SYM_CARRY_MAX);
+        if (sym_carry) rc |= be.zero(sym_carry, (size_t) L.B * dh_carry_max(L.proto));
         if (dsp_state) rc |= be.zero(dsp_state, sizeof(uint32_t) * L.B * L.state_words);
         if (syms) rc |= be.zero(syms, L.B * L.sym_stride);
         if (dec_state) rc |= be.zero(dec_state, sizeof(uint32_t) * L.B * DH_DEC_STATE_WORDS);
@@ -177,7 +178,7 @@ struct Engine {
 
     void fill_dec_params(const uint8_t* d_syms, size_t stride, const uint32_t* d_count) {
         dec.syms = d_syms; dec.sym_stride = stride; dec.sym_count = d_count;
-        dec.carry = sym_carry; dec.carry_stride = DH_SYM_CARRY_MAX;
+        dec.carry = sym_carry; dec.carry_stride = dh_carry_max(L.proto);
         dec.state = dec_state; dec.state_stride = DH_DEC_STATE_WORDS;
         dec.out = frames; dec.out_stride = L.out_cap; dec.out_cap = L.out_cap; dec.out_count = frame_count;
         dec.events = events; dec.ev_stride = L.ev_cap; dec.ev_cap = L.ev_cap; dec.ev_count = ev_count;

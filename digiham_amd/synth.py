@@ -472,12 +472,182 @@ def pocsag_stream(seed, n_messages, lead_in=37):
     return np.array(out, np.uint8), sent
 
 
+# ----------------------------------------------------------------------------- D-Star
+DSTAR_FRAME_SYNC = [1, 1, 1, 0, 1, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0]                     # JARL D-STAR 2.1.1 frame sync
+DSTAR_VOICE_SYNC = [1, 0] * 5 + [1, 1, 0, 1, 0, 0, 0] * 2                             # data-frame sync pattern
+DSTAR_TERMINATOR = [1, 0] * 16 + [0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0]     # end pattern (+ one bit)
+
+
+def dstar_pn(n):
+    """Whitening sequence x^7 + x^4 + 1 from the all-ones state."""
+    sr = 0x7F
+    out = np.zeros(n, np.uint8)
+    for i in range(n):
+        wb = (sr & 1) ^ ((sr >> 3) & 1)
+        out[i] = wb
+        sr = ((sr & 0x7E) >> 1) | (wb << 6)
+    return out
+
+
+def dstar_crc(data):
+    """CRC-CCITT, reflected (0x8408), preset and inverted: the radio header's P_FCS."""
+    c = 0xFFFF
+    for b in bytes(data):
+        for i in range(8):
+            c ^= (b >> i) & 1
+            c = (c >> 1) ^ 0x8408 if c & 1 else c >> 1
+    return c ^ 0xFFFF
+
+
+def dstar_header_bytes(rpt2, rpt1, your, my, suffix="", flags=(0, 0, 0)):
+    """The 41-byte radio header: 3 flag bytes, destination / departure repeater, companion, own callsign + suffix, FCS."""
+    f = lambda t, n: t.encode("latin-1")[:n].ljust(n, b" ")
+    h = bytes(flags) + f(rpt2, 8) + f(rpt1, 8) + f(your, 8) + f(my, 8) + f(suffix, 4)
+    c = dstar_crc(h)
+    return h + bytes([c & 0xFF, c >> 8])
+
+
+def dstar_header_bits(h41):
+    """Header bytes -> the 660 transmitted bits: rate-1/2 K=3 convolutional code (bits LSB first, two tail bits),
+    24-column interleave, whitening."""
+    bits = np.concatenate([np.unpackbits(np.frombuffer(bytes(h41), np.uint8), bitorder="little"), [0, 0]]).astype(np.uint8)
+    coded = np.zeros(660, np.uint8)
+    b1 = b2 = 0
+    for n, b in enumerate(bits):
+        coded[2 * n] = b ^ b1 ^ b2
+        coded[2 * n + 1] = b ^ b2
+        b2, b1 = b1, int(b)
+    tx = np.zeros(660, np.uint8)
+    for i in range(12):
+        for k in range(28):
+            tx[i * 28 + k] = coded[k * 24 + i]
+    for i in range(12, 24):
+        for k in range(27):
+            tx[12 + i * 27 + k] = coded[k * 24 + i]
+    return tx ^ dstar_pn(660)
+
+
+def dstar_slow_blocks(message=None, header=None, simple=b""):
+    """6-byte slow-data blocks (mini header + 5 bytes): the 20-character message (0x40-0x43), the header copy (0x55 / 0x51),
+    simple data such as DPRS / NMEA sentences (0x3n)."""
+    blocks = []
+    if message is not None:
+        m = message.encode("latin-1")[:20].ljust(20, b" ")
+        blocks += [bytes([0x40 + i]) + m[5 * i:5 * i + 5] for i in range(4)]
+    if header is not None:
+        for i in range(0, 41, 5):
+            part = bytes(header[i:i + 5])
+            blocks.append(bytes([0x50 + len(part)]) + part.ljust(5, b"\x66"))
+    for i in range(0, len(simple), 5):
+        part = bytes(simple[i:i + 5])
+        blocks.append(bytes([0x30 + len(part)]) + part.ljust(5, b"\x66"))
+    return blocks
+
+
+def dstar_dprs_sentence(text):
+    body = (text + "\r").encode("latin-1")
+    return b"$$CRC%04X," % dstar_crc(body) + body
+
+
+def dstar_gga_sentence(lat, lon):
+    """$GPGGA with the given position (degrees, positive north / east)."""
+    def dm(v, w):
+        a = abs(v); d = int(a); m = (a - d) * 60
+        return "%0*d%07.4f" % (w, d, m)
+    body = "GPGGA,123519,%s,%s,%s,%s,1,08,0.9,545.4,M,46.9,M,," % (dm(lat, 2), "N" if lat >= 0 else "S", dm(lon, 3), "E" if lon >= 0 else "W")
+    cs = 0
+    for ch in body.encode():
+        cs ^= ch
+    return ("$%s*%02X\r\n" % (body, cs)).encode()
+
+
+def dstar_voice_frames(rng, superframes, trailing_sync=True):
+    """Voice superframes of 21 frames (72 random AMBE bits + a 24-bit data frame): a sync frame, then 20 whitened
+    slow-data frames carrying that superframe's (up to 10) blocks, filler 0x66 after them.  The receiver evaluates a
+    superframe's slow data at the NEXT sync frame, hence the trailing one.  Returns (bits, voice bytes)."""
+    pn24 = dstar_pn(24)
+    bits, voice = [], []
+    for sf, blocks in enumerate(list(superframes) + ([None] if trailing_sync else [])):
+        queue = list(blocks or [])
+        for f in range(21 if blocks is not None else 1):
+            v = rng.integers(0, 2, 72).astype(np.uint8)
+            voice.append(np.packbits(v, bitorder="little"))
+            bits.append(v)
+            if f == 0:
+                bits.append(np.array(DSTAR_VOICE_SYNC, np.uint8))
+                continue
+            if f % 2 == 1:
+                cur = queue.pop(0) if queue else b"\x66" * 6
+            half = cur[:3] if f % 2 == 1 else cur[3:]
+            bits.append(np.unpackbits(np.frombuffer(half, np.uint8), bitorder="little") ^ pn24)
+    return np.concatenate(bits), voice
+
+
+def dstar_transmission(rng, my="DL1ABC", your="CQCQCQ", rpt1="DB0XYZ B", rpt2="DB0XYZ G", suffix="ID51", message="hello d-star world",
+                       n_superframes=3, simple=b"", with_header=True, inline_header=True, data_flag=False):
+    """Bit sync + frame sync + radio header, then superframes that alternate message (+ simple data) and the header copy,
+    then the end pattern in place of the last data frame."""
+    h = dstar_header_bytes(rpt2, rpt1, your, my, suffix, flags=(0x80 if data_flag else 0, 0, 0))
+    bits = []
+    if with_header:
+        bits += [np.array([1, 0] * 32 + DSTAR_FRAME_SYNC, np.uint8), dstar_header_bits(h)]
+    pending = dstar_slow_blocks(None, None, simple)
+    sfs = []
+    for i in range(n_superframes):
+        if i % 2 == 1 and inline_header:
+            sfs.append(dstar_slow_blocks(None, h))
+        else:
+            blocks = dstar_slow_blocks(message) + pending[:6]
+            pending = pending[6:]
+            sfs.append(blocks)
+    vb, voice = dstar_voice_frames(rng, sfs)
+    if not with_header:
+        vb = vb[72:]                                                   # late entry: the receiver first sees a data-frame sync
+        voice = voice[1:]
+    last = rng.integers(0, 2, 72).astype(np.uint8)
+    voice.append(np.packbits(last, bitorder="little"))
+    bits += [vb, last, np.array(DSTAR_TERMINATOR, np.uint8)]
+    return np.concatenate(bits), h, voice
+
+
+def dstar_stream(seed, n_transmissions, lead_in=41, ber=0.0):
+    """Transmissions (header + voice superframes with slow data + terminator) separated by noise bits; some enter late
+    (no header), some carry a DPRS / NMEA position, some have a damaged or a data header.  Returns (bits, infos)."""
+    rng = np.random.default_rng(seed)
+    out = [rng.integers(0, 2, lead_in).astype(np.uint8)]
+    infos = []
+    for t in range(n_transmissions):
+        kind = int(rng.integers(0, 8))
+        my = "".join(chr(int(c)) for c in rng.integers(65, 91, 6))
+        msg = "".join(chr(int(c)) for c in rng.integers(32, 127, int(rng.integers(5, 21))))
+        simple = b""
+        if kind in (1, 5):
+            simple = dstar_dprs_sentence("%s>APDPRS,DSTAR*:!4916.45N/01131.00E>test %d" % (my, t))
+        elif kind == 2:
+            simple = dstar_gga_sentence(float(rng.uniform(-80, 80)), float(rng.uniform(-170, 170)))
+        nsf = int(rng.integers(1, 5))
+        if simple:
+            nsf = max(nsf, 2 * (-(-len(simple) // 30)) - 1)            # 30 simple-data bytes per message superframe
+        b, h, voice = dstar_transmission(rng, my=my, message=msg, n_superframes=nsf, simple=simple,
+                                         with_header=kind != 3, inline_header=kind != 4, data_flag=kind == 6)
+        if kind == 7:                                                  # a header beyond repair: 40 errors in its 660 bits
+            at = 64 + 15 + rng.choice(660, 40, replace=False)
+            b = b.copy(); b[at] ^= 1
+        infos.append({"kind": kind, "my": my, "message": msg, "header": h, "simple": simple, "frames": len(voice)})
+        out += [b, rng.integers(0, 2, int(rng.integers(30, 400))).astype(np.uint8)]
+    bits = np.concatenate(out)
+    if ber > 0:
+        bits = bits ^ (rng.random(bits.size) < ber).astype(np.uint8)
+    return bits, infos
+
+
 def fsk_shape(bits, sps=40, amplitude=0.4, invert=False):
     """Two-level FSK discriminator audio: bit 1 above the centre (below with `invert`, as POCSAG is received:
     examples/pocsag-decoder.sh, fsk_demodulator -i), lightly low-passed edges."""
     lv = np.where(np.asarray(bits) > 0, 1.0, -1.0) * (-1.0 if invert else 1.0)
     x = np.repeat(lv, sps)
-    k = np.ones(max(sps // 8, 1)) / max(sps // 8, 1)
+    w = max(sps // 8, min(5, sps // 2), 1)              # without sloped edges every sampling phase looks alike to the slicer
+    k = np.ones(w) / w
     return (amplitude * np.convolve(x, k, mode="same")).astype(np.float32)
 
 

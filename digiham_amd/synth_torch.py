@@ -18,6 +18,11 @@ def periodic_streams(proto, n_units, U, seed=1000):
             s = synth.dmr_stream(seed + u, n_units, two_slots=(u % 2 == 0), lead_in=0)
         elif proto == "nxdn":
             s = synth.nxdn_stream(seed + u, n_units, lead_in=0)
+        elif proto == "dstar":                       # n_units 96-bit frames of transmissions and noise gaps
+            s = synth.dstar_stream(seed + u, n_units // 40 + 2, lead_in=0)[0]
+            while len(s) < n_units * 96:
+                s = np.concatenate([s, synth.dstar_stream(seed + u + 7777, n_units // 40 + 2, lead_in=0)[0]])
+            s = s[:n_units * 96]
         else:
             s = synth.ysf_stream(seed + u, n_units, mode="vd2", lead_in=0)
         out.append(s)
@@ -32,10 +37,14 @@ def make_batch(torch, device, proto, B, n_units, U=64, seed=1000, sps=10, amplit
     U = syms.shape[0]
     S = syms.shape[1]
     T = S * sps
-    lv = torch.tensor(synth.LEVELS, device=device)[torch.from_numpy(syms.astype(np.int64)).to(device)]      # [U][S]
+    levels = np.array([-1.0, 1.0], np.float32) if proto == "dstar" else synth.LEVELS              # bit 1 above the centre
+    lv = torch.tensor(levels, device=device)[torch.from_numpy(syms.astype(np.int64)).to(device)]      # [U][S]
     imp = torch.zeros((U, T), dtype=torch.float32, device=device)
     imp[:, ::sps] = lv
-    g = (_taps.narrow() if proto == "nxdn" else _taps.wide()).astype(np.float64)
+    if proto == "dstar":                                 # NRZ with sloped edges (synth.fsk_shape), no TX RRC
+        g = np.convolve(np.ones(sps), np.ones(5) / 5.0)
+    else:
+        g = (_taps.narrow() if proto == "nxdn" else _taps.wide()).astype(np.float64)
     g = (g / g.sum() * sps).astype(np.float32)
     gp = torch.zeros(T, dtype=torch.float32, device=device)
     gp[:len(g)] = torch.from_numpy(g).to(device)
@@ -45,7 +54,7 @@ def make_batch(torch, device, proto, B, n_units, U=64, seed=1000, sps=10, amplit
     x = torch.empty((B, T), dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    burst = {"dmr": 144, "ysf": 480, "nxdn": 192}[proto] * sps
+    burst = {"dmr": 144, "ysf": 480, "nxdn": 192, "dstar": 96}[proto] * sps
     for c0 in range(0, B, chunk):
         c1 = min(B, c0 + chunk)
         for ch in range(c0, c1):

@@ -16,6 +16,7 @@
 #include "dmr_meta.hpp"
 #include "ysf_meta.hpp"
 #include "nxdn_meta.hpp"
+#include "dstar_meta.hpp"
 
 #define BUF_SIZE 128
 #define RINGBUFFER_SIZE 1024
@@ -59,6 +60,7 @@ namespace Digiham {
                 if (proto == DH_PROTO_POCSAG) { delete meta; return; }        // no collector: the writer is released (decoder.cpp:34-38)
                 if (!metaCollector) metaCollector = proto == DH_PROTO_DMR ? (MetaCollector*) new Dmr::MetaCollector()
                                                   : proto == DH_PROTO_YSF ? (MetaCollector*) new Ysf::MetaCollector()
+                                                  : proto == DH_PROTO_DSTAR ? (MetaCollector*) new DStar::MetaCollector()
                                                   : (MetaCollector*) new Nxdn::MetaCollector();
                 metaCollector->setWriter(meta);
             }
@@ -122,6 +124,15 @@ namespace Digiham {
                     if (s == nullptr) { delete serializer; throw std::invalid_argument("Digiham::Pocsag::Decoder: only the StringSerializer format is available"); }
                     delete s;
                 }
+        };
+
+    }
+
+    namespace DStar {
+
+        class Decoder: public Digiham::Decoder {          // include/dstar_decoder.hpp, dstar_decoder.cpp:7-9
+            public:
+                Decoder(): Digiham::Decoder(DH_PROTO_DSTAR) {}
         };
 
     }

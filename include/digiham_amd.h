@@ -97,7 +97,7 @@ typedef struct dh_engine dh_engine;
 
 enum { DH_RRC_NONE = 0, DH_RRC_WIDE = 1, DH_RRC_NARROW = 2 };
 enum { DH_DEMOD_NONE = 0, DH_DEMOD_FSK2 = 2, DH_DEMOD_GFSK4 = 4 };
-enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3, DH_PROTO_POCSAG = 4 };
+enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3, DH_PROTO_POCSAG = 4, DH_PROTO_DSTAR = 5 };
 
 /* flags */
 #define DH_FLAG_FAST_FIR        0x1   /* FMA FIR: float outputs within 1e-6 of the reference, dibits NOT guaranteed bit-exact */
@@ -142,7 +142,15 @@ enum {
     DH_EV_NXDN_LICH = 32, DH_EV_NXDN_SACCH = 33, DH_EV_NXDN_SACCH_SF = 34, DH_EV_NXDN_SYNC_VOICE = 35,
     DH_EV_NXDN_FACCH1 = 36, DH_EV_NXDN_META_RESET = 37,
     /* POCSAG (src/pocsag_decoder/pocsag_phase.cpp:56-57): a = position in the batch, payload = BCH-corrected codeword (big endian) */
-    DH_EV_POCSAG_CODEWORD = 48
+    DH_EV_POCSAG_CODEWORD = 48,
+    /* D-Star (src/dstar_decoder/dstar_phase.cpp): HEADER = setFromHeader of a CRC-valid voice header, 41 bytes over two
+     * events (a = 0: bytes 0-23, a = 1: bytes 24-40; b = 0 radio header (:50), 1 slow-data header (:214)); VOICE_START =
+     * a new VoicePhase (b = 1 after a header, 0 after a voice sync); SYNC_VOICE = setSync("voice") (:110); MESSAGE = the
+     * 20-character slow-data message (:207); SIMPLE = len simple-data bytes appended (:178); FRAME_SYNC = parseFrameData
+     * (:113): the consumer now parses its simple-data lines (DPRS / NMEA, :218-245); META_RESET = MetaCollector::reset
+     * (b = 0 terminator, 1 sync lost) */
+    DH_EV_DSTAR_HEADER = 64, DH_EV_DSTAR_VOICE_START = 65, DH_EV_DSTAR_SYNC_VOICE = 66, DH_EV_DSTAR_MESSAGE = 67,
+    DH_EV_DSTAR_SIMPLE = 68, DH_EV_DSTAR_FRAME_SYNC = 69, DH_EV_DSTAR_META_RESET = 70
 };
 
 int  dh_engine_create(const dh_engine_config* cfg, dh_engine** out);

@@ -12,7 +12,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { PROTO_DMR = 1, PROTO_YSF = 2, PROTO_NXDN = 3, PROTO_POCSAG = 4 };
+enum { PROTO_DMR = 1, PROTO_YSF = 2, PROTO_NXDN = 3, PROTO_POCSAG = 4, PROTO_DSTAR = 5 };
+enum { PH_HEADER = 2 };                 /* D-Star's third phase (dstar_phase.hpp:50) */
 enum { PH_SYNC = 0, PH_FRAME = 1 };
 
 /* ---- DMR constants: src/dmr_decoder/dmr_phase.hpp:6-12,25-33 */
@@ -68,6 +69,8 @@ struct orc_decoder {
     int lich; uint8_t sacch_have; uint8_t sacch_data[4][4];
     /* Pocsag::CodewordPhase (pocsag_phase.hpp:27-36; syncCount shares sync_count) + its Message (message.hpp:11-23) */
     int codeword_counter, has_message; uint32_t msg_address; uint8_t msg_type; int msg_pos; char msg_content[80];
+    /* DStar::VoicePhase (dstar_phase.hpp:67-77; syncCount shares sync_count); simpleData lives with the event consumer */
+    int frame_count; uint8_t collected_data[6], ds_message[20], ds_message_blocks, ds_header[41], ds_header_count;
 };
 
 static void emit(orc_decoder* d, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, uint8_t len) {
@@ -118,6 +121,12 @@ orc_decoder* orc_nxdn_new(void) {
 orc_decoder* orc_pocsag_new(void) {
     orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
     d->proto = PROTO_POCSAG; d->phase = PH_SYNC;
+    return d;
+}
+
+orc_decoder* orc_dstar_new(void) {
+    orc_decoder* d = (orc_decoder*) calloc(1, sizeof(orc_decoder));
+    d->proto = PROTO_DSTAR; d->phase = PH_SYNC;
     return d;
 }
 
@@ -698,6 +707,107 @@ static size_t pocsag_step(orc_decoder* d, const uint8_t* p, int* to_sync) {
     return POCSAG_CODEWORD_SIZE;
 }
 
+/* ================================================================ D-Star */
+/* dstar_phase.hpp:12-13,18-41 */
+#define DSTAR_SYNC_SIZE 24
+#define DSTAR_TERMINATOR_SIZE 48
+#define DSTAR_HEADER_BITS 660
+#define DSTAR_VOICE_REQUIRED (72 + 24 + 24)
+static const uint8_t dstar_header_sync[24] = { 0,1,0,1,0,1,0,1,0, 1,1,1,0,1,1,0,0,1,0,1,0,0,0,0 };
+static const uint8_t dstar_voice_sync[24]  = { 1,0,1,0,1,0,1,0,1,0, 1,1,0,1,0,0,0, 1,1,0,1,0,0,0 };
+static const uint8_t dstar_terminator[48]  = { 1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,
+                                               0,0,0,1,0,0,1,1,0,1,0,1,1,1,1,0 };
+
+/* the two VoicePhase constructors (dstar_phase.cpp:60-70) + member initialisers (dstar_phase.hpp:71-76) */
+static void enter_dstar_voice_phase(orc_decoder* d, int after_header) {
+    d->frame_count = after_header ? 21 : 0;
+    d->sync_count = after_header ? 1 : 0;
+    memset(d->collected_data, 0, 6); memset(d->ds_message, 0, 20); memset(d->ds_header, 0, 41);
+    d->ds_message_blocks = 0; d->ds_header_count = 0;
+    emit(d, ORC_EV_DSTAR_VOICE_START, 0, (uint8_t) after_header, NULL, 0);    /* a new, empty simpleData */
+}
+
+/* MetaCollector::setFromHeader(header) as two events (41 bytes do not fit one payload) */
+static void dstar_emit_header(orc_decoder* d, const uint8_t* h41, uint8_t source) {
+    emit(d, ORC_EV_DSTAR_HEADER, 0, source, h41, 24);
+    emit(d, ORC_EV_DSTAR_HEADER, 1, source, h41 + 24, 17);
+}
+
+/* VoicePhase::collectDataFrame (dstar_phase.cpp:153-203) */
+static void dstar_collect_data_frame(orc_decoder* d, const uint8_t* data3) {
+    memcpy(d->collected_data + (d->frame_count % 2) * 3, data3, 3);
+    if (d->frame_count % 2 == 0) return;
+    const uint8_t* c = d->collected_data;
+    const int n = c[0] & 0x0F;
+    switch (c[0] >> 4) {
+        case 0x04:
+            if (n > 3) break;
+            memcpy(d->ds_message + n * 5, c + 1, 5);
+            d->ds_message_blocks |= (uint8_t) (1 << n);
+            break;
+        case 0x05:
+            if (n > 5) break;
+            if (d->ds_header_count + n > 41) break;
+            memcpy(d->ds_header + d->ds_header_count, c + 1, (size_t) n);
+            d->ds_header_count = (uint8_t) (d->ds_header_count + n);
+            break;
+        case 0x03:
+            if (n > 5) break;
+            emit(d, ORC_EV_DSTAR_SIMPLE, 0, 0, c + 1, (uint8_t) n);           /* simpleData += ... (:178) */
+            break;
+        default: break;                                                        /* reserved / unknown: only a log line */
+    }
+}
+
+/* VoicePhase::parseFrameData (:205-216; the simpleData line parser runs at the consumer on DSTAR_FRAME_SYNC) */
+static void dstar_parse_frame_data(orc_decoder* d) {
+    if (d->ds_message_blocks == 0x0F) emit(d, ORC_EV_DSTAR_MESSAGE, 0, 0, d->ds_message, 20);
+    if (d->ds_header_count == 41 && orc_dstar_header_crc_ok(d->ds_header)) dstar_emit_header(d, d->ds_header, 1);
+    emit(d, ORC_EV_DSTAR_FRAME_SYNC, 0, 0, NULL, 0);
+}
+
+/* VoicePhase::process (dstar_phase.cpp:76-139).  Returns the bits consumed; *to_sync = 1 when it returns a SyncPhase. */
+static size_t dstar_voice(orc_decoder* d, const uint8_t* p, int* to_sync) {
+    *to_sync = 0;
+    if (d->sync_count >= 1) {
+        if (d->out_n + 9 > d->out_cap) { d->overflow = 1; return 0; }
+        uint8_t* o = d->out + d->out_n;
+        memset(o, 0, 9);
+        for (int i = 0; i < 72; i++) o[i / 8] |= (uint8_t) ((p[i] & 1) << (i % 8));
+        d->out_n += 9;
+    }
+    const uint8_t* data_frame = p + 72;
+    if (orc_hamming_distance(data_frame, dstar_terminator, DSTAR_TERMINATOR_SIZE) <= 1 ||
+        orc_hamming_distance(data_frame, dstar_terminator + 24, DSTAR_TERMINATOR_SIZE - 24) <= 1) {
+        emit(d, ORC_EV_DSTAR_META_RESET, 0, 0, NULL, 0);
+        *to_sync = 1;
+        return 72 + 24 + 24;
+    }
+    if (d->frame_count >= 20) {                                               /* isSyncDue (:141-143) */
+        if (orc_hamming_distance(data_frame, dstar_voice_sync, DSTAR_SYNC_SIZE) > 1) {
+            if (--d->sync_count < 0) {
+                emit(d, ORC_EV_DSTAR_META_RESET, 0, 1, NULL, 0);
+                *to_sync = 1;
+                return 72 + 24;
+            }
+        } else {
+            if (++d->sync_count > 3) d->sync_count = 3;
+            if (d->sync_count > 1) emit(d, ORC_EV_DSTAR_SYNC_VOICE, 0, 0, NULL, 0);
+        }
+        dstar_parse_frame_data(d);
+        d->frame_count = 0;                                                   /* resetFrames (:145-151) */
+        memset(d->ds_message, 0, 20); d->ds_message_blocks = 0;
+        memset(d->ds_header, 0, 41); d->ds_header_count = 0;
+    } else {
+        uint8_t sr = 0x7F, descrambled[24], bytes[3] = { 0, 0, 0 };           /* scrambler->reset() (:120) */
+        orc_dstar_scramble(&sr, data_frame, descrambled, 24);
+        for (int i = 0; i < 24; i++) bytes[i / 8] |= (uint8_t) (descrambled[i] << (i % 8));
+        dstar_collect_data_frame(d, bytes);
+        d->frame_count++;
+    }
+    return 72 + 24;
+}
+
 /* ============================================ Digiham::Decoder main loop */
 /* `while (canProcess()) process()` with canProcess = available > required
  * (src/lib/decoder.cpp:21-32; cli.cpp:29-33) */
@@ -734,6 +844,34 @@ size_t orc_decoder_process(orc_decoder* d, const uint8_t* in, size_t n,
                 const size_t used = pocsag_step(d, p, &to_sync);
                 pos += used; d->consumed += used;
                 if (to_sync) { d->phase = PH_SYNC; d->has_message = 0; }
+            }
+        } else if (d->proto == PROTO_DSTAR) {
+            if (d->phase == PH_SYNC) {
+                if (!(avail > DSTAR_SYNC_SIZE)) break;                       /* dstar_phase.hpp:46 */
+                if (orc_hamming_distance(p, dstar_header_sync, DSTAR_SYNC_SIZE) <= 2) {        /* dstar_phase.cpp:20-23 */
+                    pos += DSTAR_SYNC_SIZE; d->consumed += DSTAR_SYNC_SIZE; d->phase = PH_HEADER;
+                } else if (orc_hamming_distance(p, dstar_voice_sync, DSTAR_SYNC_SIZE) <= 1) {  /* :25-28 */
+                    pos += DSTAR_SYNC_SIZE; d->consumed += DSTAR_SYNC_SIZE; d->phase = PH_FRAME;
+                    enter_dstar_voice_phase(d, 0);
+                } else { pos++; d->consumed++; }
+            } else if (d->phase == PH_HEADER) {
+                if (!(avail > DSTAR_HEADER_BITS)) break;                     /* dstar_phase.hpp:52 */
+                uint8_t h[41];
+                if (!orc_dstar_header_parse(p, h)) {                         /* dstar_phase.cpp:39-44 */
+                    pos++; d->consumed++; d->phase = PH_SYNC;
+                } else {
+                    pos += DSTAR_HEADER_BITS; d->consumed += DSTAR_HEADER_BITS;
+                    if (!((h[0] >> 7) & 1)) {                                /* isVoice (:48-54) */
+                        dstar_emit_header(d, h, 0);
+                        d->phase = PH_FRAME; enter_dstar_voice_phase(d, 1);
+                    } else d->phase = PH_SYNC;
+                }
+            } else {
+                if (!(avail > DSTAR_VOICE_REQUIRED)) break;                  /* dstar_phase.hpp:62 */
+                int to_sync;
+                const size_t used = dstar_voice(d, p, &to_sync);
+                pos += used; d->consumed += used;
+                if (to_sync) d->phase = PH_SYNC;
             }
         } else if (d->proto == PROTO_NXDN) {
             if (d->phase == PH_SYNC) {

@@ -111,6 +111,14 @@ enum {
     ORC_EV_NXDN_SYNC_VOICE = 35, /* MetaCollector::setSync("voice")                  nxdn_phase.cpp:141 */
     ORC_EV_NXDN_FACCH1     = 36, /* a=block (0/1) payload=12 bytes (CRC ok)          nxdn_phase.cpp:152-154 */
     ORC_EV_NXDN_META_RESET = 37, /* b=0 sync loss, 1 TX_RELEASE                      nxdn_phase.cpp:51,157 */
+    ORC_EV_DSTAR_HEADER      = 64, /* a=part (0: bytes 0-23, 1: bytes 24-40) b=0 radio header / 1 slow-data header; valid
+                                      voice headers only: setFromHeader            dstar_phase.cpp:50, 214 */
+    ORC_EV_DSTAR_VOICE_START = 65, /* b=1 after a header, 0 after a voice sync: a new VoicePhase   dstar_phase.cpp:27,52 */
+    ORC_EV_DSTAR_SYNC_VOICE  = 66, /* setSync("voice")                               dstar_phase.cpp:110 */
+    ORC_EV_DSTAR_MESSAGE     = 67, /* payload=20 bytes                               dstar_phase.cpp:207 */
+    ORC_EV_DSTAR_SIMPLE      = 68, /* payload=len simple-data bytes appended         dstar_phase.cpp:178 */
+    ORC_EV_DSTAR_FRAME_SYNC  = 69, /* parseFrameData(): the consumer parses its simple-data lines  dstar_phase.cpp:113,220 */
+    ORC_EV_DSTAR_META_RESET  = 70, /* b=0 terminator, 1 sync lost                    dstar_phase.cpp:97,105 */
     ORC_EV_POCSAG_CODEWORD = 48, /* a=position in the batch payload=corrected word, big endian  pocsag_phase.cpp:56-57 */
 };
 
@@ -119,6 +127,12 @@ bool orc_bch_31_21(uint32_t* data);
 uint32_t orc_bch_31_21_encode(uint32_t data21);
 uint32_t orc_bch_31_21_row(int k);
 int orc_pocsag_codeword_parse(const uint8_t* input32, uint32_t* out);
+
+/* ---------------------------------------------------------------- dstar.c */
+void orc_dstar_scramble(uint8_t* shift_register, const uint8_t* input, uint8_t* output, size_t len);
+uint16_t orc_dstar_crc(const uint8_t* data, size_t len);
+int orc_dstar_header_crc_ok(const uint8_t* decoded41);
+int orc_dstar_header_parse(const uint8_t* raw660, uint8_t* out41);
 
 /* ----------------------------------------------------------------- nxdn.c */
 void orc_nxdn_scramble(uint16_t* shift_register, const uint8_t* input, uint8_t* output, size_t len);
@@ -132,6 +146,7 @@ orc_decoder* orc_dmr_new(void);
 orc_decoder* orc_ysf_new(void);
 orc_decoder* orc_nxdn_new(void);
 orc_decoder* orc_pocsag_new(void);
+orc_decoder* orc_dstar_new(void);
 void orc_decoder_free(orc_decoder*);
 void orc_dmr_set_slot_filter(orc_decoder*, uint8_t filter);
 /* streaming: consumes symbols from in[0..n); returns symbols consumed.  Output
@@ -150,7 +165,7 @@ typedef struct {
     int levels;     /* 4 gfsk, 2 fsk, 0 = no demod */
     int invert;
     unsigned sps;
-    int proto;      /* 0 none, 1 DMR, 2 YSF, 3 NXDN, 4 POCSAG */
+    int proto;      /* 0 none, 1 DMR, 2 YSF, 3 NXDN, 4 POCSAG, 5 D-Star */
     int slot_filter;
 } orc_chain_cfg;
 

@@ -71,6 +71,12 @@ def _declare(L):
     L.orc_ysf_new.restype = vp
     L.orc_nxdn_new.restype = vp
     L.orc_pocsag_new.restype = vp
+    L.orc_dstar_new.restype = vp
+    L.orc_dstar_scramble.argtypes = [vp, vp, vp, C.c_size_t]
+    L.orc_dstar_crc.restype = C.c_uint16
+    L.orc_dstar_crc.argtypes = [vp, C.c_size_t]
+    L.orc_dstar_header_crc_ok.argtypes = [vp]
+    L.orc_dstar_header_parse.argtypes = [vp, vp]
     L.orc_bch_31_21_encode.restype = C.c_uint32
     L.orc_bch_31_21_encode.argtypes = [C.c_uint32]
     L.orc_nxdn_trellis_decode.restype = C.c_uint
@@ -250,7 +256,8 @@ class Decoder:
     """Streaming Dmr::Decoder / Ysf::Decoder; returns (output bytes, events) per call."""
 
     def __init__(self, proto):
-        self._h = {"dmr": lib().orc_dmr_new, "ysf": lib().orc_ysf_new, "nxdn": lib().orc_nxdn_new, "pocsag": lib().orc_pocsag_new}[proto]()
+        self._h = {"dmr": lib().orc_dmr_new, "ysf": lib().orc_ysf_new, "nxdn": lib().orc_nxdn_new, "pocsag": lib().orc_pocsag_new,
+                   "dstar": lib().orc_dstar_new}[proto]()
         self._tail = np.zeros(0, np.uint8)
 
     def set_slot_filter(self, f):
@@ -363,4 +370,54 @@ def nxdn_facch1(dibits72, which="oracle"):
     d = np.ascontiguousarray(dibits72, np.uint8)
     out = np.zeros(12, np.uint8)
     ok = (ref_nxdn().ref_nxdn_facch1_parse if which == "ref" else lib().orc_nxdn_facch1_parse)(_p(d), _p(out))
+    return bool(ok), out
+
+
+# ------------------------------------------------------------------ D-Star elements
+_REF_DSTAR = None
+
+
+def ref_dstar():
+    """oracle/_ref/libdigiham_ref_dstar.so: the reference's own D-Star Scrambler and Crc classes."""
+    global _REF_DSTAR
+    if _REF_DSTAR is None:
+        so = os.path.join(_HERE, "_ref", "libdigiham_ref_dstar.so")
+        if not os.path.exists(so):
+            return None
+        L = C.CDLL(so)
+        vp = C.c_void_p
+        L.ref_dstar_scramble.argtypes = [vp, vp, C.c_size_t]
+        L.ref_dstar_crc_valid.argtypes = [vp, C.c_size_t, C.c_ushort]
+        _REF_DSTAR = L
+    return _REF_DSTAR
+
+
+def dstar_scramble(bits, which="oracle"):
+    """Scrambler from its reset state over a run of bits (dstar_decoder/scrambler.cpp:7-21)."""
+    d = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros_like(d)
+    if which == "ref":
+        ref_dstar().ref_dstar_scramble(_p(d), _p(out), d.size)
+    else:
+        sr = C.c_uint8(0x7F)
+        lib().orc_dstar_scramble(C.byref(sr), _p(d), _p(out), d.size)
+    return out
+
+
+def dstar_crc(data):
+    d = np.ascontiguousarray(data, np.uint8)
+    return int(lib().orc_dstar_crc(_p(d), d.size))
+
+
+def dstar_crc_valid(data, checksum, which="oracle"):
+    d = np.ascontiguousarray(data, np.uint8)
+    if which == "ref":
+        return bool(ref_dstar().ref_dstar_crc_valid(_p(d), d.size, checksum))
+    return dstar_crc(d) == checksum
+
+
+def dstar_header_parse(raw660):
+    d = np.ascontiguousarray(raw660, np.uint8)
+    out = np.zeros(41, np.uint8)
+    ok = lib().orc_dstar_header_parse(_p(d), _p(out))
     return bool(ok), out

@@ -43,7 +43,7 @@ static int run_channel(job* j, size_t ch) {
         orc_demod_free(d);
         if (j->sym_count) j->sym_count[ch] = (uint32_t) ns;
         if (cfg->proto) {
-            orc_decoder* dec = cfg->proto == 1 ? orc_dmr_new() : cfg->proto == 2 ? orc_ysf_new() : cfg->proto == 3 ? orc_nxdn_new() : orc_pocsag_new();
+            orc_decoder* dec = cfg->proto == 1 ? orc_dmr_new() : cfg->proto == 2 ? orc_ysf_new() : cfg->proto == 3 ? orc_nxdn_new() : cfg->proto == 4 ? orc_pocsag_new() : orc_dstar_new();
             if (cfg->proto == 1) orc_dmr_set_slot_filter(dec, (uint8_t) cfg->slot_filter);
             size_t no = 0, ne = 0;
             orc_decoder_process(dec, s, ns,

@@ -83,7 +83,8 @@ struct HostBackend {
     int launch_decoder(const DhDecParams& P, int proto) {
         DhDecShared* S = new DhDecShared;
         for (uint32_t ch = 0; ch < P.n_channels; ch++) {
-            if (proto == DH_PROTO_DMR) dh_dmr_channel(P, ch, *S); else if (proto == DH_PROTO_YSF) dh_ysf_channel(P, ch, *S); else if (proto == DH_PROTO_NXDN) dh_nxdn_channel(P, ch, *S); else dh_pocsag_channel(P, ch, *S);
+            if (proto == DH_PROTO_DMR) dh_dmr_channel(P, ch, *S); else if (proto == DH_PROTO_YSF) dh_ysf_channel(P, ch, *S); else if (proto == DH_PROTO_NXDN) dh_nxdn_channel(P, ch, *S);
+            else if (proto == DH_PROTO_POCSAG) dh_pocsag_channel(P, ch, *S); else dh_dstar_channel(P, ch, *S);
         }
         delete S;
         return 0;

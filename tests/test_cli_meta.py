@@ -15,7 +15,7 @@ import pytest
 from digiham_amd import api, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOLS = ["rrc_filter", "gfsk_demodulator", "fsk_demodulator", "digitalvoice_filter", "dmr_decoder", "ysf_decoder", "nxdn_decoder", "pocsag_decoder"]
+TOOLS = ["rrc_filter", "gfsk_demodulator", "fsk_demodulator", "digitalvoice_filter", "dmr_decoder", "ysf_decoder", "nxdn_decoder", "pocsag_decoder", "dstar_decoder"]
 
 
 def _ev(type_, a=0, b=0, payload=b""):
@@ -178,6 +178,39 @@ def test_pocsag_pipe_like_the_example_script(oracle, tmp_path, gpu):
     assert len(want) > 0 and len(got) >= len(want) and (got[:len(want)] == want).all()
     lines = bytes(got).decode("latin1").split("\n")
     assert any(("address:%d;message:%s" % (a, t)) in lines for a, f, t in sent)
+
+
+@pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
+def test_dstar_pipe_like_the_example_script(oracle, tmp_path, gpu):
+    """examples/dstar-decoder.sh: fsk_demodulator -s 10 | dstar_decoder --fifo <meta>: voice frames on stdout, header fields,
+    the slow-data message, a DPRS sentence and an NMEA position on the metadata pipe."""
+    bindir = _build_tools(tmp_path, gpu)
+    rng = np.random.default_rng(9)
+    dprs = "DL1ABC>APDPRS,DSTAR*:!4916.45N/01131.00E>via d-star"
+    t1, _, _ = synth.dstar_transmission(rng, my="DL1ABC", suffix="ID51", message="Jakob, JN68", n_superframes=5,
+                                        simple=synth.dstar_dprs_sentence(dprs))
+    t2, _, _ = synth.dstar_transmission(rng, my="W1AW", suffix="", your="DL1ABC", message="position follows", n_superframes=5,
+                                        simple=synth.dstar_gga_sentence(-33.5, 151.25))
+    bits = np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), t1, rng.integers(0, 2, 300).astype(np.uint8), t2,
+                           rng.integers(0, 2, 400).astype(np.uint8)])
+    x = synth.impair(synth.fsk_shape(bits, sps=10), 5, snr_db=22, dc=0.03)
+    inp, meta, out = tmp_path / "in.f32", tmp_path / "meta.txt", tmp_path / "out.bin"
+    x.astype(np.float32).tofile(inp)
+    cmd = "%s/fsk_demodulator -s 10 < %s | %s/dstar_decoder --fifo %s > %s" % (bindir, inp, bindir, meta, out)
+    subprocess.run(["bash", "-o", "pipefail", "-c", cmd], check=True, stderr=subprocess.DEVNULL)
+    ref = oracle.chain(x[None, :], rrc=0, levels=2, sps=10, proto=5)
+    want = ref["out"][0, :ref["out_count"][0]]
+    got = np.fromfile(out, np.uint8)
+    assert len(want) > 200 * 9 and len(got) >= len(want) and (got[:len(want)] == want).all()
+    lines = meta.read_text().splitlines()
+    head = "departure:DB0XYZ B;destination:DB0XYZ G;ourcall:DL1ABC/ID51;protocol:DSTAR;sync:voice;yourcall:CQCQCQ"
+    assert head in lines, lines
+    assert "departure:DB0XYZ B;destination:DB0XYZ G;message:Jakob, JN68         ;ourcall:DL1ABC/ID51;protocol:DSTAR;sync:voice;yourcall:CQCQCQ" in lines
+    assert any(";dprs:%s;" % dprs in l and "ourcall:DL1ABC/ID51" in l for l in lines), lines
+    assert "protocol:DSTAR" in lines                                       # MetaCollector::reset() at the end pattern
+    assert any("ourcall:W1AW;" in l and "yourcall:DL1ABC" in l for l in lines)
+    pos = [l for l in lines if ";lat:" in l]
+    assert pos and all("lat:-33.5" in l and "lon:151.25" in l for l in pos), pos
 
 
 def test_cli_tools_fail_loudly_without_a_device():

@@ -17,12 +17,12 @@ def _digest(rows, counts):
     return [hashlib.sha256(rows[b, :counts[b]].tobytes()).hexdigest() for b in range(rows.shape[0])]
 
 
-@pytest.mark.parametrize("proto,B,units", [("dmr", 16384, 33), ("ysf", 4096, 12), ("dmr", 4096, 132), ("nxdn", 4096, 16)])
+@pytest.mark.parametrize("proto,B,units", [("dmr", 16384, 33), ("ysf", 4096, 12), ("dmr", 4096, 132), ("nxdn", 4096, 16), ("dstar", 4096, 60)])
 def test_replicated_channels_agree_and_match_oracle(gpu_ctx, oracle, proto, B, units):
     import torch
     from digiham_amd import api, synth_torch
     U = 32
-    kw = dict(rrc="narrow", sps=20) if proto == "nxdn" else {}
+    kw = dict(rrc="narrow", sps=20) if proto == "nxdn" else dict(rrc="none", demod="fsk") if proto == "dstar" else {}
     base, info = synth_torch.make_batch(torch, gpu_ctx.mem.device, proto, U, units, U=U, seed=4242, sps=kw.get("sps", 10))
     T = info["samples_per_channel"]
     x = base.repeat(B // U, 1).contiguous()                      # channel ch carries signal ch % U
@@ -41,7 +41,8 @@ def test_replicated_channels_agree_and_match_oracle(gpu_ctx, oracle, proto, B, u
             assert all(d[ch] == d[ch % U] for ch in range(B))
     # the U distinct signals against the oracle (both pushes as one stream)
     xh = np.tile(base.cpu().numpy(), (1, 2))
-    ref = oracle.chain(xh, proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], threads=8, **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
+    okw = dict(rrc=2, sps=20) if proto == "nxdn" else dict(rrc=0, levels=2) if proto == "dstar" else {}
+    ref = oracle.chain(xh, proto={"dmr": 1, "ysf": 2, "nxdn": 3, "dstar": 5}[proto], threads=8, **okw)
     for b in range(U):
         gs = np.concatenate([o[0][b, :o[1][b]] for o in outs])
         gf = np.concatenate([o[2][b, :o[3][b]] for o in outs])
