@@ -211,7 +211,8 @@ def main():
             dom_name = "k_rrc_tile"
         else:
             dom_ms = float(np.mean(slicer_ms)) if len(slicer_ms) else float("nan")
-            chained = kw["proto"] != "none" and not args.split_stages
+            # one launch for slicer + decoder exists for the sps-10 DMR / YSF chains (engine.hip: launch_chain)
+            chained = kw["proto"] in ("dmr", "ysf") and kw["sps"] == 10 and not args.split_stages
             dom_name = "k_chain" if chained else "k_rrc_demod"
             if chained:
                 alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)

@@ -1573,6 +1573,27 @@ template <typename Get> DH_HD uint32_t dh_dstar_crc(Get get, uint32_t len) {
     return checksum ^ 0xFFFFu;
 }
 
+// 128 symbols at `pos` as bit masks held in scalar registers (symbol i of the run in bit i): bit 0 of every symbol in
+// l[], bit 1 in h[] (hamming_distance() counts a set bit 1 as a difference against the 0/1 patterns)
+struct DhBits128 { uint64_t l[2], h[2]; };
+DH_HD void dh_dstar_take128(const DhSymView& syms, uint32_t pos, uint32_t total, DhBits128& b) {
+    for (int w = 0; w < 2; w++) {
+        uint64_t ml = 0, mh = 0;
+        DH_FOR_LANES(lane) {
+            const uint32_t j = pos + (uint32_t) (w * 64 + lane);
+            const uint32_t v = j < total ? dh_view_at(syms, j) : 0u;
+            DH_BALLOT_ACC(ml, v & 1u, lane);
+            DH_BALLOT_ACC(mh, (v >> 1) & 1u, lane);
+        }
+        b.l[w] = ml; b.h[w] = mh;
+    }
+}
+// cnt (<= 32) bits starting at bit `start` (< 64 + cnt) of a 128-bit mask
+DH_HD uint32_t dh_bits_range(const uint64_t* w, uint32_t start, uint32_t cnt) {
+    uint64_t v = start < 64u ? (w[0] >> start) | (start ? w[1] << (64u - start) : 0ull) : w[1] >> (start - 64u);
+    return (uint32_t) v & (cnt >= 32u ? 0xFFFFFFFFu : (1u << cnt) - 1u);
+}
+
 // LDS scratch of the header decoder, carved from S.carry (D-Star keeps its carried bits in S.vit_dec instead)
 struct DhDstarScratch { uint64_t dbits[11]; uint32_t dec[44]; uint32_t out[12]; };
 static_assert(sizeof(DhDstarScratch) <= DH_SYM_CARRY_MAX, "D-Star header scratch");
@@ -1680,6 +1701,10 @@ DH_HD void dh_dstar_put_bytes(DhState& s, uint32_t base, uint32_t off, uint64_t 
 }
 
 DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+#ifdef DH_PHASE_CLOCKS
+    DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
+#endif
+    DH_DCLK_BEGIN();
     DhDecCtx c;
     c.P = &P; c.T = &dh_lds_tables(S);
     uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
@@ -1704,18 +1729,19 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     DH_FOR_LANES(lane) { for (uint32_t j = (uint32_t) lane; j < syms.nc; j += DH_WAVE) lds_carry[j] = carry_buf[j]; }
     DH_BARRIER();
     uint32_t pos = 0, phase = s[DS_PHASE];
-    DhPlanes& pl = S.planes;
+    DhBits128 bits;
+    DH_DCLK(0);
 
     for (;;) {
         const uint32_t avail = total - pos;
         if (phase == 0) {                                          // SyncPhase (dstar_phase.cpp:17-34): slide bit by bit
             if (!(avail > 24)) break;
             dh_view_ensure(syms, pos, 128);
-            dh_load_planes(syms, pos, total, pl, 2);
+            dh_dstar_take128(syms, pos, total, bits);
             uint64_t hh = 0, hv = 0;
             DH_FOR_LANES(lane) {
                 const bool valid = avail > (uint32_t) lane && avail - (uint32_t) lane > 24;
-                const uint32_t l = dh_plane_range(pl.l, lane, 24), h = dh_plane_range(pl.h, lane, 24);
+                const uint32_t l = dh_bits_range(bits.l, (uint32_t) lane, 24), h = dh_bits_range(bits.h, (uint32_t) lane, 24);
                 const bool header = valid && dh_popc32(l ^ DH_DSTAR_HEADER_SYNC) + dh_popc32(h) <= 2;
                 const bool voice = valid && !header && dh_popc32(l ^ DH_DSTAR_VOICE_SYNC) + dh_popc32(h) <= 1;
                 DH_BALLOT_ACC(hh, header, lane);
@@ -1730,12 +1756,15 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 const uint32_t adv = dh_min<uint32_t>(64u, avail - 24u);
                 pos += adv; c.consumed += adv;
             }
+            DH_DCLK(1);
             continue;
         }
         if (phase == 2) {                                          // HeaderPhase (dstar_phase.cpp:36-57)
             if (!(avail > 660)) break;
             dh_view_ensure(syms, pos, 660);
-            if (!dh_dstar_header_parse(syms, pos, X)) { pos += 1u; c.consumed += 1u; phase = 0; continue; }
+            const bool parsed = dh_dstar_header_parse(syms, pos, X);
+            DH_DCLK(2);
+            if (!parsed) { pos += 1u; c.consumed += 1u; phase = 0; continue; }
             pos += 660u; c.consumed += 660u;
             if (!((X.out[0] >> 7) & 1u)) {                         // isVoice (header.cpp:150-152)
                 const uint32_t* out = X.out;
@@ -1748,16 +1777,17 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         // VoicePhase::process (dstar_phase.cpp:76-139)
         if (!(avail > 120)) break;
         dh_view_ensure(syms, pos, 128);
-        dh_load_planes(syms, pos, total, pl, 2);
+        dh_dstar_take128(syms, pos, total, bits);
+        DH_DCLK(3);
         int sync_count = (int) s[DS_SYNC_COUNT];
         if (sync_count >= 1) {
             if (c.P->out_cap - c.nout < 9u) { c.overflow = true; break; }
             uint8_t* o = c.out + c.nout;
-            DH_FOR_LANES(lane) { if (lane < 9) o[lane] = (uint8_t) dh_plane_range(pl.l, 8 * lane, 8); }
+            DH_FOR_LANES(lane) { if (lane < 9) o[lane] = (uint8_t) ((lane < 8 ? bits.l[0] >> (8 * lane) : bits.l[1]) & 0xFFull); }
             c.nout += 9u;
         }
-        const uint32_t d0 = dh_plane_range(pl.l, 72, 24), d0h = dh_plane_range(pl.h, 72, 24);
-        const uint32_t d1 = dh_plane_range(pl.l, 96, 24), d1h = dh_plane_range(pl.h, 96, 24);
+        const uint32_t d0 = dh_bits_range(bits.l, 72, 24), d0h = dh_bits_range(bits.h, 72, 24);
+        const uint32_t d1 = dh_bits_range(bits.l, 96, 24), d1h = dh_bits_range(bits.h, 96, 24);
         if (dh_popc32(d0 ^ DH_DSTAR_TERM_LO) + dh_popc32(d0h) + dh_popc32(d1 ^ DH_DSTAR_TERM_HI) + dh_popc32(d1h) <= 1 ||
             dh_popc32(d0 ^ DH_DSTAR_TERM_HI) + dh_popc32(d0h) <= 1) {
             dh_emit(c, DH_EV_DSTAR_META_RESET, 0, 0, nullptr, 0);
@@ -1765,6 +1795,7 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             if (c.overflow) break;
             continue;
         }
+        DH_DCLK(4);
         uint32_t frame_count = s[DS_DT_FRAME];
         if (frame_count >= 20u) {                                  // isSyncDue
             bool lost = false;
@@ -1823,6 +1854,7 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             s[DS_DT_FRAME] = frame_count + 1u;
         }
         pos += 96u; c.consumed += 96u;
+        DH_DCLK(5);
         if (c.overflow) break;
     }
 
@@ -1838,6 +1870,10 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     }
     s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
     s[DS_CARRY] = rem < DH_DSTAR_CARRY_MAX ? rem : DH_DSTAR_CARRY_MAX;
+#ifdef DH_PHASE_CLOCKS
+    DH_DCLK(6);
+    for (int i = 0; i < 4; i++) s[28 + i] = (dh_uniform(S.clk[2 * i]) >> 6) + ((dh_uniform(S.clk[2 * i + 1]) >> 6) << 16);
+#endif
     s.store(st_global);
     DH_BARRIER();
 }
