@@ -1622,6 +1622,36 @@ DH_HD bool dh_dstar_header_parse(const DhSymView& syms, uint32_t pos, DhDstarScr
     // four survivor byte strings instead, which is the same path under the same tie rules (k = 0 wins ties, the
     // lowest end state wins).  State i = (newest bit << 1) | previous bit; predecessor ((i << 1) & 2) | k.
     uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    {
+        // the four states on the four lanes of every quad: lane i reads the metrics of its two predecessors through
+        // DPP quad permutes ([0,2,0,2] and [1,3,1,3]), its branch words are 00 / 10 / 11 / 01 for k = 0 and the
+        // complement for k = 1; sixteen 2-bit branch distances are computed at once per 32 received bits
+        const uint32_t st = threadIdx.x & 3u;
+        const uint32_t ca = (st == 1u || st == 2u) ? 0x55555555u : 0u;      // first bit of the k = 0 branch word
+        const uint32_t cb = st >= 2u ? 0x55555555u : 0u;                     // second bit
+        uint32_t m = 0;
+#define DH_DSTAR_ACS(q) do { \
+            const uint32_t a_ = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m, 0x88, 0xF, 0xF, true) + ((ha >> (2u * (q))) & 3u); \
+            const uint32_t b_ = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m, 0xDD, 0xF, 0xF, true) + ((hb >> (2u * (q))) & 3u); \
+            dw |= ((uint32_t) __ballot(b_ < a_) & 0xFu) << (4u * (q));      /* lanes 0..3 = new states 0..3 */ \
+            m = b_ < a_ ? b_ : a_; } while (0)
+        for (uint32_t g = 0; g < 42u; g++) {                                 // 8 trellis steps = 16 received bits per round
+            const uint32_t seg = (uint32_t) (X.dbits[g >> 2] >> (16u * (g & 3u))) & 0xFFFFu;
+            const uint32_t ha = ((seg & 0x5555u) ^ (ca & 0x5555u)) + (((seg >> 1) & 0x5555u) ^ (cb & 0x5555u));
+            const uint32_t hb = 0xAAAAu - ha;
+            uint32_t dw = 0;
+            if (g < 41u) {
+                DH_DSTAR_ACS(0); DH_DSTAR_ACS(1); DH_DSTAR_ACS(2); DH_DSTAR_ACS(3);
+                DH_DSTAR_ACS(4); DH_DSTAR_ACS(5); DH_DSTAR_ACS(6); DH_DSTAR_ACS(7);
+            } else { DH_DSTAR_ACS(0); DH_DSTAR_ACS(1); }                     // steps 328, 329
+            X.dec[g] = dw;
+        }
+#undef DH_DSTAR_ACS
+        m0 = (uint32_t) __builtin_amdgcn_readlane((int) m, 0); m1 = (uint32_t) __builtin_amdgcn_readlane((int) m, 1);
+        m2 = (uint32_t) __builtin_amdgcn_readlane((int) m, 2); m3 = (uint32_t) __builtin_amdgcn_readlane((int) m, 3);
+    }
+#else
     for (uint32_t blk = 0; blk < 11u; blk++) {                     // 32 trellis steps per 64-bit word
         const uint64_t word = X.dbits[blk];
         uint32_t lo = dh_uniform((uint32_t) word), hi = dh_uniform((uint32_t) (word >> 32));
@@ -1646,6 +1676,7 @@ DH_HD bool dh_dstar_header_parse(const DhSymView& syms, uint32_t pos, DhDstarScr
           X.dec[blk * 4u + g] = dw;
         }
     }
+#endif
     DH_BARRIER();
     uint32_t state = 0, best = m0;
     if (m1 < best) { best = m1; state = 1; }

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(DH_WAVE, DH_LB) void k_chain(const DhDspParams P, c
     __syncthreads();
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
     if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, blockIdx.x, S);
+    else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, blockIdx.x, S);
     else dh_ysf_channel(D, blockIdx.x, S);
 }
 
@@ -102,7 +103,10 @@ __global__ __launch_bounds__(DH_WAVE) void k_pocsag(const DhDecParams P) {
     dh_pocsag_channel(P, blockIdx.x, S);
 }
 
-__global__ __launch_bounds__(DH_WAVE) void k_dstar(const DhDecParams P) {
+#ifndef DH_DSTAR_LB
+#define DH_DSTAR_LB 4
+#endif
+__global__ __launch_bounds__(DH_WAVE, DH_DSTAR_LB) void k_dstar(const DhDecParams P) {
     __shared__ DhDecShared S;
     dh_dstar_channel(P, blockIdx.x, S);
 }
@@ -297,7 +301,9 @@ struct HipBackend {
     }
     // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
-        if (P.sps != 10 || (nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;
+        if (P.sps != 10) return 1;
+        if (proto == DH_PROTO_DSTAR && nz == 0) return go_chain<0, false, DH_PROTO_DSTAR>(P, D);    // fsk_demodulator -s 10 | dstar_decoder
+        if ((nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;
         const bool dmr = proto == DH_PROTO_DMR;
         if (nz == 0) return dmr ? go_chain<0, false, DH_PROTO_DMR>(P, D) : go_chain<0, false, DH_PROTO_YSF>(P, D);
         if (fast) return dmr ? go_chain<80, true, DH_PROTO_DMR>(P, D) : go_chain<80, true, DH_PROTO_YSF>(P, D);

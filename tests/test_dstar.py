@@ -122,5 +122,6 @@ def test_full_chain_fsk_sps10(ctx, oracle):
     ref = oracle.chain(x, rrc=0, levels=2, sps=10, proto=5)
     assert ref["out_count"].min() > 0
     for chunks in ([n], [48000, 12345]):
-        res = run_engine(ctx, x, "dstar", chunks, rrc="none", demod="fsk", sps=10)
-        assert_matches_oracle(res, ref, len(x), "dstar %s" % chunks[:1])
+        for split in (False, True):                    # one-wavefront chain kernel / slicer and decoder as two launches
+            res = run_engine(ctx, x, "dstar", chunks, rrc="none", demod="fsk", sps=10, split_stages=split)
+            assert_matches_oracle(res, ref, len(x), "dstar %s %s" % (chunks[:1], "split" if split else "chain"))

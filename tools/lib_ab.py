@@ -6,14 +6,16 @@ import numpy as np, torch
 from digiham_amd import api, synth_torch, _capi
 proto = sys.argv[1]
 B = 16384
-x, info = synth_torch.make_batch(torch, torch.device("cuda", 0), proto, B, 132 if proto == "dmr" else 40, seed=1000)
+units = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198}[proto]
+ekw = {"nxdn": dict(rrc="narrow", sps=20), "dstar": dict(rrc="none", demod="fsk", sps=10)}.get(proto, {})
+x, info = synth_torch.make_batch(torch, torch.device("cuda", 0), proto, B, units, seed=1000, sps=ekw.get("sps", 10))
 T = info["samples_per_channel"]
 for path in sys.argv[2:] * 2:
     ctx = api.Context(lib=_capi.load(path))
     row = []
-    for split in (True, False):
+    for split in ((True, False) if proto in ("dmr", "ysf", "dstar") else (True,)):
         try:
-            eng = api.Engine(B, T, proto=proto, split_stages=split, ctx=ctx)
+            eng = api.Engine(B, T, proto=proto, split_stages=split, ctx=ctx, **ekw)
         except TypeError:
             continue
         eng.timing_enable(8)
