@@ -212,7 +212,8 @@ def main():
         else:
             dom_ms = float(np.mean(slicer_ms)) if len(slicer_ms) else float("nan")
             # one launch for slicer + decoder exists for the sps-10 DMR / YSF chains (engine.hip: launch_chain)
-            chained = (kw["proto"] in ("dmr", "ysf") or (kw["proto"] == "dstar" and kw["rrc"] == "none")) and kw["sps"] == 10 and not args.split_stages
+            chained = ((kw["proto"] in ("dmr", "ysf") or (kw["proto"] == "dstar" and kw["rrc"] == "none")) and kw["sps"] == 10
+                       or (kw["proto"] == "nxdn" and kw["rrc"] == "narrow")) and not args.split_stages
             dom_name = "k_chain" if chained else "k_rrc_demod"
             if chained:
                 alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)

@@ -232,16 +232,26 @@ DH_HD void dh_view_ensure(DhSymView& v, uint32_t pos, uint32_t need) {
     const uint32_t mis = (uint32_t) ((uintptr_t) (v.fresh + f0) & 3u);
     const uint32_t wb = f0 >= mis ? f0 - mis : f0;             // start the window on a 4-byte aligned address when possible
     DH_BARRIER();                                              // earlier readers of the window are done
+    // four 32-bit words per lane.  The loads are issued unconditionally (a lane past the end of the push reads the
+    // window's first word instead) so that all four are in flight together; a load under a branch would be waited
+    // for before the next one starts.  Words that straddle the end, or an unaligned row, take the byte loop.
+    const bool aligned = (((uintptr_t) (v.fresh + wb)) & 3u) == 0 && wb + 4u <= v.nfresh;
     DH_FOR_LANES(lane) {
-        for (uint32_t idx = 4u * (uint32_t) lane; idx < DH_SYMWIN; idx += 4u * DH_WAVE) {
-            const uint32_t f = wb + idx;
-            const uint8_t* src = v.fresh + f;
-            uint32_t word = 0;
-            if (f + 4u <= v.nfresh && ((uintptr_t) src & 3u) == 0) word = *reinterpret_cast<const uint32_t*>(src);
-            else {
-                for (uint32_t b = 0; b < 4u; b++) if (f + b < v.nfresh) word |= (uint32_t) src[b] << (8u * b);
+        constexpr int NW = DH_SYMWIN / (4 * DH_WAVE);
+        uint32_t word[NW];
+        for (int k = 0; k < NW; k++) {
+            const uint32_t f = wb + 4u * (uint32_t) lane + (uint32_t) k * 4u * DH_WAVE;
+            const bool whole = aligned && f + 4u <= v.nfresh;
+            word[k] = aligned ? *reinterpret_cast<const uint32_t*>(v.fresh + (whole ? f : wb)) : 0u;
+        }
+        for (int k = 0; k < NW; k++) {
+            const uint32_t idx = 4u * (uint32_t) lane + (uint32_t) k * 4u * DH_WAVE, f = wb + idx;
+            uint32_t w = word[k];
+            if (!(aligned && f + 4u <= v.nfresh)) {
+                w = 0;
+                for (uint32_t b = 0; b < 4u; b++) if (f + b < v.nfresh) w |= (uint32_t) v.fresh[f + b] << (8u * b);
             }
-            *reinterpret_cast<uint32_t*>(v.win + idx) = word;
+            *reinterpret_cast<uint32_t*>(v.win + idx) = w;
         }
     }
     DH_BARRIER();
@@ -1595,7 +1605,7 @@ DH_HD uint32_t dh_bits_range(const uint64_t* w, uint32_t start, uint32_t cnt) {
 }
 
 // LDS scratch of the header decoder, carved from S.carry (D-Star keeps its carried bits in S.vit_dec instead)
-struct DhDstarScratch { uint64_t dbits[11]; uint32_t dec[44]; uint32_t out[12]; };
+struct DhDstarScratch { uint64_t dbits[11]; uint32_t dec[44]; uint32_t out[12]; uint64_t pk[8]; };
 static_assert(sizeof(DhDstarScratch) <= DH_SYM_CARRY_MAX, "D-Star header scratch");
 
 // Header::parseFromHeader (header.cpp:24-58) on the 660 bits at `pos`: true when the path metric is <= 10 and the CRC
@@ -1731,6 +1741,34 @@ DH_HD void dh_dstar_put_bytes(DhState& s, uint32_t base, uint32_t off, uint64_t 
     }
 }
 
+// VoicePhase::collectDataFrame (dstar_phase.cpp:153-203) on the descrambled 24 bits `x` of data frame `frame_count`
+DH_HD void dh_dstar_collect(DhDecCtx& c, DhState& s, uint32_t frame_count, uint32_t x) {
+    if ((frame_count & 1u) == 0u) { s[DS_DT_COLLECT0] = x; return; }
+    s[DS_DT_COLLECT1] = x;
+    const uint32_t c0 = s[DS_DT_COLLECT0];
+    const uint32_t mini = c0 & 0xFFu, n = mini & 0x0Fu;
+    const uint64_t data = (uint64_t) (c0 >> 8) | ((uint64_t) x << 16);       // collected_data[1..5]
+    if ((mini >> 4) == 0x4u) {
+        if (n <= 3u) { dh_dstar_put_bytes(s, DS_DT_MESSAGE, n * 5u, data, 5u); s[DS_DT_BLOCKS] = (uint32_t) s[DS_DT_BLOCKS] | (1u << n); }
+    } else if ((mini >> 4) == 0x5u) {
+        const uint32_t hc = s[DS_DT_HCOUNT];
+        if (n <= 5u && hc + n <= 41u) { dh_dstar_put_bytes(s, DS_DT_HEADER, hc, data, n); s[DS_DT_HCOUNT] = hc + n; }
+    } else if ((mini >> 4) == 0x3u) {
+        if (n <= 5u) {
+            uint8_t b[5];
+            for (uint32_t i = 0; i < 5u; i++) b[i] = (uint8_t) (data >> (8u * i));
+            dh_emit(c, DH_EV_DSTAR_SIMPLE, 0, 0, b, (int) n);
+        }
+    }
+}
+
+// end pattern in a data frame (dstar_phase.cpp:92-96): all 48 bits, or its second half alone, with at most one error
+DH_HD bool dh_dstar_is_terminator(uint32_t d0, uint32_t d1) {
+    return dh_popc32(d0 ^ DH_DSTAR_TERM_LO) + dh_popc32(d1 ^ DH_DSTAR_TERM_HI) <= 1 || dh_popc32(d0 ^ DH_DSTAR_TERM_HI) <= 1;
+}
+
+#define DH_DSTAR_BATCH 5          // data frames handled per round on the fast path (5 x 96 + 24 bits <= 512)
+
 DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 #ifdef DH_PHASE_CLOCKS
     DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
@@ -1807,10 +1845,70 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         }
         // VoicePhase::process (dstar_phase.cpp:76-139)
         if (!(avail > 120)) break;
+        int sync_count = (int) s[DS_SYNC_COUNT];
+        {
+            // Fast path: up to DH_DSTAR_BATCH consecutive data frames that are not sync frames.  Packed LSB first, a
+            // frame is 12 bytes: 9 voice bytes (the output, :81-86) and the 3 data bytes (:122-126); 512 bits from `pos`
+            // are packed with lane votes, the voice bytes of all frames go out in one coalesced store, sync / end
+            // pattern tests and the slow-data bytes are constant shifts of the packed words.  Symbols other than 0 / 1
+            // and a frame holding the end pattern take the one-frame path below.
+            const uint32_t fc0 = s[DS_DT_FRAME];
+            uint32_t nb = fc0 < 20u ? dh_min<uint32_t>(DH_DSTAR_BATCH, 20u - fc0) : 0u;
+            if (nb >= 2u && avail > 96u * (nb - 1u) + 120u && (sync_count < 1 || c.P->out_cap - c.nout >= 9u * nb)) {
+                dh_view_ensure(syms, pos, 512);
+                uint64_t W[9], odd = 0;
+                W[8] = 0;
+                for (int w = 0; w < 8; w++) {
+                    uint64_t ml = 0;
+                    DH_FOR_LANES(lane) {
+                        const uint32_t j = pos + (uint32_t) (w * 64 + lane);
+                        const uint32_t v = j < total ? dh_view_at(syms, j) : 0u;
+                        DH_BALLOT_ACC(ml, v & 1u, lane);
+                        DH_BALLOT_ACC(odd, v > 1u, lane);
+                    }
+                    W[w] = ml;
+                }
+                if (odd == 0) {
+                    uint32_t n = nb, xs[DH_DSTAR_BATCH];
+#pragma unroll
+                    for (uint32_t f = 0; f < DH_DSTAR_BATCH; f++) {
+                        if (f >= n) break;
+                        const uint32_t d0 = dh_bits_range(W + ((96u * f + 72u) >> 6), (96u * f + 72u) & 63u, 24);
+                        const uint32_t d1 = dh_bits_range(W + ((96u * f + 96u) >> 6), (96u * f + 96u) & 63u, 24);
+                        xs[f] = d0;
+                        if (dh_dstar_is_terminator(d0, d1)) n = f;
+                    }
+                    if (n >= 1u) {
+                        if (sync_count >= 1) {
+                            for (int w = 0; w < 8; w++) X.pk[w] = W[w];
+                            DH_BARRIER();
+                            const uint8_t* pk = reinterpret_cast<const uint8_t*>(X.pk);
+                            uint8_t* o = c.out + c.nout;
+                            DH_FOR_LANES(lane) {
+                                const uint32_t f = (uint32_t) lane / 9u, i = (uint32_t) lane % 9u;
+                                if ((uint32_t) lane < 9u * n) o[lane] = pk[12u * f + i];
+                            }
+                            DH_BARRIER();
+                            c.nout += 9u * n;
+                        }
+                        constexpr DhDstarPn pn{};
+#pragma unroll
+                        for (uint32_t f = 0; f < DH_DSTAR_BATCH; f++) {
+                            if (f >= n) break;
+                            dh_dstar_collect(c, s, fc0 + f, xs[f] ^ (pn.w[0] & 0xFFFFFFu));
+                            pos += 96u; c.consumed += 96u;
+                        }
+                        s[DS_DT_FRAME] = fc0 + n;
+                        DH_DCLK(5);
+                        if (c.overflow) break;
+                        continue;
+                    }
+                }
+            }
+        }
         dh_view_ensure(syms, pos, 128);
         dh_dstar_take128(syms, pos, total, bits);
         DH_DCLK(3);
-        int sync_count = (int) s[DS_SYNC_COUNT];
         if (sync_count >= 1) {
             if (c.P->out_cap - c.nout < 9u) { c.overflow = true; break; }
             uint8_t* o = c.out + c.nout;
@@ -1861,27 +1959,7 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             for (int i = 0; i < 11; i++) s[DS_DT_HEADER + i] = 0;
         } else {
             constexpr DhDstarPn pn{};
-            const uint32_t x = d0 ^ (pn.w[0] & 0xFFFFFFu);          // scrambler->reset() + 24 bits, packed LSB first (:120-129)
-            // collectDataFrame (:153-203)
-            if ((frame_count & 1u) == 0u) s[DS_DT_COLLECT0] = x;
-            else {
-                s[DS_DT_COLLECT1] = x;
-                const uint32_t c0 = s[DS_DT_COLLECT0];
-                const uint32_t mini = c0 & 0xFFu, n = mini & 0x0Fu;
-                const uint64_t data = (uint64_t) (c0 >> 8) | ((uint64_t) x << 16);       // collected_data[1..5]
-                if ((mini >> 4) == 0x4u) {
-                    if (n <= 3u) { dh_dstar_put_bytes(s, DS_DT_MESSAGE, n * 5u, data, 5u); s[DS_DT_BLOCKS] = (uint32_t) s[DS_DT_BLOCKS] | (1u << n); }
-                } else if ((mini >> 4) == 0x5u) {
-                    const uint32_t hc = s[DS_DT_HCOUNT];
-                    if (n <= 5u && hc + n <= 41u) { dh_dstar_put_bytes(s, DS_DT_HEADER, hc, data, n); s[DS_DT_HCOUNT] = hc + n; }
-                } else if ((mini >> 4) == 0x3u) {
-                    if (n <= 5u) {
-                        uint8_t b[5];
-                        for (uint32_t i = 0; i < 5u; i++) b[i] = (uint8_t) (data >> (8u * i));
-                        dh_emit(c, DH_EV_DSTAR_SIMPLE, 0, 0, b, (int) n);
-                    }
-                }
-            }
+            dh_dstar_collect(c, s, frame_count, d0 ^ (pn.w[0] & 0xFFFFFFu));     // scrambler->reset() + 24 bits, packed LSB first (:120-129)
             s[DS_DT_FRAME] = frame_count + 1u;
         }
         pos += 96u; c.consumed += 96u;

@@ -53,18 +53,20 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(co
 // the symbols just produced.  The decoder is latency-bound (scalar control, LDS round trips); inside this kernel
 // its stalls are covered by the other wavefronts' FIR arithmetic instead of by nothing, as in a separate launch.
 // The two stages use the LDS block one after the other.
-template <int NZ, bool FAST, int PROTO>
-__global__ __launch_bounds__(DH_WAVE, DH_LB) void k_chain(const DhDspParams P, const DhDecParams D) {
+// SPS = 10 is the specialised slicer of the DMR / YSF / D-Star pipes, SPS = 0 takes the run-time value (NXDN: 20).
+template <int NZ, bool FAST, int PROTO, int SPS = 10>
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_chain(const DhDspParams P, const DhDecParams D) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     {
-        DhDspShared L = dh_dsp_carve(dh_smem, 10u);
-        dh_rrc_demod_channel<NZ, FAST, 10>(P, blockIdx.x, L);
+        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
+        dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, L);
     }
     __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
     __syncthreads();
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
     if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, blockIdx.x, S);
     else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, blockIdx.x, S);
+    else if (PROTO == DH_PROTO_NXDN) dh_nxdn_channel(D, blockIdx.x, S);
     else dh_ysf_channel(D, blockIdx.x, S);
 }
 
@@ -290,17 +292,18 @@ struct HipBackend {
         if (nz == 160) return fast ? go_rrc_demod<160, true, 0>(P) : go_rrc_demod<160, false, 0>(P);
         return -1;
     }
-    template <int NZ, bool FAST, int PROTO> int go_chain(const DhDspParams& P, const DhDecParams& D) {
-        size_t lds = dh_dsp_shared_bytes(10, NZ);
+    template <int NZ, bool FAST, int PROTO, int SPS = 10> int go_chain(const DhDspParams& P, const DhDecParams& D) {
+        size_t lds = dh_dsp_shared_bytes(SPS ? (uint32_t) SPS : P.sps, NZ);
         if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
 #ifdef DH_LDS_PAD
         lds += DH_LDS_PAD;                  // occupancy experiments (tools/build_variant.sh)
 #endif
-        hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P, D);
+        hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P, D);
         return launched("k_chain");
     }
     // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
+        if (proto == DH_PROTO_NXDN && nz == 160 && !fast) return go_chain<160, false, DH_PROTO_NXDN, 0>(P, D);   // rrc_filter -n | gfsk_demodulator -s 20 | nxdn_decoder
         if (P.sps != 10) return 1;
         if (proto == DH_PROTO_DSTAR && nz == 0) return go_chain<0, false, DH_PROTO_DSTAR>(P, D);    // fsk_demodulator -s 10 | dstar_decoder
         if ((nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;

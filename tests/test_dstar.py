@@ -125,3 +125,30 @@ def test_full_chain_fsk_sps10(ctx, oracle):
         for split in (False, True):                    # one-wavefront chain kernel / slicer and decoder as two launches
             res = run_engine(ctx, x, "dstar", chunks, rrc="none", demod="fsk", sps=10, split_stages=split)
             assert_matches_oracle(res, ref, len(x), "dstar %s %s" % (chunks[:1], "split" if split else "chain"))
+
+
+def test_tiny_empty_and_ragged_pushes(ctx, oracle):
+    """Pushes of 1..13 samples, one just under / over a bit, and a header that arrives split over many pushes."""
+    bits, _ = synth.dstar_stream(31, 2)
+    x = synth.impair(synth.fsk_shape(bits, sps=10), 3, snr_db=25, dc=0.02)[None, :]
+    ref = oracle.chain(x, rrc=0, levels=2, sps=10, proto=5)
+    assert ref["out_count"][0] > 0
+    res = run_engine(ctx, x, "dstar", [1, 2, 3, 9, 10, 11, 13, 659, 661, 6600, 37, 5000], rrc="none", demod="fsk", sps=10)
+    assert_matches_oracle(res, ref, 1)
+    # decoder-only engine fed 1 .. 7 bits at a time through a header and the first superframe
+    rng = np.random.default_rng(8)
+    stream = np.concatenate([rng.integers(0, 2, 50).astype(np.uint8), synth.dstar_transmission(rng, n_superframes=1)[0]])
+    out, ev = oracle.Decoder("dstar").process(stream)
+    eng = api.Engine(1, 64, rrc="none", demod="none", proto="dstar", ctx=ctx)
+    o, e, lo, k = [], [], 0, 0
+    while lo < len(stream):
+        n = [1, 7, 0, 3, 5, 2][k % 6]; k += 1
+        part = np.zeros((1, 64), np.uint8); part[0, :min(n, len(stream) - lo)] = stream[lo:lo + n]
+        eng.push_symbols(part, np.full(1, min(n, len(stream) - lo), np.uint32))
+        lo += n
+        f, fc = eng.frames(); evs, ec = eng.events()
+        o.append(f[0, :fc[0]].copy()); e.append(evs[0, :ec[0]].copy())
+    eng.close()
+    go, ge = np.concatenate(o), np.concatenate(e)
+    assert len(go) == len(out) and (go == out).all() and ge.tobytes() == ev.tobytes()
+    assert (ev["type"] == EV_HEADER).sum() >= 2

@@ -106,5 +106,6 @@ def test_full_chain_narrow_rrc_sps20(ctx, oracle):
     ref = oracle.chain(x, rrc=2, sps=20, proto=3)
     assert ref["out_count"].sum() > 0
     for chunks in ([n], [4800, 12345]):
-        res = run_engine(ctx, x, "nxdn", chunks, rrc="narrow", sps=20)
-        assert_matches_oracle(res, ref, len(x), "nxdn %s" % chunks[:1])
+        for split in (False, True):                    # one-wavefront chain kernel / slicer and decoder as two launches
+            res = run_engine(ctx, x, "nxdn", chunks, rrc="narrow", sps=20, split_stages=split)
+            assert_matches_oracle(res, ref, len(x), "nxdn %s %s" % (chunks[:1], "split" if split else "chain"))

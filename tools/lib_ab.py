@@ -13,7 +13,7 @@ T = info["samples_per_channel"]
 for path in sys.argv[2:] * 2:
     ctx = api.Context(lib=_capi.load(path))
     row = []
-    for split in ((True, False) if proto in ("dmr", "ysf", "dstar") else (True,)):
+    for split in (True, False):
         try:
             eng = api.Engine(B, T, proto=proto, split_stages=split, ctx=ctx, **ekw)
         except TypeError:
