@@ -45,6 +45,9 @@ WORKLOADS = {
     # examples/dstar-decoder.sh: fsk_demodulator -s 10 | dstar_decoder (no RRC stage on this path)
     "dstar_full": ("dstar", dict(rrc="none", demod="fsk", sps=10, proto="dstar"),
                    "full chain fsk(10)->dstar_decoder (D-Star)"),
+    # examples/pocsag-decoder.sh: fsk_demodulator -i -s 40 | pocsag_decoder
+    "pocsag_full": ("pocsag", dict(rrc="none", demod="fsk", sps=40, proto="pocsag", invert=True),
+                    "full chain fsk(40, inverted)->pocsag_decoder (POCSAG 1200)"),
     # BASELINE configs[4] per GPU: half the channels DMR, half YSF, one engine (and one launch per push) each
     "mixed": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
               "half DMR + half YSF channels, full chains (BASELINE configs[4] per-GPU share)"),
@@ -72,6 +75,8 @@ def profiled_traffic(workload, channels, T):
 def oracle_kw(proto):
     if proto == "dstar":
         return dict(proto=5, rrc=0, levels=2, sps=10)
+    if proto == "pocsag":
+        return dict(proto=4, rrc=0, levels=2, sps=40, invert=True)
     return dict(proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
 
 
@@ -125,7 +130,7 @@ def main():
 
     proto, kw, desc = WORKLOADS[args.workload]
     B = args.channels
-    units = args.units or {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198}[proto]
+    units = args.units or {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}[proto]
     x, info = synth_torch.make_batch(torch, device, proto, B, units, seed=1000 + 7919 * rank, sps=kw["sps"])
     T = info["samples_per_channel"]
     ctx = api.Context(device=local)
@@ -203,7 +208,7 @@ def main():
         n_gpus = world
         # dominant kernel: fused RRC + slicer (k_rrc_demod); algorithmic bytes per launch =
         # input f32 (4 B/sample) + dibits out (1 B per 10 samples) -- SURVEY.md section 8(d)
-        alg_bytes = B * T * 4.0 + B * (T / 10.0)              # of ONE launch of the dominant kernel (mixed: the DMR engine's)
+        alg_bytes = B * T * 4.0 + B * (T / float(kw["sps"]))   # of ONE launch of the dominant kernel (mixed: the DMR engine's)
         if kw.get("keep_filtered"):
             # unfused config 2: the RRC kernel is dominant; 4 B in + 4 B out per sample
             dom_ms = float(np.mean(rrc_ms)) if len(rrc_ms) else float("nan")

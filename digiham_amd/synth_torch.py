@@ -23,6 +23,11 @@ def periodic_streams(proto, n_units, U, seed=1000):
             while len(s) < n_units * 96:
                 s = np.concatenate([s, synth.dstar_stream(seed + u + 7777, n_units // 40 + 2, lead_in=0)[0]])
             s = s[:n_units * 96]
+        elif proto == "pocsag":                      # n_units 32-bit words of transmissions and noise gaps
+            s = synth.pocsag_stream(seed + u, n_units // 40 + 2, lead_in=0)[0]
+            while len(s) < n_units * 32:
+                s = np.concatenate([s, synth.pocsag_stream(seed + u + 7777, n_units // 40 + 2, lead_in=0)[0]])
+            s = s[:n_units * 32]
         else:
             s = synth.ysf_stream(seed + u, n_units, mode="vd2", lead_in=0)
         out.append(s)
@@ -37,11 +42,12 @@ def make_batch(torch, device, proto, B, n_units, U=64, seed=1000, sps=10, amplit
     U = syms.shape[0]
     S = syms.shape[1]
     T = S * sps
-    levels = np.array([-1.0, 1.0], np.float32) if proto == "dstar" else synth.LEVELS              # bit 1 above the centre
+    levels = (np.array([-1.0, 1.0], np.float32) if proto == "dstar" else                         # bit 1 above the centre
+              np.array([1.0, -1.0], np.float32) if proto == "pocsag" else synth.LEVELS)          # POCSAG is received inverted
     lv = torch.tensor(levels, device=device)[torch.from_numpy(syms.astype(np.int64)).to(device)]      # [U][S]
     imp = torch.zeros((U, T), dtype=torch.float32, device=device)
     imp[:, ::sps] = lv
-    if proto == "dstar":                                 # NRZ with sloped edges (synth.fsk_shape), no TX RRC
+    if proto in ("dstar", "pocsag"):                     # NRZ with sloped edges (synth.fsk_shape), no TX RRC
         g = np.convolve(np.ones(sps), np.ones(5) / 5.0)
     else:
         g = (_taps.narrow() if proto == "nxdn" else _taps.wide()).astype(np.float64)
@@ -54,7 +60,7 @@ def make_batch(torch, device, proto, B, n_units, U=64, seed=1000, sps=10, amplit
     x = torch.empty((B, T), dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    burst = {"dmr": 144, "ysf": 480, "nxdn": 192, "dstar": 96}[proto] * sps
+    burst = {"dmr": 144, "ysf": 480, "nxdn": 192, "dstar": 96, "pocsag": 32}[proto] * sps
     for c0 in range(0, B, chunk):
         c1 = min(B, c0 + chunk)
         for ch in range(c0, c1):
