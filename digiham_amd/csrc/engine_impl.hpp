@@ -186,8 +186,11 @@ struct Engine {
     }
 
     int push(const float* d_in, size_t stride, size_t n) {
-        if (!d_in || n > L.max_samples || stride < n) return DH_EINVAL;
+        if ((!d_in && n) || n > L.max_samples || stride < n) return DH_EINVAL;
         if (!L.rrc && !L.demod) return DH_EINVAL;
+        // an empty push is a module call with nothing readable: it runs (zero outputs, state untouched) and never
+        // dereferences the sample pointer, which may then be null
+        if (!d_in) d_in = reinterpret_cast<const float*>(overflow);
         last_n = (uint32_t) n;
         int rc = 0;
         const float* demod_in = d_in; size_t demod_stride = stride;

@@ -162,7 +162,7 @@ int  dh_engine_set_slot_filter(dh_engine* e, uint32_t filter);
 
 /* Feed n new samples per channel (n <= max_samples).  d_samples is [B][stride]
  * float32, channel-major, resident in HBM.  Asynchronous on the engine stream.
- * Outputs of this push replace those of the previous push. */
+ * Outputs of this push replace those of the previous push.  n = 0 is a valid (empty) push; d_samples may then be NULL. */
 int  dh_engine_push(dh_engine* e, const float* d_samples, size_t stride, size_t n);
 /* same, from host memory (staged through an engine-owned device buffer) */
 int  dh_engine_push_host(dh_engine* e, const float* h_samples, size_t stride, size_t n);

@@ -128,12 +128,12 @@ def test_full_chain_fsk_sps10(ctx, oracle):
 
 
 def test_tiny_empty_and_ragged_pushes(ctx, oracle):
-    """Pushes of 1..13 samples, one just under / over a bit, and a header that arrives split over many pushes."""
+    """Pushes of 0..13 samples, one just under / over a bit, and a header that arrives split over many pushes."""
     bits, _ = synth.dstar_stream(31, 2)
     x = synth.impair(synth.fsk_shape(bits, sps=10), 3, snr_db=25, dc=0.02)[None, :]
     ref = oracle.chain(x, rrc=0, levels=2, sps=10, proto=5)
     assert ref["out_count"][0] > 0
-    res = run_engine(ctx, x, "dstar", [1, 2, 3, 9, 10, 11, 13, 659, 661, 6600, 37, 5000], rrc="none", demod="fsk", sps=10)
+    res = run_engine(ctx, x, "dstar", [1, 0, 2, 3, 9, 10, 11, 13, 0, 659, 661, 6600, 37, 5000], rrc="none", demod="fsk", sps=10)
     assert_matches_oracle(res, ref, 1)
     # decoder-only engine fed 1 .. 7 bits at a time through a header and the first superframe
     rng = np.random.default_rng(8)
