@@ -18,6 +18,18 @@
 
 #include "../../include/digiham_amd.h"     // dh_event, DH_EV_*
 
+// one value per lane that outlives a lane loop: a register on the GPU, a [lane] array in the harness; DH_LV_READ
+// fetches the value of lane k (wave-uniform k) -- v_readlane
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_LANE_VALUE(type, name) type name
+#define DH_LV(name, lane) name
+#define DH_LV_READ(name, k) ((uint32_t) __builtin_amdgcn_readlane((int) (name), (int) (k)))
+#else
+#define DH_LANE_VALUE(type, name) type name[DH_WAVE]
+#define DH_LV(name, lane) name[lane]
+#define DH_LV_READ(name, k) ((uint32_t) name[k])
+#endif
+
 #define DH_SYM_CARRY_MAX 512          // symbols a decoder may leave unread between pushes (<= 480)
 #define DH_DSTAR_CARRY_MAX 704        // D-Star: the header phase waits for more than 660 bits (dstar_phase.hpp:52)
 DH_HD uint32_t dh_carry_max(int proto) { return proto == DH_PROTO_DSTAR ? DH_DSTAR_CARRY_MAX : DH_SYM_CARRY_MAX; }
@@ -1605,7 +1617,7 @@ DH_HD uint32_t dh_bits_range(const uint64_t* w, uint32_t start, uint32_t cnt) {
 }
 
 // LDS scratch of the header decoder, carved from S.carry (D-Star keeps its carried bits in S.vit_dec instead)
-struct DhDstarScratch { uint64_t dbits[11]; uint32_t dec[44]; uint32_t out[12]; uint64_t pk[8]; };
+struct DhDstarScratch { uint64_t dbits[11]; uint32_t dec[44]; uint32_t out[12]; };
 static_assert(sizeof(DhDstarScratch) <= DH_SYM_CARRY_MAX, "D-Star header scratch");
 
 // Header::parseFromHeader (header.cpp:24-58) on the 660 bits at `pos`: true when the path metric is <= 10 and the CRC
@@ -1848,47 +1860,46 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         int sync_count = (int) s[DS_SYNC_COUNT];
         {
             // Fast path: up to DH_DSTAR_BATCH consecutive data frames that are not sync frames.  Packed LSB first, a
-            // frame is 12 bytes: 9 voice bytes (the output, :81-86) and the 3 data bytes (:122-126); 512 bits from `pos`
-            // are packed with lane votes, the voice bytes of all frames go out in one coalesced store, sync / end
-            // pattern tests and the slow-data bytes are constant shifts of the packed words.  Symbols other than 0 / 1
-            // and a frame holding the end pattern take the one-frame path below.
+            // frame is 12 bytes: 9 voice bytes (the output, :81-86) and the 3 data bytes (:122-126).  Every lane loads
+            // eight symbols of this push straight from HBM / L2 (three aligned words, funnel-shifted) and packs them
+            // into ONE byte with a multiply: lane 12 f + i then holds byte i of frame f.  The voice bytes of all frames
+            // leave in one store from those registers; end-pattern tests and slow-data bytes read the lanes they need
+            // (v_readlane).  Symbols other than 0 / 1, a frame holding the end pattern, the carried symbols at the
+            // start of a push and the last 516 symbols of a push take the one-frame path below.
             const uint32_t fc0 = s[DS_DT_FRAME];
             uint32_t nb = fc0 < 20u ? dh_min<uint32_t>(DH_DSTAR_BATCH, 20u - fc0) : 0u;
-            if (nb >= 2u && avail > 96u * (nb - 1u) + 120u && (sync_count < 1 || c.P->out_cap - c.nout >= 9u * nb)) {
-                dh_view_ensure(syms, pos, 512);
-                uint64_t W[9], odd = 0;
-                W[8] = 0;
-                for (int w = 0; w < 8; w++) {
-                    uint64_t ml = 0;
-                    DH_FOR_LANES(lane) {
-                        const uint32_t j = pos + (uint32_t) (w * 64 + lane);
-                        const uint32_t v = j < total ? dh_view_at(syms, j) : 0u;
-                        DH_BALLOT_ACC(ml, v & 1u, lane);
-                        DH_BALLOT_ACC(odd, v > 1u, lane);
-                    }
-                    W[w] = ml;
+            const uint32_t fpos = pos - syms.nc;                    // offset in this push's symbols (valid when pos >= nc)
+            const uint32_t mis = (uint32_t) ((uintptr_t) (syms.fresh + fpos) & 3u);
+            if (nb >= 2u && pos >= syms.nc && fpos >= mis && fpos - mis + 516u <= syms.nfresh &&
+                (sync_count < 1 || c.P->out_cap - c.nout >= 9u * nb)) {
+                DH_LANE_VALUE(uint32_t, pkb);
+                uint64_t odd = 0;
+                const uint32_t* words = reinterpret_cast<const uint32_t*>(syms.fresh + fpos - mis);
+                DH_FOR_LANES(lane) {
+                    const uint32_t w0 = words[2 * lane], w1 = words[2 * lane + 1], w2 = words[2 * lane + 2];
+                    const uint32_t lo = mis ? (w0 >> (8u * mis)) | (w1 << (32u - 8u * mis)) : w0;
+                    const uint32_t hi = mis ? (w1 >> (8u * mis)) | (w2 << (32u - 8u * mis)) : w1;
+                    DH_BALLOT_ACC(odd, ((lo | hi) & 0xFEFEFEFEu) != 0u, lane);
+                    // bit 0 of byte k -> bit k: 0x01020408 = 2^24 + 2^17 + 2^10 + 2^3 moves them to bits 24..27
+                    DH_LV(pkb, lane) = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 24) << 4);
                 }
                 if (odd == 0) {
                     uint32_t n = nb, xs[DH_DSTAR_BATCH];
 #pragma unroll
                     for (uint32_t f = 0; f < DH_DSTAR_BATCH; f++) {
                         if (f >= n) break;
-                        const uint32_t d0 = dh_bits_range(W + ((96u * f + 72u) >> 6), (96u * f + 72u) & 63u, 24);
-                        const uint32_t d1 = dh_bits_range(W + ((96u * f + 96u) >> 6), (96u * f + 96u) & 63u, 24);
+                        const uint32_t d0 = DH_LV_READ(pkb, 12u * f + 9u) | DH_LV_READ(pkb, 12u * f + 10u) << 8 | DH_LV_READ(pkb, 12u * f + 11u) << 16;
+                        const uint32_t d1 = DH_LV_READ(pkb, 12u * f + 12u) | DH_LV_READ(pkb, 12u * f + 13u) << 8 | DH_LV_READ(pkb, 12u * f + 14u) << 16;
                         xs[f] = d0;
                         if (dh_dstar_is_terminator(d0, d1)) n = f;
                     }
                     if (n >= 1u) {
                         if (sync_count >= 1) {
-                            for (int w = 0; w < 8; w++) X.pk[w] = W[w];
-                            DH_BARRIER();
-                            const uint8_t* pk = reinterpret_cast<const uint8_t*>(X.pk);
                             uint8_t* o = c.out + c.nout;
                             DH_FOR_LANES(lane) {
-                                const uint32_t f = (uint32_t) lane / 9u, i = (uint32_t) lane % 9u;
-                                if ((uint32_t) lane < 9u * n) o[lane] = pk[12u * f + i];
+                                const uint32_t f = (uint32_t) lane / 12u, i = (uint32_t) lane % 12u;
+                                if (f < n && i < 9u) o[9u * f + i] = (uint8_t) DH_LV(pkb, lane);
                             }
-                            DH_BARRIER();
                             c.nout += 9u * n;
                         }
                         constexpr DhDstarPn pn{};
