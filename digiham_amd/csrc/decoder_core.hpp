@@ -725,6 +725,9 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
     int steps = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) steps = sizes[q] > steps ? sizes[q] : steps;
+#ifdef DH_VIT_SKIP
+    steps = DH_VIT_SKIP;            // timing experiment: forward pass cut short (results are wrong)
+#endif
     const int mysize = g == 0 ? sizes[0] : g == 1 ? sizes[1] : g == 2 ? sizes[2] : sizes[3];   // static indices only
     const uint32_t outbit = (uint32_t) i >> 3;
     const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
@@ -908,6 +911,9 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0, phase = s[DS_PHASE];
+    // position of a frame whose two codewords are already decoded in S.vit_out[2], [3]: a Viterbi pass has room for
+    // four codewords, a frame needs two, so the pass of frame k also decodes frame k+1 when its symbols are here
+    uint32_t ahead_pos = 0xFFFFFFFFu;
 
     for (;;) {
         const uint32_t avail = total - pos;
@@ -933,7 +939,9 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         // FramePhase (ysf_phase.cpp:41-172)
         if (!(avail > 480)) break;
         DH_DCLK(0);
-        dh_view_ensure(syms, pos, 512);
+        const bool have = ahead_pos == pos;
+        const bool two = !have && avail > 960;                     // the next frame is complete in this push as well
+        dh_view_ensure(syms, pos, two ? 960 : 512);
         dh_load_planes(syms, pos, total, pl, 8);
         DH_DCLK(1);
         int sync_count = (int) s[DS_SYNC_COUNT];
@@ -944,23 +952,36 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         }
         s[DS_SYNC_COUNT] = (uint32_t) sync_count;
 
-        // stage 1: the two 100-dibit codewords of a frame (FICH and, speculatively, the V/D2 DCH) in one Viterbi pass
-        DH_FOR_LANES(lane) {
-            if (lane < 25) {
-                uint32_t f = 0, d = 0;
-                for (int q = 0; q < 4; q++) {
-                    const int i = lane * 4 + q;
-                    f = (f << 2) | dh_sym_at(pl, 20 + (i * 20) % 100 + (i * 20) / 100);      // fich.cpp:16-19
-                    d = (d << 2) | dh_sym_at(pl, 120 + (i % 5) * 72 + (i * 2) / 10);         // ysf_phase.cpp:103-106
+        // stage 1: the two 100-dibit codewords of a frame (FICH and, speculatively, the V/D2 DCH) in one Viterbi pass,
+        // together with those of the following frame when it is already here
+        const int vo = have ? 2 : 0;                               // where this frame's decoded codewords are
+        if (have) ahead_pos = 0xFFFFFFFFu;
+        else {
+            DH_FOR_LANES(lane) {
+                if (lane < 25) {
+                    uint32_t f = 0, d = 0, f2 = 0, d2 = 0;
+                    for (int q = 0; q < 4; q++) {
+                        const int i = lane * 4 + q;
+                        const int fi = 20 + (i * 20) % 100 + (i * 20) / 100;                     // fich.cpp:16-19
+                        const int di = 120 + (i % 5) * 72 + (i * 2) / 10;                        // ysf_phase.cpp:103-106
+                        f = (f << 2) | dh_sym_at(pl, fi);
+                        d = (d << 2) | dh_sym_at(pl, di);
+                        if (two) {
+                            f2 = (f2 << 2) | (dh_view_at(syms, pos + 480u + (uint32_t) fi) & 3u);
+                            d2 = (d2 << 2) | (dh_view_at(syms, pos + 480u + (uint32_t) di) & 3u);
+                        }
+                    }
+                    S.vit_in[0][lane] = (uint8_t) f; S.vit_in[1][lane] = (uint8_t) d;
+                    if (two) { S.vit_in[2][lane] = (uint8_t) f2; S.vit_in[3][lane] = (uint8_t) d2; }
                 }
-                S.vit_in[0][lane] = (uint8_t) f; S.vit_in[1][lane] = (uint8_t) d;
             }
-        }
-        DH_BARRIER();
-        DH_DCLK(2);
-        {
-            const int sizes1[4] = { 100, 100, 0, 0 };
-            dh_viterbi_wave(S, sizes1);
+            DH_BARRIER();
+            DH_DCLK(2);
+            {
+                const int sizes1[4] = { 100, 100, two ? 100 : 0, two ? 100 : 0 };
+                dh_viterbi_wave(S, sizes1);
+            }
+            if (two) ahead_pos = pos + 480u;
         }
         DH_DCLK(3);
 
@@ -969,7 +990,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
         {
             uint32_t g[4];
             for (int i = 0; i < 4; i++) {
-                g[i] = (uint32_t) S.vit_out[0][i * 3] << 16 | (uint32_t) S.vit_out[0][i * 3 + 1] << 8 | S.vit_out[0][i * 3 + 2];
+                g[i] = (uint32_t) S.vit_out[vo][i * 3] << 16 | (uint32_t) S.vit_out[vo][i * 3 + 1] << 8 | S.vit_out[vo][i * 3 + 2];
                 fresh &= dh_block_decode_wave<12>(T.g2412, P.T->lut_g2412, g[i]);
             }
             if (fresh) {
@@ -1016,7 +1037,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                         c.nout += 40;
                     }
                     if (fresh) {                                                    // decodeV2DataChannel (:258-269)
-                        const uint8_t* w = S.vit_out[1];
+                        const uint8_t* w = S.vit_out[vo + 1];
                         const uint32_t checksum = (uint32_t) w[10] << 8 | w[11];
                         if (dh_crc16_bytewise(w, 10) == checksum) {
                             uint8_t dch[13];
@@ -1047,7 +1068,9 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 }
             } else if (frame_type == 0) {                                           // header (:139-161)
                 dh_emit(c, DH_EV_YSF_META_RESET, 0, 1, nullptr, 0);
-                // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333)
+                // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333); this pass uses
+                // the slots of a frame decoded ahead, which is then simply decoded again when its turn comes
+                ahead_pos = 0xFFFFFFFFu;
                 DH_FOR_LANES(lane) {
                     if (lane < 45) {
                         uint32_t a = 0, b = 0;
