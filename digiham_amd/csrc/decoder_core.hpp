@@ -220,7 +220,7 @@ struct DhDecShared {
     uint32_t colword[16];
     uint32_t vit_metric[2][64];
     uint64_t vit_dec[192];
-    uint8_t  vit_in[4][48];           // up to 4 concurrent codewords, dibits packed 4/byte
+    uint32_t vit_in[4][48];           // up to 4 concurrent codewords of 192 dibits, one dibit per byte (dh_vit_word)
     uint8_t  vit_out[4][24];
     uint8_t  vit_best_metric[4];
 #ifdef DH_PHASE_CLOCKS
@@ -679,6 +679,12 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 // minimum metric, trellis.c:94-98) and trace the decisions back.  Output bits are assembled in a register and
 // stored once per byte; the eight decision words of a byte are fetched together (their addresses do not depend
 // on the trace-back state).
+// four dibits packed MSB first (the reference's input format, trellis.c:47-49) -> one dibit per byte, first in byte 0:
+// the layout of S.vit_in, whose words are v_perm selectors for the branch-metric tables as they stand
+DH_HD uint32_t dh_vit_word(uint32_t packed) {
+    return ((packed >> 6) & 3u) | ((packed >> 4) & 3u) << 8 | ((packed >> 2) & 3u) << 16 | (packed & 3u) << 24;
+}
+
 DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
     DH_FOR_LANES(lane) {
         if ((lane & 15) == 0) {
@@ -718,7 +724,11 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
 
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // gfx950 forward pass: path metrics stay in registers, the two predecessor metrics come through ds_bpermute
-// (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.
+// (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.  Per step and lane: two byte
+// adds (SDWA: uint8 wrap for free, like the reference's uint8 metrics), a compare, a min, two v_writelane; the branch
+// metrics of four steps come from two v_perm whose selector is the input word itself.
+// NXDN = the reference's NXDN flavour (trellis.cpp:35-60) AND codewords of different lengths in one pass: the plain
+// flavour is only called with equal lengths (zero-length slots run along and are ignored).
 template <bool NXDN = false>
 __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
     const int lane = (int) threadIdx.x, g = lane >> 4, i = lane & 15;
@@ -737,42 +747,46 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
     uint32_t tab0 = 0, tab1 = 0;
 #pragma unroll
     for (uint32_t v = 0; v < 4; v++) { tab0 |= (uint32_t) __popc(v ^ t0) << (8 * v); tab1 |= (uint32_t) __popc(v ^ t1) << (8 * v); }
-    // The uint8 path metric lives in the TOP byte of a register: adding (branch metric << 24) wraps exactly like the
-    // reference's uint8 arithmetic and unsigned compares see the same order, with no masking.
-    const uint32_t* inw = reinterpret_cast<const uint32_t*>(S.vit_in[g]);       // dibits 4 per byte, first in the MSBs
+    const uint32_t* inw = S.vit_in[g];                  // one dibit per byte, four steps per word
     uint32_t m = 0;
     for (int blk = 0; blk * 64 < steps; blk++) {
         // decisions of 64 steps collect in one register pair, step (64 blk + c) in lane c, written with v_writelane
         uint32_t dlo = 0, dhi = 0;
 #pragma unroll
-        for (int wq = 0; wq < 4; wq++) {
-            const uint32_t w = inw[blk * 4 + wq];
+        for (int wq = 0; wq < 16; wq++) {
+            if (blk * 64 + wq * 4 < steps) {
+                const uint32_t w = inw[blk * 16 + wq];
+                const uint32_t h0 = __builtin_amdgcn_perm(tab0, tab0, w), h1 = __builtin_amdgcn_perm(tab1, tab1, w);
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int c = wq * 16 + q, pos = blk * 64 + c;
-                if (pos < steps) {
-                    const int sh = 8 * (q >> 2) + 6 - 2 * (q & 3);
-                    const uint32_t sel = ((w >> sh) & 3u) | 0x0C0C0C00u;                   // v_perm selector: byte `dibit`, zeros above
-                    const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
-                    const uint32_t m0 = a + (__builtin_amdgcn_perm(tab0, tab0, sel) << 24);
-                    const uint32_t m1 = b + (__builtin_amdgcn_perm(tab1, tab1, sel) << 24);
-                    const bool active = pos < mysize;
-                    // NXDN (trellis.cpp:35-60): for the first four steps a state that overlaps the shifting `blocked`
-                    // mask only looks at its k = 0 predecessor
-                    const bool both = !NXDN || pos >= 4 || ((uint32_t) i & ((0xFu << pos) & 0xFu)) == 0u;
-                    const bool take1 = active && both && (m1 < m0);
-                    if (active) m = take1 ? m1 : m0;
-                    const uint64_t dec = __ballot(take1 ? 1 : 0);
-                    const uint32_t slo = (uint32_t) dec, shi = (uint32_t) (dec >> 32), sc = (uint32_t) c;
-                    uint32_t keep;
-                    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
-                        : "+v"(dlo), "+v"(dhi), "=&s"(keep) : "s"(slo), "s"(shi), "s"(sc));
+                for (int q = 0; q < 4; q++) {
+                    const int c = wq * 4 + q, pos = blk * 64 + c;
+                    if (pos < steps) {
+                        const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
+                        const uint32_t m0 = (a + ((h0 >> (8 * q)) & 0xFFu)) & 0xFFu;
+                        const uint32_t m1 = (b + ((h1 >> (8 * q)) & 0xFFu)) & 0xFFu;
+                        bool take1 = m1 < m0;
+                        if (NXDN) {
+                            const bool active = pos < mysize;
+                            // for the first four steps a state that overlaps the shifting `blocked` mask only looks
+                            // at its k = 0 predecessor
+                            const bool both = c >= 4 || blk > 0 || ((uint32_t) i & ((0xFu << c) & 0xFu)) == 0u;
+                            take1 = take1 && active && both;
+                            if (active) m = take1 ? m1 : m0;
+                        } else {
+                            m = m1 < m0 ? m1 : m0;
+                        }
+                        const uint64_t dec = __builtin_amdgcn_ballot_w64(take1);
+                        const uint32_t slo = (uint32_t) dec, shi = (uint32_t) (dec >> 32), sc = (uint32_t) c;
+                        uint32_t keep;
+                        asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+                            : "+v"(dlo), "+v"(dhi), "=&s"(keep) : "s"(slo), "s"(shi), "s"(sc));
+                    }
                 }
             }
         }
         S.vit_dec[blk * 64 + lane] = (uint64_t) dhi << 32 | dlo;
     }
-    S.vit_metric[0][lane] = m >> 24;
+    S.vit_metric[0][lane] = m;
     __syncthreads();
     dh_viterbi_finish(S, sizes, 0);
 }
@@ -791,7 +805,7 @@ inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
             bool sel = false;
             uint32_t nm = S.vit_metric[cur][lane];
             if (pos < sizes[g]) {
-                const uint32_t in = ((uint32_t) S.vit_in[g][pos >> 2] >> (2 * (3 - (pos & 3)))) & 3u;
+                const uint32_t in = (S.vit_in[g][pos >> 2] >> (8 * (pos & 3))) & 3u;
                 const uint32_t outbit = (uint32_t) i >> 3;
                 const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
                 const uint32_t m0 = (S.vit_metric[cur][g * 16 + p0] + (uint32_t) dh_popc32(in ^ dh_trellis_out(p0, outbit))) & 0xFFu;
@@ -971,8 +985,8 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                             d2 = (d2 << 2) | (dh_view_at(syms, pos + 480u + (uint32_t) di) & 3u);
                         }
                     }
-                    S.vit_in[0][lane] = (uint8_t) f; S.vit_in[1][lane] = (uint8_t) d;
-                    if (two) { S.vit_in[2][lane] = (uint8_t) f2; S.vit_in[3][lane] = (uint8_t) d2; }
+                    S.vit_in[0][lane] = dh_vit_word(f); S.vit_in[1][lane] = dh_vit_word(d);
+                    if (two) { S.vit_in[2][lane] = dh_vit_word(f2); S.vit_in[3][lane] = dh_vit_word(d2); }
                 }
             }
             DH_BARRIER();
@@ -1081,7 +1095,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                             a = (a << 2) | dh_sym_at(pl, inpos);
                             b = (b << 2) | dh_sym_at(pl, inpos + 36);
                         }
-                        S.vit_in[2][lane] = (uint8_t) a; S.vit_in[3][lane] = (uint8_t) b;
+                        S.vit_in[2][lane] = dh_vit_word(a); S.vit_in[3][lane] = dh_vit_word(b);
                     }
                 }
                 DH_BARRIER();
@@ -1279,7 +1293,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                         }
                         v = (v << 1) | x;
                     }
-                    S.vit_in[0][l] = (uint8_t) v;
+                    S.vit_in[0][l] = dh_vit_word(v);
                 } else if (l >= 16 && l < 64) {                     // facch1.cpp:39-61
                     const int blk = (l - 16) / 24, by = (l - 16) % 24;
                     uint32_t v = 0;
@@ -1293,7 +1307,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                         }
                         v = (v << 1) | x;
                     }
-                    S.vit_in[1 + blk][by] = (uint8_t) v;
+                    S.vit_in[1 + blk][by] = dh_vit_word(v);
                 }
             }
             DH_BARRIER();
@@ -1408,7 +1422,7 @@ DH_HD void dh_pocsag_take32(const DhSymView& syms, uint32_t pos, uint32_t& word,
 // Message::serialize with the StringSerializer (message.cpp:17-25, meta.cpp:8-17): `address:<n>;message:<text>\n`
 DH_HD void dh_pocsag_serialize(DhDecCtx& c, DhState& s, DhDecShared& S) {
     if (!s[DS_PC_HAS] || (uint32_t) s[DS_PC_POS] == 0u) return;
-    uint8_t* line = &S.vit_in[0][0];                      // 192 bytes of scratch, unused by this protocol
+    uint8_t* line = reinterpret_cast<uint8_t*>(&S.vit_in[0][0]);     // 768 bytes of scratch, unused by this protocol
     uint32_t n = 0;
     const char* a = "address:";
     for (int i = 0; i < 8; i++) line[n++] = (uint8_t) a[i];

@@ -97,7 +97,7 @@ DH_HD void dh_trellis_wave(const uint8_t* in, size_t in_stride, int n_dibits, ui
         for (int e = lane; e < 4 * nin; e += DH_WAVE) {
             const int g = e / nin, b = e % nin;
             const size_t cw = wave * 4 + g;
-            S.vit_in[g][b] = cw < n ? in[cw * in_stride + b] : (uint8_t) 0;
+            S.vit_in[g][b] = dh_vit_word(cw < n ? in[cw * in_stride + b] : (uint8_t) 0);
         }
     }
     DH_BARRIER();
