@@ -58,7 +58,7 @@ def profiled_traffic(workload, channels, T):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
     KiB, per-dispatch average; MI355X_MICROARCH.md) -- bench.py cannot collect counters itself.  Only for the
     configuration those passes were run on (tools/profile_gpu.sh: the default workload)."""
-    path = os.path.join(ROOT, "profiles", "r01_h_chain_pmc.txt")
+    path = os.path.join(ROOT, "profiles", "r01_k_chain_pmc.txt")
     if workload != "dmr_full" or channels != 16384 or T != 190080 or not os.path.exists(path):
         return None, None
     fetch = write = None
@@ -69,7 +69,7 @@ def profiled_traffic(workload, channels, T):
             write = float(line.split("avg=")[1].split()[0])
     if fetch is None or write is None:
         return None, None
-    return fetch * 2.0 * 1024.0 + write * 1024.0, "profiles/r01_h_chain_pmc.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)"
+    return fetch * 2.0 * 1024.0 + write * 1024.0, "profiles/r01_k_chain_pmc.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)"
 
 
 def oracle_kw(proto):
