@@ -37,13 +37,16 @@ int hip_fail(hipError_t e, const char* what) {
 #ifndef DH_TILES_PER_WG
 #define DH_TILES_PER_WG 4
 #endif
+#ifndef DH_LB_NARROW
+#define DH_LB_NARROW 2   // the 161-tap kernels: 256 VGPRs
+#endif
 #ifndef DH_LB
-#define DH_LB 3          // minimum waves per SIMD the wide-filter kernels are register-budgeted for
+#define DH_LB 4          // minimum waves per SIMD the wide-filter kernels are register-budgeted for (128 VGPRs)
 #endif
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
 template <int NZ, bool FAST, int SPS>
-__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(const DhDspParams P) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
     dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_rrc_demod(co
 // The two stages use the LDS block one after the other.
 // SPS = 10 is the specialised slicer of the DMR / YSF / D-Star pipes, SPS = 0 takes the run-time value (NXDN: 20).
 template <int NZ, bool FAST, int PROTO, int SPS = 10>
-__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_chain(const DhDspParams P, const DhDecParams D) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_chain(const DhDspParams P, const DhDecParams D) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     {
         DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_LB)) void k_chain(const 
 }
 
 template <int NZ, bool FAST>
-__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? 2 : DH_TILE_LB)) void k_rrc_tile(const DhRrcParams R) {
+__global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_TILE_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared S = dh_dsp_carve(dh_smem, 0u);
     // DH_TILES_PER_WG consecutive tiles of one channel per wavefront: fewer, longer-lived workgroups
