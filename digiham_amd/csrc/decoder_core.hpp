@@ -1045,7 +1045,11 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                         DH_FOR_LANES(lane) {
                             if (lane < 40) {
                                 const int blk = lane >> 3, j = lane & 7;
+#ifdef DH_VD2_SKIP
+                                o[lane] = (uint8_t) data_type;      // timing experiment (results are wrong)
+#else
                                 o[lane] = j == 0 ? (uint8_t) data_type : dh_ysf_v2_voice_byte(pl, 120 + 20 + blk * 72, j - 1);
+#endif
                             }
                         }
                         c.nout += 40;

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 x, info = synth_torch.make_batch(torch, dev, proto, B, 132 if proto == "dmr" else 40, seed=1000)
 T = info["samples_per_channel"]
 ctx = api.Context(device=0)
-K = 10
+K = int(os.environ.get('SS_K', '10'))
 for share in shares:
     cuts = [0]
     for v in share:
