@@ -152,3 +152,27 @@ def test_tiny_empty_and_ragged_pushes(ctx, oracle):
     go, ge = np.concatenate(o), np.concatenate(e)
     assert len(go) == len(out) and (go == out).all() and ge.tobytes() == ev.tobytes()
     assert (ev["type"] == EV_HEADER).sum() >= 2
+
+
+def test_decoder_only_rows_at_odd_addresses(ctx, oracle):
+    """Three channels in a symbol buffer with an odd row pitch: the packed fast path funnel-shifts unaligned rows."""
+    streams = [synth.dstar_stream(s, 4)[0] for s in (41, 42, 43)]
+    n = min(len(s) for s in streams)
+    chunk, pitch = 1501, 1503
+    eng = api.Engine(3, pitch, rrc="none", demod="none", proto="dstar", ctx=ctx)
+    got_o, got_e = [[] for _ in range(3)], [[] for _ in range(3)]
+    for lo in range(0, n, chunk):
+        part = np.zeros((3, pitch), np.uint8)
+        cnt = np.zeros(3, np.uint32)
+        for b in range(3):
+            seg = streams[b][lo:min(lo + chunk, n)]
+            part[b, :len(seg)] = seg; cnt[b] = len(seg)
+        eng.push_symbols(part, cnt)
+        f, fc = eng.frames(); ev, ec = eng.events()
+        for b in range(3):
+            got_o[b].append(f[b, :fc[b]].copy()); got_e[b].append(ev[b, :ec[b]].copy())
+    eng.close()
+    for b in range(3):
+        out, ev = oracle.Decoder("dstar").process(streams[b][:n])
+        go, ge = np.concatenate(got_o[b]), np.concatenate(got_e[b])
+        assert len(out) > 0 and len(go) == len(out) and (go == out).all() and ge.tobytes() == ev.tobytes()
