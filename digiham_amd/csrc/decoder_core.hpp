@@ -511,8 +511,11 @@ DH_HD void dh_stage_decoder_lds(const DhDecParams& P, DhDecShared& S, const uint
 DH_HD const DhFecTables& dh_lds_tables(const DhDecShared& S) { return *reinterpret_cast<const DhFecTables*>(S.fec_small); }
 
 // BPTC(196,96) of a data burst, columns on lanes (bptc_196_96.c:5-59 on the dibits of dmr_phase.cpp:256-269)
-DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared& S, uint8_t* out12) {
+DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, uint8_t* out12) {
+    // 15 columns on 15 lanes: gather through the interleave from the bit planes (reading the symbol window directly
+    // instead measured slower: 1.97 against 1.77 ms), Hamming(13,9); the corrected column words stay in registers
     uint64_t okmask = 0;
+    DH_LANE_VALUE(uint32_t, colw);
     DH_FOR_LANES(lane) {
         bool ok = true;
         uint32_t w = 0;
@@ -528,24 +531,34 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, DhDecShared
             ok = dh_block_decode(T.h139, T.lut_h139, w);
         }
         DH_BALLOT_ACC(okmask, ok, lane);
-        if (lane < 15) S.colword[lane] = w;
+        DH_LV(colw, lane) = w;
     }
-    DH_BARRIER();
     if (okmask != ~0ull) return false;
-    bool ok = true;
+    // the 9 data rows: row i is bit 12-i of every column word -- one vote per row (column k in bit k, the row word wants
+    // it in bit 14-k); then the rows on 9 lanes for Hamming(15,11)
     uint32_t rows[9];
     for (int i = 0; i < 9; i++) {
-        uint32_t w = 0;
-        for (int k = 0; k < 15; k++) w |= ((S.colword[k] >> (12 - i)) & 1u) << (14 - k);
-        ok &= dh_block_decode(T.h1511, T.lut_h1511, w);
-        rows[i] = w;
+        uint64_t m = 0;
+        DH_FOR_LANES(lane) { DH_BALLOT_ACC(m, lane < 15 && ((DH_LV(colw, lane) >> (12 - i)) & 1u) != 0u, lane); }
+        rows[i] = dh_brev32((uint32_t) m) >> 17;
     }
-    DH_BARRIER();
-    if (!ok) return false;
+    uint64_t rowok = 0;
+    DH_LANE_VALUE(uint32_t, roww);
+    DH_FOR_LANES(lane) {
+        bool ok = true;
+        uint32_t w = 0;
+        if (lane < 9) {
+            for (int i = 0; i < 9; i++) if (lane == i) w = rows[i];
+            ok = dh_block_decode(T.h1511, T.lut_h1511, w);
+        }
+        DH_BALLOT_ACC(rowok, ok, lane);
+        DH_LV(roww, lane) = w;
+    }
+    if (rowok != ~0ull) return false;
     uint64_t acc = 0; int nacc = 0, ob = 0;
     for (int r = 0; r < 9; r++) {
         const int nb = r == 0 ? 8 : 11;
-        acc = (acc << nb) | ((rows[r] >> 4) & ((1u << nb) - 1)); nacc += nb;
+        acc = (acc << nb) | ((DH_LV_READ(roww, r) >> 4) & ((1u << nb) - 1)); nacc += nb;
         while (nacc >= 8) { out12[ob++] = (uint8_t) (acc >> (nacc - 8)); nacc -= 8; }
     }
     return true;
@@ -616,7 +629,11 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             const DhDmrFrameResult R = dh_dmr_frame_head(c, syms, pos, S);
             DH_DCLK(2);
             if (R.to_sync) { phase = 0; continue; }
+#ifdef DH_DMR_SKIP_VOICE
+            if (false) {        // timing experiment (results are wrong)
+#else
             if (R.voice_out) {
+#endif
                 uint8_t* o = c.out + c.nout;
                 DH_FOR_LANES(lane) {
                     if (lane < 27) {
@@ -627,12 +644,16 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
                 }
                 c.nout += 27;
             }
+#ifdef DH_DMR_SKIP_BPTC
+            if (false) {        // timing experiment (results are wrong)
+#else
             if (R.want_bptc) {
+#endif
                 dh_load_planes(syms, pos, total, pl, 3);
                 uint8_t lc[12];
                 for (int i = 0; i < 12; i++) lc[i] = 0;
                 const int slot = (int) s[DS_SLOT];
-                if (dh_dmr_bptc_wave(dh_lds_tables(S), pl, S, lc)) {
+                if (dh_dmr_bptc_wave(dh_lds_tables(S), pl, lc)) {
                     dh_emit(c, DH_EV_DMR_BPTC, (uint8_t) slot, R.data_type, lc, 12);
                     if (R.data_type == 1) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 0, lc, 9);
                     else if (R.data_type == 2 || R.data_type == 9) dh_emit(c, DH_EV_DMR_SOFT_RESET, (uint8_t) slot, R.data_type, nullptr, 0);
