@@ -720,22 +720,21 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
                 S.vit_best_metric[g] = (uint8_t) bm;
                 const int nbytes = (size + 7) >> 3;
                 for (int b = nbytes; b < 24; b++) S.vit_out[g][b] = 0;
-                uint32_t state = best;
-                const int gsh = g * 16;
+                // trace back without masking the state register: H = (H << 1) | k keeps the state in its low four bits
+                // and pushes the older output bits up, so after the eight steps of a byte they sit in bits 4..11,
+                // first step highest: the byte is their bit reversal.  A step is: 16 decision bits of this codeword
+                // (read as a halfword), pick bit `state`, shift it in.
+                uint32_t H = best;
+                const uint16_t* dec16 = reinterpret_cast<const uint16_t*>(S.vit_dec) + g;
                 for (int b = nbytes - 1; b >= 0; b--) {
-                    uint64_t d[8];
+                    uint32_t d[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) d[j] = S.vit_dec[(b * 8 + j) < 192 ? (b * 8 + j) : 191];
-                    uint32_t byte = 0;
+                    for (int j = 0; j < 8; j++) d[j] = dec16[4 * ((b * 8 + j) < 192 ? (b * 8 + j) : 191)];
 #pragma unroll
                     for (int j = 7; j >= 0; j--) {
-                        if (b * 8 + j < size) {
-                            byte |= (state >> 3) << (7 - j);
-                            const uint32_t k = (uint32_t) ((d[j] >> (gsh + (int) state)) & 1ull);
-                            state = ((state << 1) & 0xEu) | k;
-                        }
+                        if (b * 8 + j < size) H = (H << 1) | ((d[j] >> (H & 15u)) & 1u);
                     }
-                    S.vit_out[g][b] = (uint8_t) byte;
+                    S.vit_out[g][b] = (uint8_t) (dh_brev32((H >> 4) & 0xFFu) >> 24);
                 }
             }
         }
