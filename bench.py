@@ -37,6 +37,8 @@ WORKLOADS = {
                  "full chain rrc(wide)->gfsk(10)->ysf_decoder incl. Golay/Viterbi (BASELINE configs[3])"),
     "rrc_gfsk": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="none", keep_filtered=True),
                  "rrc(wide) materialised + gfsk(10), float path (BASELINE configs[1])"),
+    "rrc_gfsk_fast": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="none", keep_filtered=True, fast_fir=True),
+                      "rrc(wide) materialised with the FMA FIR (1e-6 float tolerance of configs[1]) + gfsk(10)"),
     "dmr_fast": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=True),
                  "full DMR chain with the FMA FIR (float outputs 1e-6, dibits not guaranteed bit-exact)"),
     # narrow RRC -> gfsk -s 20 -> nxdn_decoder (examples/nxdn48-decoder.sh)
