@@ -948,16 +948,35 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
         // every tile but the first reads `in` only: 16 bytes per lane per load
         const float* src = in + (t0 - NZ);
         const uint32_t have = cnt + NZ;
-        DH_FOR_LANES(lane) {
-            for (uint32_t e = 4u * (uint32_t) lane; e < DH_FTILE + NZ; e += 4u * DH_WAVE) {
-                dh_f4 v; v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; v.w = 0.0f;
-                if (e + 4u <= have) v = dh_load4_unaligned(src + e);
-                else if (e < have) {
-                    v.x = src[e];
-                    if (e + 1u < have) v.y = src[e + 1u];
-                    if (e + 2u < have) v.z = src[e + 2u];
+        if (have >= DH_FTILE + NZ) {
+            // a full tile: the loads are issued unconditionally (clamped addresses) so that all of them are in flight
+            // together -- under a branch each would be waited for before the next starts
+            constexpr int NV = (DH_FTILE + NZ + 4 * DH_WAVE - 1) / (4 * DH_WAVE);
+            DH_FOR_LANES(lane) {
+                dh_f4 v[NV];
+#pragma unroll
+                for (int r = 0; r < NV; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    v[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
                 }
-                dh_store4(&S.xf[DH_XPAD(e)], v);
+#pragma unroll
+                for (int r = 0; r < NV; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XPAD(e)], v[r]);
+                }
+            }
+        } else {
+            DH_FOR_LANES(lane) {
+                for (uint32_t e = 4u * (uint32_t) lane; e < DH_FTILE + NZ; e += 4u * DH_WAVE) {
+                    dh_f4 v; v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; v.w = 0.0f;
+                    if (e + 4u <= have) v = dh_load4_unaligned(src + e);
+                    else if (e < have) {
+                        v.x = src[e];
+                        if (e + 1u < have) v.y = src[e + 1u];
+                        if (e + 2u < have) v.z = src[e + 2u];
+                    }
+                    dh_store4(&S.xf[DH_XPAD(e)], v);
+                }
             }
         }
     } else {
@@ -971,6 +990,7 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
         }
     }
     DH_BARRIER();
+    DH_COMPILER_FENCE();                                // the taps become live after the staging registers are dead
     float tv[NZ / 2 + 1];
 #pragma unroll
     for (int i = 0; i <= NZ / 2; i++) { tv[i] = R.taps[i]; DH_TO_VGPR(tv[i]); }
