@@ -199,6 +199,21 @@ template <bool FAST> __device__ __forceinline__ dh_f2 dh_f2_mac(float c, dh_f2 w
     const dh_f2 p = c * w;                                 // v_pk_mul_f32, rounded
     return acc + p;                                        // v_pk_add_f32, rounded (-ffp-contract=off)
 }
+// The same with the tap as ONE HALF of a 64-bit scalar register pair (two taps per pair, chosen with op_sel): the
+// packed multiply takes the pair as its scalar operand, so the taps occupy 41 / 81 SGPRs instead of as many VGPRs.
+// Left to the compiler a scalar tap becomes a (c, c) pair -- two SGPRs per tap, which spills SGPRs into VGPR lanes
+// in the slicer kernel -- hence the explicit instruction.
+template <bool FAST, int HALF> __device__ __forceinline__ dh_f2 dh_f2_mac_pair(dh_f2 cc, dh_f2 w, dh_f2 acc) {
+    dh_f2 p;
+    if (FAST) {
+        if (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(p) : "s"(cc), "v"(w), "v"(acc));
+        else           asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(p) : "s"(cc), "v"(w), "v"(acc));
+        return p;
+    }
+    if (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "s"(cc), "v"(w));
+    else           asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(cc), "v"(w));
+    return acc + p;                                        // v_pk_add_f32, rounded (-ffp-contract=off)
+}
 #else
 struct dh_f2 { float x, y; };
 inline dh_f2 dh_f2_make(float a, float b) { dh_f2 v; v.x = a; v.y = b; return v; }
@@ -263,32 +278,44 @@ template <int NZ, int B> __device__ __forceinline__ void dh_fir_issue(uint32_t a
 __device__ __forceinline__ void dh_fir_arrived(dh_f2 (&d)[DH_FIR_G]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
 }
-template <int NZ, bool FAST, int B> struct DhFirBatch {
+// SG: the taps are read as 64-bit scalar pairs from the kernel arguments (dh_f2_mac_pair) instead of from a register
+// array.  A packed multiply with a scalar operand issues a little slower (slicer kernels: +5 %), so this only pays
+// where the 41 / 81 tap registers cost a wavefront per SIMD -- the stand-alone RRC kernel (168 -> 105 VGPRs).
+template <int NZ, bool FAST, int B, bool SG = false> struct DhFirBatch {
+    // tap I = B * DH_FIR_G + G: accumulate it on the eight window pairs, then slide the window by one sample
+    template <int G> static __device__ __forceinline__ void tap(const float* taps, dh_f2 (&accp)[DH_FIR_H], dh_f2 (&w)[DH_FIR_H], dh_f2 (&cur)[DH_FIR_G]) {
+        constexpr int I = B * DH_FIR_G + G;
+        if constexpr (I <= NZ) {
+            constexpr int TI = I <= NZ / 2 ? I : NZ - I;
+            if constexpr (SG) {
+                const dh_f2 cc = reinterpret_cast<const dh_f2*>(taps)[TI >> 1];     // wave-uniform 64-bit load
+#pragma unroll
+                for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac_pair<FAST, TI & 1>(cc, w[j], accp[j]);
+            } else {
+                const float c = taps[TI];
+#pragma unroll
+                for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac<FAST>(c, w[j], accp[j]);
+            }
+            if constexpr (I < NZ) {
+#pragma unroll
+                for (int j = 0; j < DH_FIR_H - 1; j++) w[j] = w[j + 1];
+                w[DH_FIR_H - 1] = cur[G];
+            }
+        }
+    }
     static __device__ __forceinline__ void run(const float* taps, uint32_t addr, dh_f2 (&accp)[DH_FIR_H], dh_f2 (&w)[DH_FIR_H], dh_f2 (&cur)[DH_FIR_G]) {
         if constexpr (B * DH_FIR_G <= NZ) {
             dh_f2 nxt[DH_FIR_G];
             dh_fir_issue<NZ, B + 1>(addr, nxt);
-#pragma unroll
-            for (int g = 0; g < DH_FIR_G; g++) {
-                const int i = B * DH_FIR_G + g;
-                if (i <= NZ) {
-                    const float c = taps[i <= NZ / 2 ? i : NZ - i];
-#pragma unroll
-                    for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac<FAST>(c, w[j], accp[j]);
-                    if (i < NZ) {
-#pragma unroll
-                        for (int j = 0; j < DH_FIR_H - 1; j++) w[j] = w[j + 1];
-                        w[DH_FIR_H - 1] = cur[g];
-                    }
-                }
-            }
+            tap<0>(taps, accp, w, cur); tap<1>(taps, accp, w, cur); tap<2>(taps, accp, w, cur); tap<3>(taps, accp, w, cur);
+            static_assert(DH_FIR_G == 4, "four taps per batch");
             if constexpr ((B + 1) * DH_FIR_G < NZ) dh_fir_arrived(nxt);
-            DhFirBatch<NZ, FAST, B + 1>::run(taps, addr, accp, w, nxt);
+            DhFirBatch<NZ, FAST, B + 1, SG>::run(taps, addr, accp, w, nxt);
         }
     }
 };
 
-template <int NZ, bool FAST>
+template <int NZ, bool FAST, bool SG = false>
 __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
     // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
     const uint32_t addr = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (xs_all + (DH_FIR_L + 1) * lane);
@@ -302,7 +329,7 @@ __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, doub
     dh_fir_arrived(cur);
 #pragma unroll
     for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_make(0.0f, 0.0f);
-    DhFirBatch<NZ, FAST, 0>::run(taps, addr, accp, w, cur);
+    DhFirBatch<NZ, FAST, 0, SG>::run(taps, addr, accp, w, cur);
     float acc[DH_FIR_L];
 #pragma unroll
     for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
@@ -592,9 +619,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
             float tv[NZ / 2 + 1];
 #pragma unroll
-            // (from the LDS copy into vector registers: taps read as scalar operands straight from the kernel
-            // arguments free 40 VGPRs but cost this kernel 9 % -- 12.9 -> 14.1 ms -- while the stand-alone RRC kernel
-            // below, which has few other scalars, gains 12 % from exactly that)
+            // (from the LDS copy into vector registers: taps as scalar operands free 40 VGPRs but cost this kernel 5 %,
+            // see DhFirBatch)
             for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
             DH_FOR_LANES_FRESH(lane) {
                 if ((uint32_t) (lane * DH_FIR_L) < need)
@@ -996,13 +1022,17 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
     DH_COMPILER_FENCE();                                // the taps become live after the staging registers are dead
     float tv[NZ / 2 + 1];
 #pragma unroll
-    for (int i = 0; i <= NZ / 2; i++) tv[i] = R.taps[i];       // scalar operands of the packed multiplies: 113 instead of 168 VGPRs
+    for (int i = 0; i <= NZ / 2; i++) tv[i] = R.taps[i];       // harness only: the GPU reads R.taps as scalar pairs (DhFirBatch SG)
     // Each lane produces 16 consecutive outputs.  Stored straight from registers, one store instruction would touch
     // 64 separate 64-byte pieces of the row; instead the tile goes through the (now idle) window block and leaves
     // as four fully coalesced 1 KB stores.
     DH_LANE_ARRAY(float, fo, DH_FIR_L);
     DH_FOR_LANES(lane) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        if ((uint32_t) lane * DH_FIR_L < cnt) dh_fir_lane<NZ, FAST, true>(R.taps, R.gain, R.rgain, R.inv_gain, S.xf, lane, DH_LA(fo, lane));
+#else
         if ((uint32_t) lane * DH_FIR_L < cnt) dh_fir_lane<NZ, FAST>(tv, R.gain, R.rgain, R.inv_gain, S.xf, lane, DH_LA(fo, lane));
+#endif
     }
     DH_BARRIER();                                       // every lane has read its window
     DH_FOR_LANES(lane) {
