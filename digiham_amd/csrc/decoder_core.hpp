@@ -747,9 +747,10 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
 // (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.  Per step and lane: two byte
 // adds (SDWA: uint8 wrap for free, like the reference's uint8 metrics), a compare, a min, two v_writelane; the branch
 // metrics of four steps come from two v_perm whose selector is the input word itself.
-// NXDN = the reference's NXDN flavour (trellis.cpp:35-60) AND codewords of different lengths in one pass: the plain
-// flavour is only called with equal lengths (zero-length slots run along and are ignored).
-template <bool NXDN = false>
+// NXDN = the reference's NXDN flavour (trellis.cpp:35-60); RAGGED = codewords of different non-zero lengths in one
+// pass (a shorter one must stop updating at its own length); otherwise zero-length slots simply run along and are
+// ignored.
+template <bool NXDN = false, bool RAGGED = NXDN>
 __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
     const int lane = (int) threadIdx.x, g = lane >> 4, i = lane & 15;
     int steps = 0;
@@ -785,13 +786,17 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
                         const uint32_t m0 = (a + ((h0 >> (8 * q)) & 0xFFu)) & 0xFFu;
                         const uint32_t m1 = (b + ((h1 >> (8 * q)) & 0xFFu)) & 0xFFu;
                         bool take1 = m1 < m0;
-                        if (NXDN) {
-                            const bool active = pos < mysize;
+                        if (NXDN && c < 4) {
                             // for the first four steps a state that overlaps the shifting `blocked` mask only looks
                             // at its k = 0 predecessor
-                            const bool both = c >= 4 || blk > 0 || ((uint32_t) i & ((0xFu << c) & 0xFu)) == 0u;
-                            take1 = take1 && active && both;
+                            take1 = take1 && (blk > 0 || ((uint32_t) i & ((0xFu << c) & 0xFu)) == 0u);
+                        }
+                        if (RAGGED) {
+                            const bool active = pos < mysize;
+                            take1 = take1 && active;
                             if (active) m = take1 ? m1 : m0;
+                        } else if (NXDN && c < 4) {
+                            m = take1 ? m1 : m0;
                         } else {
                             m = m1 < m0 ? m1 : m0;
                         }
@@ -812,7 +817,7 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
 }
 #else
 // plain statement of the same recursion for the CPU harness: metrics exchanged through the LDS arrays
-template <bool NXDN = false>
+template <bool NXDN = false, bool RAGGED = NXDN>
 inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
     int steps = 0;
     for (int g = 0; g < 4; g++) steps = sizes[g] > steps ? sizes[g] : steps;
@@ -1337,7 +1342,8 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
             DH_BARRIER();
             {
                 const int sizes[4] = { want_sacch ? 36 : 0, f0 ? 96 : 0, f1 ? 96 : 0, 0 };
-                if (want_sacch || f0 || f1) dh_viterbi_wave<true>(S, sizes);
+                if (f0 || f1) dh_viterbi_wave<true, true>(S, sizes);           // 36 / 96 / 96 steps side by side
+                else if (want_sacch) dh_viterbi_wave<true, false>(S, sizes);   // voice frames: the SACCH alone
             }
             if (want_sacch) {
                 const uint8_t* w = S.vit_out[0];
