@@ -171,3 +171,19 @@ def test_lc_fields_from_events(ctx):
     for e in lcs:
         f = api.parse_lc(e["payload"])
         assert (f["opcode"], f["target"], f["source"]) == (0, 1234, 5678901)
+
+
+@pytest.mark.parametrize("proto", ["dmr", "ysf", "nxdn", "dstar", "pocsag"])
+def test_noise_only_channels_match_oracle(ctx, oracle, proto):
+    """Channels that carry nothing but noise: the slicers' timing fallbacks and the decoders' false syncs (NXDN's
+    10-dibit sync word fires on noise and decodes frames) must still be the reference's."""
+    rng = np.random.default_rng(77)
+    n = {"nxdn": 60000, "pocsag": 120000}.get(proto, 30000)
+    x = (rng.normal(0, 0.25, (3, n)) + np.array([[0.0], [0.1], [-0.3]])).astype(np.float32)
+    ekw = {"nxdn": dict(rrc="narrow", sps=20), "dstar": dict(rrc="none", demod="fsk", sps=10),
+           "pocsag": dict(rrc="none", demod="fsk", sps=40, invert=True)}.get(proto, {})
+    okw = {"dmr": dict(proto=1), "ysf": dict(proto=2), "nxdn": dict(proto=3, rrc=2, sps=20),
+           "dstar": dict(proto=5, rrc=0, levels=2, sps=10), "pocsag": dict(proto=4, rrc=0, levels=2, sps=40, invert=True)}[proto]
+    ref = oracle.chain(x, **okw)
+    res = run_engine(ctx, x, proto, [n // 3, n - n // 3], **ekw)
+    assert_matches_oracle(res, ref, 3, proto + " noise")
