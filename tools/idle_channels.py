@@ -19,3 +19,12 @@ for proto, kw in (("dmr", {}), ("ysf", {}), ("dstar", dict(rrc="none", demod="fs
     a, b, c = eng.timing_read()
     print("%-7s noise only: rrc %.2f slicer/chain %.2f decoder %.2f ms; output bytes %d" % (proto, a.mean(), b.mean(), c.mean(), int(eng.frames()[1].sum())), flush=True)
     eng.close()
+
+# how often the timing recovery takes its ordered (exact-order) fallback on noise vs. on a clean signal
+from digiham_amd import synth_torch
+for name, sig in (("noise", x[:4096]), ("dmr", synth_torch.make_batch(torch, dev, "dmr", 4096, 132, seed=1000)[0])):
+    eng = api.Engine(4096, T, proto="none", ctx=ctx)
+    eng.push(sig); eng.sync()
+    blocks, ordered = eng.timing_stats()
+    print("%s: %d timing blocks, %d ordered fallbacks (%.2f %%)" % (name, int(blocks.sum()), int(ordered.sum()), 100.0 * ordered.sum() / max(blocks.sum(), 1)))
+    eng.close()
