@@ -3,7 +3,8 @@
  * state machines (TEST INFRASTRUCTURE ONLY).
  *
  * PARITY UNPINNED for the state machines (reference TUs need csdr headers, see
- * dh_oracle.h); the FEC they call is the pinned fec.c.  Metadata bookkeeping
+ * dh_oracle.h); the FEC they call is the pinned fec.c and the burst / frame elements
+ * (CACH/TACT, EMB, slot type, embedded LC, FICH) are the pinned elements.c.  Metadata bookkeeping
  * (MetaCollector, talker alias, GPS, callsign strings) is out of scope: every
  * call the reference makes into its MetaCollector is recorded as an orc_event
  * carrying the raw FEC-corrected bytes instead.
@@ -152,49 +153,6 @@ static int dmr_get_sync_type(const uint8_t* s) {
     return -1;
 }
 
-/* cach.cpp:11-31 (only the TACT is used downstream) + tact.cpp:9-12,20-22.
- * returns -1 when Hamming(7,4) fails, else the TC (slot) bit */
-static int dmr_cach_tact_slot(const uint8_t* raw) {
-    static const uint8_t tact_positions[7] = { 0, 4, 8, 12, 14, 18, 22 };
-    uint8_t tact = 0;
-    for (int i = 0; i < 7; i++) {
-        uint8_t bit = tact_positions[i];
-        int pos = bit / 2, shift = 1 - (bit % 2);
-        tact = (uint8_t) ((tact << 1) | ((raw[pos] >> shift) & 1));
-    }
-    if (!orc_hamming_7_4(&tact)) return -1;
-    return (tact >> 5) & 1;
-}
-
-/* embedded.cpp:32-94; returns 1 and fills lc[9] on success */
-static int dmr_embedded_get_lc(emb_collector* c, uint8_t* lc) {
-    if (c->offset < 3) return 0;
-    uint16_t m[8] = { 0 };
-    for (int i = 0; i < 16; i++) {
-        uint8_t byte = c->data[i];
-        for (int k = 0; k < 8; k++) m[k] = (uint16_t) ((m[k] << 1) | ((byte >> (7 - k)) & 1));
-    }
-    for (int i = 0; i < 7; i++) if (!orc_hamming_16_11(&m[i])) return 0;
-    uint16_t parity = 0;
-    for (int i = 0; i < 8; i++) parity ^= m[i];
-    if (parity != 0) return 0;
-    lc[0] = (uint8_t) ((m[0] & 0xFF00) >> 8);
-    lc[1] = (uint8_t) ((m[0] & 0x00E0) | ((m[1] & 0xF800) >> 11));
-    lc[2] = (uint8_t) (((m[1] & 0x07E0) >> 3) | ((m[2] & 0xC000) >> 14));
-    lc[3] = (uint8_t) ((m[2] & 0x3FC0) >> 6);
-    lc[4] = (uint8_t) ((m[3] & 0xFF00) >> 8);
-    lc[5] = (uint8_t) ((m[3] & 0x00C0) | ((m[4] & 0xFC00) >> 10));
-    lc[6] = (uint8_t) (((m[4] & 0x03C0) >> 2) | ((m[5] & 0xF000) >> 12));
-    lc[7] = (uint8_t) (((m[5] & 0x0FC0) >> 4) | ((m[6] & 0xC000) >> 14));
-    lc[8] = (uint8_t) ((m[6] & 0x3FC0) >> 6);
-    uint16_t checksum = 0;
-    for (int i = 0; i < 9; i++) checksum = (uint16_t) (checksum + lc[i]);
-    uint8_t checksum_mod = (uint8_t) (checksum % 31);
-    uint8_t received = 0;
-    for (int i = 0; i < 5; i++) received |= (uint8_t) ((m[i + 2] & 0x0020) >> (i + 1));
-    return checksum_mod == received;
-}
-
 static void dmr_slot_sync_lost(orc_decoder* d) {
     /* dmr_phase.cpp:175-182 == :194-200 */
     if (--d->slot_sync_count[d->slot] < 0) {
@@ -207,7 +165,8 @@ static void dmr_slot_sync_lost(orc_decoder* d) {
 
 /* dmr_phase.cpp:65-302.  returns 1 when the phase falls back to SyncPhase (no advance) */
 static int dmr_frame(orc_decoder* d, const uint8_t* p) {
-    int tact_slot = dmr_cach_tact_slot(p);
+    uint8_t tact = 0;                                    /* Cach::parse + Tact::getSlot (elements.c) */
+    int tact_slot = orc_dmr_cach_parse(p, &tact, NULL) ? (tact >> 5) & 1 : -1;
     uint8_t next = (uint8_t) (d->slot ^ 1);              /* :69 (0xFE while slot == -1) */
     if (tact_slot >= 0) {
         if ((uint8_t) tact_slot != next) {
@@ -249,14 +208,14 @@ static int dmr_frame(orc_decoder* d, const uint8_t* p) {
                 const uint8_t* raw = p + DMR_SYNC_OFFSET + i * 20;
                 for (int k = 0; k < 4; k++) emb_data = (uint16_t) ((emb_data << 2) | raw[k]);
             }
-            if (orc_quadratic_residue(&emb_data)) {
+            if (orc_dmr_emb_parse(&emb_data)) {
                 if (++d->sync_count > 5) d->sync_count = 5;
                 if (++d->slot_sync_count[slot] > 5) d->slot_sync_count[slot] = 5;
                 uint8_t embedded_data[4] = { 0 };
                 const uint8_t* emb_raw = p + DMR_SYNC_OFFSET + 4;
                 for (int i = 0; i < 16; i++) embedded_data[i / 4] |= (uint8_t) (emb_raw[i] << (6 - (i % 4) * 2));
                 emb_collector* c = &d->emb[slot];
-                uint8_t lcss = (emb_data >> 9) & 3, cc = (emb_data >> 12) & 15;
+                uint8_t lcss = orc_dmr_emb_lcss(emb_data), cc = orc_dmr_emb_color_code(emb_data);
                 emit(d, ORC_EV_DMR_EMB, (uint8_t) slot, lcss, &cc, 1);
                 switch (lcss) {
                     case LCSS_SINGLE: break;
@@ -269,7 +228,7 @@ static int dmr_frame(orc_decoder* d, const uint8_t* p) {
                     case LCSS_STOP: {
                         if (c->offset <= 3) { memcpy(c->data + c->offset * 4, embedded_data, 4); c->offset++; }
                         uint8_t lc[9];
-                        if (dmr_embedded_get_lc(c, lc)) emit(d, ORC_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
+                        if (orc_dmr_embedded_get_lc(c->data, c->offset, lc)) emit(d, ORC_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
                         c->offset = 0;
                         break;
                     }
@@ -313,8 +272,8 @@ static int dmr_frame(orc_decoder* d, const uint8_t* p) {
                 for (int i = 0; i < 5; i++) slot_type = (slot_type << 2) | (raw[i] & 3);
                 raw = p + DMR_SYNC_OFFSET + DMR_SYNC_SIZE;
                 for (int i = 0; i < 5; i++) slot_type = (slot_type << 2) | (raw[i] & 3);
-                if (orc_golay_20_8(&slot_type)) {
-                    uint8_t data_type = (slot_type >> 12) & 15, cc = (slot_type >> 16) & 15;
+                if (orc_dmr_slottype_parse(&slot_type)) {
+                    uint8_t data_type = orc_dmr_slottype_data_type(slot_type), cc = orc_dmr_slottype_color_code(slot_type);
                     emit(d, ORC_EV_DMR_SLOTTYPE, (uint8_t) slot, data_type, &cc, 1);
                     if (data_type != DT_RATE_3_4_DATA) {
                         uint8_t payload[25] = { 0 };
@@ -342,30 +301,6 @@ static int dmr_frame(orc_decoder* d, const uint8_t* p) {
 }
 
 /* ================================================================== YSF */
-
-/* fich.cpp:12-52 */
-static int ysf_fich_parse(const uint8_t* data, uint32_t* fich) {
-    uint8_t raw[25] = { 0 };
-    for (int i = 0; i < 100; i++) {
-        int offset = ((i * 20) % 100 + i * 20 / 100);
-        raw[i / 4] |= (uint8_t) ((data[offset] & 3) << (6 - 2 * (i % 4)));
-    }
-    uint8_t tr[13];
-    orc_decode_trellis(raw, 100, tr);
-    uint32_t g[4];
-    bool ok = true;
-    for (int i = 0; i < 4; i++) {
-        g[i] = (uint32_t) tr[i * 3] << 16 | (uint32_t) tr[i * 3 + 1] << 8 | tr[i * 3 + 2];
-        ok &= orc_golay_24_12(&g[i]);
-    }
-    if (!ok) return 0;
-    uint32_t fich_data = (g[0] & 0x00FFF000) << 8 | (g[1] & 0x00FFF000) >> 4 | (g[2] & 0x00FF0000) >> 16;
-    uint16_t fich_checksum = (uint16_t) ((g[2] & 0x0000F000) | (g[3] & 0x00FFF000) >> 12);
-    uint8_t be[4] = { (uint8_t) (fich_data >> 24), (uint8_t) (fich_data >> 16), (uint8_t) (fich_data >> 8), (uint8_t) fich_data };
-    if (orc_crc16_checksum(be, 4) != fich_checksum) return 0;
-    *fich = fich_data;
-    return 1;
-}
 
 /* ysf_phase.cpp:221-239 */
 static void ysf_decode_tribits(const uint8_t* input, uint8_t* output, uint8_t num) {
@@ -433,7 +368,7 @@ static int ysf_frame(orc_decoder* d, const uint8_t* p) {
         }
     }
     uint32_t fich = 0;
-    int fresh = ysf_fich_parse(p + YSF_SYNC_SIZE, &fich);
+    int fresh = orc_ysf_fich_parse(p + YSF_SYNC_SIZE, &fich);
     if (fresh) {
         d->running_fich = fich; d->has_running_fich = 1;
         uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };

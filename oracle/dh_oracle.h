@@ -13,7 +13,11 @@
  *   - FEC primitives (fec.c): PINNED against the reference's own C sources,
  *     compiled unmodified into oracle/_ref/libdigiham_ref_fec.so by
  *     oracle/Makefile and compared exhaustively (tests/test_oracle_vs_ref.py).
- *   - DSP (dsp.c) and frame state machines (dmr.c, ysf.c): PARITY UNPINNED --
+ *   - Burst / frame element parsers (elements.c: CACH/TACT, EMB, slot type,
+ *     embedded LC, LC getters, FICH; pocsag.c: Codeword; dstar.c: header): PINNED
+ *     against the reference's own csdr-free classes compiled in place
+ *     (oracle/_ref/libdigiham_ref_{dmr,ysf,pocsag,dstar}.so, tests/test_elements.py).
+ *   - DSP (dsp.c) and frame state machines (decoders.c): PARITY UNPINNED --
  *     those reference TUs include <csdr/module.hpp> (csdr 0.18, third-party,
  *     absent from this image), so they are unbuildable here without writing
  *     stand-in headers, which the rules forbid.  They are restated line by
@@ -121,6 +125,19 @@ enum {
     ORC_EV_DSTAR_META_RESET  = 70, /* b=0 terminator, 1 sync lost                    dstar_phase.cpp:97,105 */
     ORC_EV_POCSAG_CODEWORD = 48, /* a=position in the batch payload=corrected word, big endian  pocsag_phase.cpp:56-57 */
 };
+
+/* ------------------------------------------------------------- elements.c */
+/* burst / frame element parsers (pinned against oracle/_ref/libdigiham_ref_{dmr,ysf}.so) */
+int orc_dmr_cach_parse(const uint8_t* raw12, uint8_t* tact, uint8_t* payload3 /* or NULL */);
+int orc_dmr_emb_parse(uint16_t* data);
+uint8_t orc_dmr_emb_color_code(uint16_t data);
+uint8_t orc_dmr_emb_lcss(uint16_t data);
+int orc_dmr_slottype_parse(uint32_t* data);
+uint8_t orc_dmr_slottype_color_code(uint32_t data);
+uint8_t orc_dmr_slottype_data_type(uint32_t data);
+int orc_dmr_embedded_get_lc(const uint8_t* data16, int offset, uint8_t* lc9);
+void orc_dmr_lc_fields(const uint8_t* lc9, uint32_t* fields4 /* opcode, fid, source, target */, uint8_t* data7);
+int orc_ysf_fich_parse(const uint8_t* dibits100, uint32_t* fich);
 
 /* --------------------------------------------------------------- pocsag.c */
 bool orc_bch_31_21(uint32_t* data);

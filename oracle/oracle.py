@@ -421,3 +421,123 @@ def dstar_header_parse(raw660):
     out = np.zeros(41, np.uint8)
     ok = lib().orc_dstar_header_parse(_p(d), _p(out))
     return bool(ok), out
+
+
+# ------------------------------------------------------------------ burst / frame element parsers (batch)
+_REF_LIBS = {}
+
+
+def ref_lib(name):
+    """oracle/_ref/libdigiham_ref_<name>.so (the reference's own classes compiled in place), or None when not built."""
+    if name not in _REF_LIBS:
+        so = os.path.join(_HERE, "_ref", "libdigiham_ref_%s.so" % name)
+        _REF_LIBS[name] = C.CDLL(so) if os.path.exists(so) else None
+    return _REF_LIBS[name]
+
+
+class Elements:
+    """The element parsers as batch calls.  which = "oracle": oracle/elements.c (orc_el_*); which = "ref": the
+    reference's own Cach / Emb / SlotType / EmbeddedCollector / Lc / Gps / TalkerAliasCollector / Fich / DataCollector /
+    Codeword / Header classes through oracle/ref_{dmr,ysf,pocsag,dstar}.cpp (ref_el_*).  Same signatures on both sides;
+    the host-side-only elements (GPS, talker alias, YSF data frames) exist on the "ref" side only."""
+    _HOME = {"dmr_cach": "dmr", "dmr_emb": "dmr", "dmr_slottype": "dmr", "dmr_embedded_lc": "dmr", "dmr_lc": "dmr",
+             "dmr_gps": "dmr", "dmr_talkeralias": "dmr", "ysf_fich": "ysf", "ysf_gps": "ysf", "ysf_data": "ysf",
+             "pocsag_codeword": "pocsag", "dstar_header": "dstar"}
+
+    def __init__(self, which="oracle"):
+        self.which = which
+
+    def _fn(self, name):
+        if self.which == "oracle":
+            return getattr(lib(), "orc_el_" + name)
+        L = ref_lib(self._HOME[name])
+        if L is None:
+            raise RuntimeError("oracle/_ref/libdigiham_ref_%s.so not built" % self._HOME[name])
+        return getattr(L, "ref_el_" + name)
+
+    def dmr_cach(self, raw):
+        """raw [n][12] dibits -> [n][8] = has_tact, tact, busy, slot, lcss, payload[3]"""
+        raw = np.ascontiguousarray(raw, np.uint8).reshape(-1, 12)
+        out = np.zeros((len(raw), 8), np.uint8)
+        self._fn("dmr_cach")(_p(raw), C.c_size_t(len(raw)), _p(out))
+        return out
+
+    def dmr_emb(self, words):
+        w = np.ascontiguousarray(words, np.uint16).ravel()
+        out, cor = np.zeros((len(w), 4), np.uint8), np.zeros(len(w), np.uint16)
+        self._fn("dmr_emb")(_p(w), C.c_size_t(len(w)), _p(out), _p(cor))
+        return out, cor
+
+    def dmr_slottype(self, words):
+        w = np.ascontiguousarray(words, np.uint32).ravel()
+        out, cor = np.zeros((len(w), 4), np.uint8), np.zeros(len(w), np.uint32)
+        self._fn("dmr_slottype")(_p(w), C.c_size_t(len(w)), _p(out), _p(cor))
+        return out, cor
+
+    def dmr_embedded_lc(self, prev, frags, nfrags):
+        prev = np.ascontiguousarray(prev, np.uint8).reshape(-1, 16)
+        frags = np.ascontiguousarray(frags, np.uint8).reshape(-1, 20)
+        nfrags = np.ascontiguousarray(nfrags, np.uint8).ravel()
+        out = np.zeros((len(prev), 10), np.uint8)
+        self._fn("dmr_embedded_lc")(_p(prev), _p(frags), _p(nfrags), C.c_size_t(len(prev)), _p(out))
+        return out
+
+    def dmr_lc(self, lc):
+        lc = np.ascontiguousarray(lc, np.uint8).reshape(-1, 9)
+        fields, data7 = np.zeros((len(lc), 4), np.uint32), np.zeros((len(lc), 7), np.uint8)
+        self._fn("dmr_lc")(_p(lc), C.c_size_t(len(lc)), _p(fields), _p(data7))
+        return fields, data7
+
+    def dmr_gps(self, d):
+        d = np.ascontiguousarray(d, np.uint8).reshape(-1, 7)
+        out = np.zeros((len(d), 2), np.float32)
+        self._fn("dmr_gps")(_p(d), C.c_size_t(len(d)), _p(out))
+        return out
+
+    def dmr_talkeralias(self, blocks, order):
+        blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1, 28)
+        order = np.ascontiguousarray(order, np.uint8).reshape(-1, 4)
+        n = len(blocks)
+        complete, text, ln = np.zeros(n, np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.uint8)
+        self._fn("dmr_talkeralias")(_p(blocks), _p(order), C.c_size_t(n), _p(complete), _p(text), _p(ln))
+        return complete, text, ln
+
+    def ysf_fich(self, dibits):
+        d = np.ascontiguousarray(dibits, np.uint8).reshape(-1, 100)
+        out, data = np.zeros((len(d), 4), np.uint8), np.zeros(len(d), np.uint32)
+        self._fn("ysf_fich")(_p(d), C.c_size_t(len(d)), _p(out), _p(data))
+        return out, data
+
+    def ysf_gps(self, d):
+        d = np.ascontiguousarray(d, np.uint8).reshape(-1, 9)
+        ok, out = np.zeros(len(d), np.uint8), np.zeros((len(d), 2), np.float32)
+        self._fn("ysf_gps")(_p(d), C.c_size_t(len(d)), _p(ok), _p(out))
+        return ok, out
+
+    def ysf_data(self, chunks, offsets):
+        chunks = np.ascontiguousarray(chunks, np.uint8).reshape(-1, 80)
+        offsets = np.ascontiguousarray(offsets, np.uint8).reshape(-1, 8)
+        n = len(chunks)
+        has2, frame = np.zeros(n, np.uint8), np.zeros((n, 4), np.uint32)
+        radio, latlon = np.zeros((n, 32), np.uint8), np.zeros((n, 2), np.float32)
+        self._fn("ysf_data")(_p(chunks), _p(offsets), C.c_size_t(n), _p(has2), _p(frame), _p(radio), _p(latlon))
+        return has2, frame, radio, latlon
+
+    def pocsag_codeword(self, bits):
+        b = np.ascontiguousarray(bits, np.uint8).reshape(-1, 32)
+        out, words = np.zeros((len(b), 4), np.uint8), np.zeros((len(b), 3), np.uint32)
+        self._fn("pocsag_codeword")(_p(b), C.c_size_t(len(b)), _p(out), _p(words))
+        return out, words
+
+    def dstar_header(self, raw):
+        r = np.ascontiguousarray(raw, np.uint8).reshape(-1, 660)
+        n = len(r)
+        ok, data, text = np.zeros(n, np.uint8), np.zeros((n, 41), np.uint8), np.zeros((n, 160), np.uint8)
+        self._fn("dstar_header")(_p(r), C.c_size_t(n), _p(ok), _p(data), _p(text))
+        return ok, data, text
+
+
+def all_cach_dibits(start, count):
+    """CACH number i (24 bits, dibit 0 = the two most significant bits) for i in [start, start + count) -> [count][12]"""
+    i = np.arange(start, start + count, dtype=np.uint32)
+    return np.stack([((i >> (22 - 2 * k)) & 3).astype(np.uint8) for k in range(12)], axis=1)
