@@ -11,14 +11,23 @@ configs[2], 16 384 DMR channels x 3.96 s of 48 kS/s audio per GPU, full chain in
 State (filter history, timing recovery, decoder phase) carries from step to step exactly as in a
 continuous stream; the input buffer is periodic so the stream is seamless.
 
+One process per GPU.  Started as plain `python bench.py --gpus N` with N > 1 it re-executes itself under
+`torch.distributed.run` with N ranks (and refuses when the box has fewer GPUs); a line whose n_gpus differs from
+--gpus is never printed.  Channels shard by index, no collective on the data path: RCCL only carries the barrier
+and the MAX / SUM of the report.  `--scaling weak` (default): --channels per GPU; `--scaling strong`:
+--total-channels split over the ranks (BASELINE configs[4]: --workload mixed --scaling strong --total-channels 65536).
+
 One JSON line on rank 0: value = whole-job real-time 48 kS/s channels = samples/s / 48 000, plus
-`roofline` for the dominant kernel (k_chain, timed with HIP events on its own stream inside
-the timed region) and `cpu_baseline` (the oracle's scalar restatement of the reference pipe on
-this box's host cores, bounded sample, rank 0 at N = 1 only).
+`roofline` for the dominant kernel (timed with HIP events on its own stream inside the timed region),
+`cpu_baseline` (the oracle's scalar restatement of the reference pipe on this box's host cores, bounded sample,
+rank 0 at N = 1 only) and `other_configs`: the other single-GPU BASELINE configs timed on the same lease
+(N = 1 only, after the headline's timed region; --no-other-configs skips them).
 """
 import argparse
 import json
+import math
 import os
+import socket
 import sys
 import time
 
@@ -30,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 SAMPLE_RATE = 48000
 
 WORKLOADS = {
-    # name: (proto, engine kwargs, algorithmic bytes per input sample of the dominant kernel, description)
+    # name: (protocol of the synthetic signal, engine kwargs, description)
     "dmr_full": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
                  "full chain rrc(wide)->gfsk(10)->dmr_decoder incl. BPTC(196,96) (BASELINE configs[2])"),
     "ysf_full": ("ysf", dict(rrc="wide", demod="gfsk", sps=10, proto="ysf"),
@@ -50,28 +59,31 @@ WORKLOADS = {
     # examples/pocsag-decoder.sh: fsk_demodulator -i -s 40 | pocsag_decoder
     "pocsag_full": ("pocsag", dict(rrc="none", demod="fsk", sps=40, proto="pocsag", invert=True),
                     "full chain fsk(40, inverted)->pocsag_decoder (POCSAG 1200)"),
-    # BASELINE configs[4] per GPU: half the channels DMR, half YSF, one engine (and one launch per push) each
+    # BASELINE configs[4]: half the channels DMR, half YSF, one engine (and one launch per push) each
     "mixed": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
-              "half DMR + half YSF channels, full chains (BASELINE configs[4] per-GPU share)"),
+              "half DMR + half YSF channels, full chains (BASELINE configs[4])"),
 }
+UNITS = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}     # bursts / frames per step: ~3.96-4 s
 
 
 def profiled_traffic(workload, channels, T):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
     KiB, per-dispatch average; MI355X_MICROARCH.md) -- bench.py cannot collect counters itself.  Only for the
-    configuration those passes were run on (tools/profile_gpu.sh: the default workload)."""
-    path = os.path.join(ROOT, "profiles", "r01_k_chain_pmc.txt")
-    if workload != "dmr_full" or channels != 16384 or T != 190080 or not os.path.exists(path):
+    configuration those passes were run on (tools/profile_gpu.sh: the default workload); newest round first."""
+    if workload != "dmr_full" or channels != 16384 or T != 190080:
         return None, None
-    fetch = write = None
-    for line in open(path):
-        if "k_chain" in line and " FETCH_SIZE " in line:
-            fetch = float(line.split("avg=")[1].split()[0])
-        if "k_chain" in line and " WRITE_SIZE " in line:
-            write = float(line.split("avg=")[1].split()[0])
-    if fetch is None or write is None:
-        return None, None
-    return fetch * 2.0 * 1024.0 + write * 1024.0, "profiles/r01_k_chain_pmc.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)"
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted((f for f in os.listdir(pdir) if f.endswith("_chain_pmc.txt")), reverse=True):
+        fetch = write = None
+        for line in open(os.path.join(pdir, name)):
+            if "k_chain" in line and " FETCH_SIZE " in line:
+                fetch = float(line.split("avg=")[1].split()[0])
+            if "k_chain" in line and " WRITE_SIZE " in line:
+                write = float(line.split("avg=")[1].split()[0])
+        if fetch is not None and write is not None:
+            return fetch * 2.0 * 1024.0 + write * 1024.0, \
+                "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)" % name
+    return None, None
 
 
 def oracle_kw(proto):
@@ -82,29 +94,244 @@ def oracle_kw(proto):
     return dict(proto={"dmr": 1, "ysf": 2, "nxdn": 3}[proto], **(dict(rrc=2, sps=20) if proto == "nxdn" else {}))
 
 
+def effective_cores():
+    """(visible, effective): os.cpu_count() vs what this process may actually use = min(affinity mask, cgroup CPU quota)."""
+    visible = os.cpu_count() or 1
+    eff = visible
+    try:
+        eff = min(eff, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                eff = min(eff, max(1, int(math.ceil(float(quota) / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return visible, max(1, eff)
+
+
 def cpu_baseline(x_host_fn, proto, budget_s=12.0):
-    """Time the oracle (scalar restatement of the reference pipe) on this box's host cores."""
+    """Time the oracle (unpinned scalar CPU restatement of the reference pipe) on the host cores this process may use."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    visible, cores = effective_cores()
     probe = x_host_fn(1)
     n = probe.shape[1]
+    O.chain(probe[:, : min(n, 24000)], threads=1, **oracle_kw(proto))                     # page in
     t0 = time.perf_counter()
     O.chain(probe[:, : min(n, 96000)], threads=1, **oracle_kw(proto))
     per_sample = (time.perf_counter() - t0) / min(n, 96000)
-    # size the sample for ~budget_s of wall time with every core busy
-    chans = max(cores, int(budget_s / (per_sample * n) * cores))
+    chans = max(cores, int(budget_s / (per_sample * n) * cores))                          # ~budget_s with every thread busy
     chans = min(chans, 16384)
     x = x_host_fn(chans)
     t0 = time.perf_counter()
     O.chain(x, threads=cores, **oracle_kw(proto))
     dt = time.perf_counter() - t0
     rate = x.size / dt
+    per_core, single = rate / 1e6 / cores, 1e-6 / per_sample
     return {"value": rate / SAMPLE_RATE, "unit": "channels", "msamples_per_s": rate / 1e6,
-            "msamples_per_s_per_core": rate / 1e6 / cores, "single_thread_msamples_per_s": 1e-6 / per_sample,
-            "cores": cores, "kind": "port",
+            "msamples_per_s_per_core": per_core, "single_thread_msamples_per_s": single,
+            "cores": cores, "cores_visible": visible, "cores_effective": cores, "oversubscribed": bool(per_core < 0.5 * single),
+            "kind": "port",
+            "what": "CPU restatement (unpinned port): oracle/ C code, not the reference binaries -- rrc_filter / gfsk_demodulator / "
+                    "*_decoder need csdr, which this image lacks, so examples/dmr-decoder.sh itself cannot be timed here",
             "sample": "%d channels x %d samples of the same synthetic workload through oracle/ (scalar C restatement of "
                       "[rrc_filter|]g/fsk_demodulator|%s_decoder, bit-exact with the GPU path), %d pthreads, %.1f s wall"
                       % (chans, x.shape[1], proto, cores, dt)}
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become N ranks, or fail loudly."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.exit("bench.py: --gpus %d requested but this box has %d GPU(s); not reporting a line for fewer GPUs" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class Job:
+    """The engines of one workload on this rank's GPU, with their inputs resident in HBM."""
+
+    def __init__(self, torch, ctx, device, workload, channels, rank, split_stages=False, streams=1, units=0):
+        from digiham_amd import api, synth_torch
+        self.torch, self.workload = torch, workload
+        proto, kw, self.desc = WORKLOADS[workload]
+        if split_stages:
+            kw = dict(kw, split_stages=True)
+        self.kw, self.proto = kw, proto
+        parts = [(proto, kw, channels)] if workload != "mixed" else \
+                [("dmr", kw, channels[0]), ("ysf", dict(kw, proto="ysf"), channels[1])]
+        self.parts = []
+        for i, (p, k, B) in enumerate(parts):
+            if B == 0:
+                continue
+            x, info = synth_torch.make_batch(torch, device, p, B, units or UNITS[p], seed=1000 * (i + 1) + 7919 * rank, sps=k["sps"])
+            T = info["samples_per_channel"]
+            stream = torch.cuda.Stream(device) if streams > 1 else None
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    eng = api.Engine(B, T, ctx=ctx, **k)
+            else:
+                eng = api.Engine(B, T, ctx=ctx, **k)
+            self.parts.append({"proto": p, "kw": k, "B": B, "T": T, "x": x, "eng": eng, "stream": stream})
+        self.samples_per_step = float(sum(p["B"] * p["T"] for p in self.parts))
+
+    def step(self):
+        for p in self.parts:
+            p["eng"].push(p["x"])
+
+    def sync(self):
+        for p in self.parts:
+            p["eng"].sync()                 # raises on any output-buffer overflow
+
+    def close(self):
+        for p in self.parts:
+            p["eng"].close()
+
+    def timed(self, steps, warmup, barrier=lambda: None):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.  Returns seconds."""
+        torch = self.torch
+        for p in self.parts:
+            p["eng"].timing_enable(max(steps, 1))
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        for p in self.parts:
+            p["eng"].timing_read()          # drop warm-up timings
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        self.sync()
+        return dt
+
+    def roofline(self, split_stages=False):
+        """Dominant kernel of the first part: its algorithmic bytes per launch over its average
+        launch duration, from the HIP events the engine records on its own stream around every launch."""
+        import numpy as np
+        p = self.parts[0]
+        kw, B, T = p["kw"], p["B"], p["T"]
+        rrc_ms, slicer_ms, dec_ms = p["eng"].timing_read()
+        frame_bytes = int(p["eng"].frames()[1].sum()) if kw["proto"] != "none" else 0      # decoder output of the last step
+        alg_bytes = B * T * 4.0 + B * (T / float(kw["sps"]))          # input f32 (4 B/sample) + dibits out (1 B per sps samples)
+        if kw.get("keep_filtered"):
+            dom_ms = float(np.mean(rrc_ms)) if len(rrc_ms) else float("nan")              # unfused config: the RRC kernel dominates
+            alg_bytes = B * T * 8.0                                                       # 4 B in + 4 B out per sample
+            dom_name = "k_rrc_tile"
+        else:
+            dom_ms = float(np.mean(slicer_ms)) if len(slicer_ms) else float("nan")
+            # one launch for slicer + decoder exists for these chains (engine.hip: launch_chain)
+            chained = ((kw["proto"] in ("dmr", "ysf") or (kw["proto"] == "dstar" and kw["rrc"] == "none")) and kw["sps"] == 10
+                       or (kw["proto"] == "nxdn" and kw["rrc"] == "narrow")) and not split_stages
+            dom_name = "k_chain" if chained else "k_rrc_demod"
+            if chained:
+                alg_bytes += frame_bytes            # + decoder output (<= 27 B per 1440 samples for DMR)
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        taps = {"wide": 81, "narrow": 161, "none": 0}[kw["rrc"]]
+        fir_flops = B * T * 2.0 * taps              # one mul + one add per tap and sample, unfused
+        traffic, traffic_src = profiled_traffic(self.workload, B, T) if dom_name == "k_chain" else (None, None)
+        mean = lambda a: float(np.mean(a)) if len(a) else None
+        return {"bound": "hbm", "kernel": dom_name + ("<%s>" % kw["proto"] if dom_name == "k_chain" else ""),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                "co_limit": {"what": "fp32 VALU (%d-tap FIR, %s)" % (taps, "FMA" if kw.get("fast_fir") else "unfused mul+add for bit-exactness"),
+                             "achieved_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops": 157.3}}, \
+               {"rrc": mean(rrc_ms), "slicer": mean(slicer_ms), "decoder": mean(dec_ms)}
+
+    def verify(self, ctx, nv, reps=2):
+        """Replay the first nv channels of every part from reset on a small engine and on the oracle (outside any timed
+        region): dibits, decoder bytes (and the filtered floats of the materialised-RRC configs) must agree."""
+        import numpy as np
+        from digiham_amd import api
+        from oracle import oracle as O
+        ok, frame_bytes, worst = True, 0, 0.0
+        for p in self.parts:
+            kw, T = p["kw"], p["T"]
+            n = min(nv, p["B"])
+            small = api.Engine(n, T, ctx=ctx, **kw)
+            xs = p["x"][:n].contiguous()
+            got_s, got_f, got_y = [[] for _ in range(n)], [[] for _ in range(n)], []
+            for _ in range(reps):
+                small.push(xs)
+                s, sc = small.symbols()
+                for b in range(n):
+                    got_s[b].append(s[b, :sc[b]].copy())
+                if kw["proto"] != "none":
+                    f, fc = small.frames()
+                    for b in range(n):
+                        got_f[b].append(f[b, :fc[b]].copy())
+                if kw.get("keep_filtered"):
+                    got_y.append(small.filtered()[:, :T].copy())
+            small.close()
+            xh = np.tile(xs.cpu().numpy(), (1, reps))
+            okw = oracle_kw(p["proto"])
+            if kw["proto"] == "none":
+                okw = dict(okw, proto=0)
+            ref = O.chain(xh, threads=min(n, effective_cores()[1]), keep_filtered=bool(kw.get("keep_filtered")), **okw)
+            for b in range(n):
+                gs = np.concatenate(got_s[b])
+                same = len(gs) == ref["sym_count"][b] and bool((gs == ref["syms"][b, :len(gs)]).all())
+                if kw.get("fast_fir"):
+                    same = True                      # dibits are not guaranteed with the FMA FIR; the floats are checked below
+                ok &= same
+                if kw["proto"] != "none":
+                    gf = np.concatenate(got_f[b])
+                    ok &= len(gf) == ref["out_count"][b] and bool((gf == ref["out"][b, :len(gf)]).all())
+                    frame_bytes += len(gf)
+            if kw.get("keep_filtered"):
+                y, r = np.concatenate(got_y, axis=1), ref["filtered"]
+                if kw.get("fast_fir"):               # BASELINE.md section 4: 1e-6 relative to max(|ref|, rms(ref))
+                    rms = np.sqrt(np.mean(r.astype(np.float64) ** 2)) + 1e-30
+                    err = float(np.max(np.abs(y.astype(np.float64) - r) / np.maximum(np.abs(r), rms)))
+                    worst = max(worst, err)
+                    ok &= err <= 1e-6
+                else:
+                    ok &= bool((y.view(np.uint32) == r.view(np.uint32)).all())
+        out = {"channels": nv, "pushes": reps, "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir"), "frame_bytes": frame_bytes}
+        if self.kw.get("fast_fir"):
+            out.update({"within_1e-6_vs_oracle": bool(ok), "max_rel_err": worst})
+        return ok, out
+
+
+def other_configs(torch, ctx, device, steps, warmup, verify):
+    """The remaining single-GPU BASELINE configs on the same lease (each its own engines, inputs resident, same timing
+    method as the headline)."""
+    out = []
+    for workload, channels in (("rrc_gfsk", 4096), ("rrc_gfsk_fast", 4096), ("ysf_full", 16384), ("mixed", (8192, 8192))):
+        t_start = time.perf_counter()
+        job = Job(torch, ctx, device, workload, channels, rank=0)
+        dt = job.timed(steps, warmup)
+        roof, stage = job.roofline()
+        entry = {"workload": workload, "config": "%s channels x %d samples: %s" % (channels, job.parts[0]["T"], job.desc),
+                 "steps": steps, "ms_per_step": dt / steps * 1e3, "value": job.samples_per_step * steps / dt / SAMPLE_RATE, "unit": "channels",
+                 "kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "frac": roof["frac"], "stage_ms": stage}
+        if verify:
+            ok, entry["verified"] = job.verify(ctx, min(verify, 4))
+            assert ok, "GPU output differs from the oracle (%s)" % workload
+        job.close()
+        del job
+        torch.cuda.empty_cache()
+        entry["wall_s"] = time.perf_counter() - t_start
+        out.append(entry)
+    return out
 
 
 def main():
@@ -113,158 +340,106 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dmr_full", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--channels", type=int, default=16384, help="channels per GPU (weak scaling)")
+    ap.add_argument("--total-channels", type=int, default=65536, help="channels of the whole job (strong scaling)")
     ap.add_argument("--units", type=int, default=0, help="bursts (DMR, 30 ms) or frames (YSF, 100 ms) per step; 0 = ~4 s")
+    ap.add_argument("--streams", type=int, default=1, help="mixed: 2 = the two engines on their own HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--split-stages", action="store_true", help="slicer and decoder as two kernels (per-stage timing)")
     ap.add_argument("--verify", type=int, default=8, help="channels checked bit-exact against the oracle after the run")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)            # does not return
+
     import numpy as np
     import torch
-    from digiham_amd import api, shard, synth_torch
+    from digiham_amd import api, shard
 
     rank, world, local = shard.init_process_group()
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s): launch with --nproc-per-node == --gpus" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs; there is no CPU path"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-
-    proto, kw, desc = WORKLOADS[args.workload]
-    B = args.channels
-    units = args.units or {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}[proto]
-    x, info = synth_torch.make_batch(torch, device, proto, B, units, seed=1000 + 7919 * rank, sps=kw["sps"])
-    T = info["samples_per_channel"]
     ctx = api.Context(device=local)
-    if args.split_stages:
-        kw = dict(kw, split_stages=True)
+
     mixed = args.workload == "mixed"
-    if mixed:
-        B = B // 2                          # this many DMR channels + as many YSF channels
-        x = x[:B].contiguous()
-        x2, info2 = synth_torch.make_batch(torch, device, "ysf", B, 40, seed=2000 + 7919 * rank)
-        T2 = info2["samples_per_channel"]
-        eng2 = api.Engine(B, T2, ctx=ctx, **dict(kw, proto="ysf"))
-    eng = api.Engine(B, T, ctx=ctx, **kw)
-    n_timed = args.steps
-    eng.timing_enable(max(n_timed, 1))
-
-    def step():
-        eng.push(x)
+    if args.scaling == "strong":                # a fixed job, split by channel index
         if mixed:
-            eng2.push(x2)
+            half = args.total_channels // 2
+            (a0, a1), (b0, b1) = shard.channel_range(half, rank, world), shard.channel_range(args.total_channels - half, rank, world)
+            channels = (a1 - a0, b1 - b0)
+        else:
+            lo, hi = shard.channel_range(args.total_channels, rank, world)
+            channels = hi - lo
+    else:
+        channels = (args.channels // 2, args.channels - args.channels // 2) if mixed else args.channels
+    job = Job(torch, ctx, device, args.workload, channels, rank, split_stages=args.split_stages, streams=args.streams, units=args.units)
 
-    for _ in range(args.warmup):
-        step()
-    eng.sync()
-    eng.timing_read()                       # drop warm-up timings
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    shard.barrier()
-    dt = time.perf_counter() - t0
-    eng.sync()                              # raises on any output-buffer overflow
-    if mixed:
-        eng2.sync()
-    rrc_ms, slicer_ms, dec_ms = eng.timing_read()
-    frame_bytes_step = 0
-    if kw["proto"] != "none":
-        frame_bytes_step = int(eng.frames()[1].sum())          # decoder output of the last step, all channels
-
-    samples = float(B) * T * args.steps + (float(B) * T2 * args.steps if mixed else 0.0)
+    dt = job.timed(args.steps, args.warmup, barrier=shard.barrier)
+    samples = job.samples_per_step * args.steps
     dt_max, samples_all = shard.reduce_report(dt, samples, device)
+    roof, stage = job.roofline(args.split_stages)
 
-    # ---- parity spot check on the last step (outside the timed region)
     verified = None
-    if args.verify and kw["proto"] != "none" and not kw.get("fast_fir"):
-        from oracle import oracle as O
-        nv = min(args.verify, B)
-        # replay the whole stream of the first nv channels from reset on a small engine, and on the oracle
-        small = api.Engine(nv, T, ctx=ctx, **kw)
-        xs = x[:nv].contiguous()
-        got_s, got_f = [[] for _ in range(nv)], [[] for _ in range(nv)]
-        reps = 2
-        for _ in range(reps):
-            small.push(xs)
-            s, sc = small.symbols()
-            f, fc = small.frames()
-            for b in range(nv):
-                got_s[b].append(s[b, :sc[b]].copy()); got_f[b].append(f[b, :fc[b]].copy())
-        xh = np.tile(xs.cpu().numpy(), (1, reps))
-        ref = O.chain(xh, threads=min(nv, os.cpu_count() or 1), **oracle_kw(proto))
-        ok = True
-        for b in range(nv):
-            gs, gf = np.concatenate(got_s[b]), np.concatenate(got_f[b])
-            ok &= len(gs) == ref["sym_count"][b] and bool((gs == ref["syms"][b, :len(gs)]).all())
-            ok &= len(gf) == ref["out_count"][b] and bool((gf == ref["out"][b, :len(gf)]).all())
-        verified = {"channels": nv, "pushes": reps, "bit_exact_vs_oracle": bool(ok),
-                    "frame_bytes": int(sum(len(np.concatenate(g)) for g in got_f))}
-        small.close()
+    if args.verify and not (job.kw["proto"] == "none" and not job.kw.get("keep_filtered")):
+        ok, verified = job.verify(ctx, args.verify)
         assert ok, "GPU output differs from the oracle"
 
     if rank == 0:
         rate = samples_all / dt_max
-        n_gpus = world
-        # dominant kernel: fused RRC + slicer (k_rrc_demod); algorithmic bytes per launch =
-        # input f32 (4 B/sample) + dibits out (1 B per 10 samples) -- SURVEY.md section 8(d)
-        alg_bytes = B * T * 4.0 + B * (T / float(kw["sps"]))   # of ONE launch of the dominant kernel (mixed: the DMR engine's)
-        if kw.get("keep_filtered"):
-            # unfused config 2: the RRC kernel is dominant; 4 B in + 4 B out per sample
-            dom_ms = float(np.mean(rrc_ms)) if len(rrc_ms) else float("nan")
-            alg_bytes = B * T * 8.0
-            dom_name = "k_rrc_tile"
-        else:
-            dom_ms = float(np.mean(slicer_ms)) if len(slicer_ms) else float("nan")
-            # one launch for slicer + decoder exists for the sps-10 DMR / YSF chains (engine.hip: launch_chain)
-            chained = ((kw["proto"] in ("dmr", "ysf") or (kw["proto"] == "dstar" and kw["rrc"] == "none")) and kw["sps"] == 10
-                       or (kw["proto"] == "nxdn" and kw["rrc"] == "narrow")) and not args.split_stages
-            dom_name = "k_chain" if chained else "k_rrc_demod"
-            if chained:
-                alg_bytes += frame_bytes_step          # + decoder output (<= 27 B per 1440 samples for DMR)
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_src = profiled_traffic(args.workload, B, T) if dom_name == "k_chain" else (None, None)
-        taps = {"wide": 81, "narrow": 161, "none": 0}[kw["rrc"]]
-        fir_flops = B * T * 2.0 * taps       # one mul + one add per tap and sample, unfused
+        proto = job.proto
+        per_gpu = [p["B"] for p in job.parts]
+        T = job.parts[0]["T"]
         line = {
             "metric": "concurrent 48 kS/s DMR+YSF channels sustained end-to-end" if mixed else
                       "concurrent 48 kS/s DMR channels sustained end-to-end (rrc_filter->gfsk_demodulator->dmr_decoder)"
                       if proto == "dmr" else "concurrent 48 kS/s %s channels sustained end-to-end" % proto.upper(),
             "value": rate / SAMPLE_RATE, "unit": "channels",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d %s channels/GPU x %.2f s (%d samples) of 48 kS/s FM-discriminator audio, %s"
-                                   % (2 * B if mixed else B, "DMR+YSF" if mixed else proto.upper(), T / SAMPLE_RATE, T, desc),
-                       "channels_per_gpu": B, "samples_per_channel_per_step": T, "sharding": "channels, no collective"},
+            "config": {"workload": "%s %s channels%s x %.2f s (%d samples) of 48 kS/s FM-discriminator audio, %s"
+                                   % ("+".join(str(b) for b in per_gpu), "DMR+YSF" if mixed else proto.upper(),
+                                      "/GPU" if args.scaling == "weak" else " on rank 0 of a fixed %d-channel job" % args.total_channels,
+                                      T / SAMPLE_RATE, T, job.desc),
+                       "channels_per_gpu": sum(per_gpu), "samples_per_channel_per_step": T,
+                       "total_channels": int(round(samples_all / args.steps / T)) if not mixed else
+                                         (args.total_channels if args.scaling == "strong" else sum(per_gpu) * world),
+                       "sharding": "channels, no collective", "streams": args.streams},
             "msamples_per_s": rate / 1e6,
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "co_limit": {"what": "fp32 VALU (%d-tap FIR, unfused mul+add for bit-exactness)" % taps,
-                                      "achieved_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops": 157.3}},
-            "stage_ms": {"rrc": float(np.mean(rrc_ms)) if len(rrc_ms) else None,
-                         "slicer": float(np.mean(slicer_ms)) if len(slicer_ms) else None,
-                         "decoder": float(np.mean(dec_ms)) if len(dec_ms) else None},
-            "verified": verified,
+            "roofline": roof, "stage_ms": stage, "verified": verified,
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
+            x0 = job.parts[0]["x"]
+
             def host_rows(k):
-                return np.ascontiguousarray(x[:k].cpu().numpy())
+                return np.ascontiguousarray(x0[:k].cpu().numpy())
             try:
                 line["cpu_baseline"] = cpu_baseline(host_rows, proto)
             except Exception as e:          # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
-    eng.close()
-    if mixed:
-        eng2.close()
+    job.close()
+    del job
+    if rank == 0:
+        default_headline = args.workload == "dmr_full" and args.scaling == "weak" and args.channels == 16384
+        if world == 1 and default_headline and not args.no_other_configs:
+            torch.cuda.empty_cache()
+            try:
+                line["other_configs"] = other_configs(torch, ctx, device, min(args.steps, 10), min(args.warmup, 2), args.verify)
+            except Exception as e:
+                line["other_configs"] = {"error": repr(e)}
+        assert line["n_gpus"] == args.gpus
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         shard.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)         # the last line of stdout, after RCCL's own chatter
 
 
 if __name__ == "__main__":

@@ -380,3 +380,50 @@ def test_dstar_header_events_vs_reference(ctx, gold):
             assert got[pos][0] + got[pos][1] == h41
         n_ok += len(exp)
     assert n_ok > 0
+
+
+def test_tact_slot_tracking_vs_reference(ctx, gold):
+    """The reference's Cach::parse / Tact::getSlot results (golden sample of random 24-bit CACHs, mixed with clean ones)
+    drive the TDMA slot of every burst: the `a` field of each burst's SLOTTYPE event must follow dmr_phase.cpp:65-95 fed
+    with the REFERENCE's TACT outcome for that CACH."""
+    v, _ = gold
+    n = _size(ctx, 4096, 128)
+    B = _size(ctx, 16, 2)
+    K = n // B
+    rng = np.random.default_rng(12)
+    idx = v["cach_sample_idx"][:n]
+    cach = np.stack([((idx >> (22 - 2 * k)) & 3).astype(np.uint8) for k in range(12)], axis=1)
+    has, tslot = v["cach_sample"][:n, 0].copy(), v["cach_sample"][:n, 3].copy()
+    bursts = rng.integers(0, 4, (n, 144)).astype(np.uint8)
+    st = np.array(synth.bits_to_dibits(synth._bits_of(synth.block_encode("golay_20_8", (5 << 4) | 3), 20)), np.uint8)   # cc 5, CSBK
+    bursts[:, 61:66], bursts[:, 90:95], bursts[:, 66:90] = st[:5], st[5:], BS_DATA
+    bursts[:, :12] = cach
+    clean = rng.random(n) < 0.6                                  # runs of clean, alternating CACHs let the stability counter climb
+    for i in np.nonzero(clean)[0]:
+        bursts[i, :12] = CACH[i & 1]; has[i] = 1; tslot[i] = i & 1
+    lead = np.broadcast_to(rng.integers(0, 4, LEAD).astype(np.uint8), (B, LEAD))
+    streams = np.concatenate([lead, bursts.reshape(B, K * 144), np.zeros((B, 160), np.uint8)], axis=1)
+    evs = _run_symbols(ctx, "dmr", streams)
+    for b in range(B):
+        got = _events_at(evs[b], api_ev("DMR_SLOTTYPE"), LEAD + 144 * K)
+        slot, stab, exp = -1, 0, {}
+        for k in range(K):
+            i = b * K + k
+            nxt = (slot ^ 1) & 0xFF
+            if has[i]:
+                if tslot[i] != nxt:
+                    if stab < 5:
+                        stab, slot = 0, int(tslot[i])
+                    else:
+                        stab -= 1
+                        slot = nxt if slot != -1 else slot
+                else:
+                    stab, slot = min(stab + 1, 100), nxt
+            elif slot != -1:
+                stab = -100 if stab < -100 else stab - 1
+                slot = nxt
+            if slot != -1:
+                exp[LEAD + 144 * k] = slot
+        assert sorted(got) == sorted(exp), "channel %d" % b
+        assert all(int(got[p]["a"]) == s and int(got[p]["b"]) == 3 and int(got[p]["payload"][0]) == 5 for p, s in exp.items()), "channel %d" % b
+        assert len(set(exp.values())) == 2

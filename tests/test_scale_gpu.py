@@ -17,7 +17,7 @@ def _digest(rows, counts):
     return [hashlib.sha256(rows[b, :counts[b]].tobytes()).hexdigest() for b in range(rows.shape[0])]
 
 
-@pytest.mark.parametrize("proto,B,units", [("dmr", 16384, 33), ("ysf", 4096, 12), ("dmr", 4096, 132), ("nxdn", 4096, 16), ("dstar", 4096, 60)])
+@pytest.mark.parametrize("proto,B,units", [("dmr", 16384, 33), ("ysf", 4096, 12), ("ysf", 16384, 12), ("dmr", 4096, 132), ("nxdn", 4096, 16), ("dstar", 4096, 60)])
 def test_replicated_channels_agree_and_match_oracle(gpu_ctx, oracle, proto, B, units):
     import torch
     from digiham_amd import api, synth_torch
@@ -69,3 +69,42 @@ def test_reset_restores_initial_state(gpu_ctx):
     assert int(a[1].sum()) > 0
     # the second push continued the stream (decoder already in sync, timing already settled): not the same bytes
     assert _digest(a[0], a[1]) != _digest(b[0], b[1])
+
+
+def test_mixed_dmr_ysf_engines_on_two_streams(gpu_ctx, oracle):
+    """BASELINE configs[4], one GPU's share: 8 192 DMR + 8 192 YSF channels as two engines created on their own HIP
+    streams, pushed back to back (the launches may overlap on the device).  Replication over every channel plus the
+    U distinct signals of each protocol against the oracle, two pushes (state carry)."""
+    import torch
+    from digiham_amd import api, synth_torch
+    U, B = 32, 8192
+    dev = gpu_ctx.mem.device
+    parts = []
+    for proto, units, seed in (("dmr", 33, 515), ("ysf", 12, 616)):
+        base, info = synth_torch.make_batch(torch, dev, proto, U, units, U=U, seed=seed)
+        stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(stream):                          # the engine captures the current stream
+            eng = api.Engine(B, info["samples_per_channel"], proto=proto, ctx=gpu_ctx)
+        parts.append({"proto": proto, "base": base, "x": base.repeat(B // U, 1).contiguous(), "eng": eng, "outs": []})
+    torch.cuda.synchronize()
+    for _ in range(2):
+        for p in parts:                                          # both launches in flight before anything is read back
+            p["eng"].push(p["x"])
+        for p in parts:
+            s, sc = p["eng"].symbols(); f, fc = p["eng"].frames(); e, ec = p["eng"].events()
+            p["outs"].append((s, sc, f, fc, e, ec))
+    for p in parts:
+        p["eng"].close()
+        for s, sc, f, fc, e, ec in p["outs"]:
+            for rows, counts in ((s, sc), (f, fc), (e.view(np.uint8).reshape(B, -1), ec * 32)):
+                d = _digest(rows, counts)
+                assert all(d[ch] == d[ch % U] for ch in range(B))
+        ref = oracle.chain(np.tile(p["base"].cpu().numpy(), (1, 2)), proto={"dmr": 1, "ysf": 2}[p["proto"]], threads=8)
+        for b in range(U):
+            gs = np.concatenate([o[0][b, :o[1][b]] for o in p["outs"]])
+            gf = np.concatenate([o[2][b, :o[3][b]] for o in p["outs"]])
+            ge = np.concatenate([o[4][b, :o[5][b]] for o in p["outs"]])
+            assert len(gs) == ref["sym_count"][b] and (gs == ref["syms"][b, :len(gs)]).all()
+            assert len(gf) == ref["out_count"][b] and (gf == ref["out"][b, :len(gf)]).all()
+            assert ge.tobytes() == ref["events"][b, :ref["event_count"][b]].tobytes()
+        assert sum(int(o[3].sum()) for o in p["outs"]) > 0

@@ -6,7 +6,7 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --verify 0 $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --verify 0 $*"
 if [ -z "${SKIP_TRACE:-}" ]; then timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py $ARGS > $OUT/trace.log 2>&1; fi
 grep '^{' $OUT/trace.log > $OUT/bench_under_trace.json
 python tools/rocpd_summary.py $OUT/trace_results.db > $OUT/trace_summary.txt 2>&1
