@@ -126,6 +126,15 @@ class Context:
                "dh_debug_div_gain", self.lib)
         return self.mem.to_numpy(out)
 
+    def debug_div_const(self, x, divisor):
+        """x (numpy float32, or a device array) / float(divisor) as the slicer kernels compute it; returns what it was given."""
+        dev = self.mem.is_device_array(x)
+        d = x if dev else self.mem.from_numpy(np.ascontiguousarray(x, np.float32).ravel())
+        out = self.mem.zeros((d.shape[0],), np.float32)
+        _check(self.lib.dh_debug_div_const(self.mem.ptr(d), self.mem.ptr(out), d.shape[0], int(divisor), self.mem.stream()),
+               "dh_debug_div_const", self.lib)
+        return out if dev else self.mem.to_numpy(out)
+
     def dvfilter(self, x, state=None):
         """x: int16 [B][n] numpy; returns (y, state) with state a device array [B][22] to carry on."""
         a = np.ascontiguousarray(x, np.int16)

@@ -70,6 +70,11 @@ int dh_debug_div_gain(const float* in, float* out, size_t n, int narrow, void* s
     return dh_be_div_gain(in, out, n, narrow, s);
 }
 
+int dh_debug_div_const(const float* in, float* out, size_t n, unsigned divisor, void* s) {
+    if (((!in || !out) && n) || divisor == 0) return DH_EINVAL;
+    return dh_be_div_const(in, out, n, divisor, s);
+}
+
 int dh_engine_create(const dh_engine_config* cfg, dh_engine** out) {
     if (!cfg || !out) return DH_EINVAL;
     *out = nullptr;

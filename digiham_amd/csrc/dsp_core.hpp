@@ -142,31 +142,51 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps) {          // base: 16-
 // operands in tests/test_numerics.py).
 DH_HD float dh_div_gain_exact(float acc, double gain) { return (float) ((double) acc / gain); }
 
-// fast part: returns (float) q' and sets `suspect` when the exact division has to decide
-DH_HD float dh_div_gain_fast(float acc, double rgain, bool& suspect) {
+// fast part: returns (float) q' and sets `suspect` when the exact division has to decide.
+// Both tests are "an unsigned word is small":
+//   tie    t = (low word of q' << 3) + 0x80000020 <= 64: the low 29 mantissa bits of q' are within 4 ulp(double) of a
+//          float midpoint (0x0FFFFFFC .. 0x10000004; the shift drops the three bits above them);
+//   range  r = (bits(acc) << 1) - 1 < 2 * bits(2^-118) - 1: acc is non-zero and |acc| < 2^-118.  Results that may be
+//          float subnormals round at other bit positions: with 1 < gain < 128 they need |acc| < 2^-118; the quotient of
+//          a finite acc cannot overflow.  0, inf and nan are fine: acc * rgain is then acc / gain bit for bit.
+// One v_lshl_add_u32 each; a lane's sixteen outputs share ONE decision, so the words are min-reduced (v_min3_u32,
+// half an instruction per word) and compared once (dh_fir_finish).
+#define DH_DIV_TIE_MAX 64u
+#define DH_DIV_RANGE_MAX (2u * 0x04800000u - 1u)             /* bits(2^-118) = (127 - 118) << 23 */
+DH_HD float dh_div_gain_words(float acc, double rgain, uint32_t& tie, uint32_t& range) {
     const double q = (double) acc * rgain;
     union { double d; uint64_t u; } b; b.d = q;
-    // within 4 ulp(double) of a float midpoint: low 29 mantissa bits in [0x0FFFFFFC, 0x10000004]; the shift drops
-    // the three bits above them, so this is one v_lshl_add_u32 and one compare
-    const bool near_tie = (((uint32_t) b.u << 3) + 0x80000020u) <= 64u;
-    // Results that may be float subnormals (or overflow) round at other bit positions: with 1 < gain < 128 they
-    // need |acc| < 2^-118; the quotient of a finite acc cannot overflow.  0, inf and nan are fine: acc * rgain is
-    // then acc / gain bit for bit.
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-    const bool odd_range = __builtin_fabsf(acc) < 0x1p-118f && acc != 0.0f;      // two compares, masks ANDed on the SALU
-#else
     union { float f; uint32_t u; } a; a.f = acc;
-    const uint32_t be = (a.u >> 23) & 0xFFu;
-    const bool odd_range = be == 0u ? (a.u << 1) != 0u : be < 127u - 118u;
-#endif
-    suspect = near_tie || odd_range;
+    tie = ((uint32_t) b.u << 3) + 0x80000020u;
+    range = (a.u << 1) + 0xFFFFFFFFu;
     return (float) q;
+}
+DH_HD float dh_div_gain_fast(float acc, double rgain, bool& suspect) {
+    uint32_t tie, range;
+    const float y = dh_div_gain_words(acc, rgain, tie, range);
+    suspect = tie <= DH_DIV_TIE_MAX || range < DH_DIV_RANGE_MAX;
+    return y;
 }
 
 DH_HD float dh_div_gain(float acc, double gain, double rgain) {
     bool suspect;
     const float y = dh_div_gain_fast(acc, rgain, suspect);
     return suspect ? dh_div_gain_exact(acc, gain) : y;
+}
+
+// x / d for a float constant d (the samples per symbol: `volume_sum / samplesPerSymbol`, gfsk_demodulator.cpp:83), r =
+// RN(1 / d): q0 = RN(x r) is within 1 ulp of x / d, the FMA delivers the residual x - d q0 exactly, and
+// RN(q0 + residual * r) is then the correctly rounded quotient (Markstein's theorem; it needs r correctly rounded and
+// no underflow / overflow on the way).  Three instructions instead of the eleven of an IEEE division; 0, tiny, huge
+// and non-finite x (anything outside 2^-100 <= |x| <= 2^100) take the real division.  tests/test_numerics.py runs all
+// 2^32 floats through it for d = 10 (and the other sps values on a sample).
+DH_HD float dh_div_const(float x, float d, float r) {
+    union { float f; uint32_t u; } a; a.f = x;
+    const uint32_t t = (a.u << 1) - 2u * 0x0D800000u;                   // bits(2^-100) = (127 - 100) << 23
+    if (t > 2u * (0x71800000u - 0x0D800000u)) return x / d;             // bits(2^100) = (127 + 100) << 23
+    const float q0 = x * r;
+    const float rem = __builtin_fmaf(-q0, d, x);
+    return __builtin_fmaf(rem, r, q0);
 }
 
 // loop-invariant wave-uniform values that should live in VGPRs rather than compete for the 102 SGPRs
@@ -223,6 +243,16 @@ template <bool FAST> inline dh_f2 dh_f2_mac(float c, dh_f2 w, dh_f2 acc) {
     return dh_f2_make(acc.x + px, acc.y + py);
 }
 #endif
+// element-wise pair arithmetic for both builds (device: v_pk_add_f32 / v_pk_fma_f32)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ dh_f2 dh_f2_add(dh_f2 a, dh_f2 b) { return a + b; }
+__device__ __forceinline__ dh_f2 dh_f2_sub(dh_f2 a, dh_f2 b) { return a - b; }
+__device__ __forceinline__ dh_f2 dh_f2_fma(dh_f2 a, dh_f2 b, dh_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+inline dh_f2 dh_f2_add(dh_f2 a, dh_f2 b) { return dh_f2_make(a.x + b.x, a.y + b.y); }
+inline dh_f2 dh_f2_sub(dh_f2 a, dh_f2 b) { return dh_f2_make(a.x - b.x, a.y - b.y); }
+inline dh_f2 dh_f2_fma(dh_f2 a, dh_f2 b, dh_f2 c) { return dh_f2_make(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)); }
+#endif
 #define DH_FIR_H (DH_FIR_L / 2)
 #define DH_XLOFF(e) ((e) + ((e) >> 4))                 // dword offset of window element e from the lane's base
 
@@ -233,13 +263,14 @@ DH_HD void dh_fir_finish(const float* acc, double gain, double rgain, float inv_
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) out16[j] = acc[j] * inv_gain;
     } else {
-        bool any = false;                                 // OR of sixteen compare masks: scalar work, no per-lane bit set
+        uint32_t tmin = 0xFFFFFFFFu, rmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) {
-            bool s;
-            out16[j] = dh_div_gain_fast(acc[j], rgain, s);
-            any = any || s;
+            uint32_t t, r;
+            out16[j] = dh_div_gain_words(acc[j], rgain, t, r);
+            tmin = dh_min<uint32_t>(tmin, t); rmin = dh_min<uint32_t>(rmin, r);
         }
+        const bool any = tmin <= DH_DIV_TIE_MAX || rmin < DH_DIV_RANGE_MAX;
         if (any) {                                        // ~2e-8 per sample: one copy of the IEEE division, not sixteen
 #pragma unroll 1
             for (int j = 0; j < DH_FIR_L; j++) {
@@ -281,7 +312,11 @@ __device__ __forceinline__ void dh_fir_arrived(dh_f2 (&d)[DH_FIR_G]) {
 // SG: the taps are read as 64-bit scalar pairs from the kernel arguments (dh_f2_mac_pair) instead of from a register
 // array.  A packed multiply with a scalar operand issues a little slower (slicer kernels: +5 %), so this only pays
 // where the 41 / 81 tap registers cost a wavefront per SIMD -- the stand-alone RRC kernel (168 -> 105 VGPRs).
-template <int NZ, bool FAST, int B, bool SG = false> struct DhFirBatch {
+// ZINIT = false: the accumulators start as the first product instead of 0 + product -- the same float except that a
+// product of -0 stays -0 where the reference's `sum = 0; sum += c * x` gives +0.  The sign of a zero cannot reach a
+// dibit (the slicer only adds, subtracts and compares filtered samples), so the slicer kernels drop the eight packed
+// adds and the zeroing; the materialised RRC output (k_rrc_tile) keeps the reference's bits.
+template <int NZ, bool FAST, int B, bool SG = false, bool ZINIT = true> struct DhFirBatch {
     // tap I = B * DH_FIR_G + G: accumulate it on the eight window pairs, then slide the window by one sample
     template <int G> static __device__ __forceinline__ void tap(const float* taps, dh_f2 (&accp)[DH_FIR_H], dh_f2 (&w)[DH_FIR_H], dh_f2 (&cur)[DH_FIR_G]) {
         constexpr int I = B * DH_FIR_G + G;
@@ -291,6 +326,10 @@ template <int NZ, bool FAST, int B, bool SG = false> struct DhFirBatch {
                 const dh_f2 cc = reinterpret_cast<const dh_f2*>(taps)[TI >> 1];     // wave-uniform 64-bit load
 #pragma unroll
                 for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_mac_pair<FAST, TI & 1>(cc, w[j], accp[j]);
+            } else if constexpr (I == 0 && !ZINIT) {
+                const float c = taps[TI];
+#pragma unroll
+                for (int j = 0; j < DH_FIR_H; j++) accp[j] = c * w[j];              // v_pk_mul_f32
             } else {
                 const float c = taps[TI];
 #pragma unroll
@@ -310,13 +349,14 @@ template <int NZ, bool FAST, int B, bool SG = false> struct DhFirBatch {
             tap<0>(taps, accp, w, cur); tap<1>(taps, accp, w, cur); tap<2>(taps, accp, w, cur); tap<3>(taps, accp, w, cur);
             static_assert(DH_FIR_G == 4, "four taps per batch");
             if constexpr ((B + 1) * DH_FIR_G < NZ) dh_fir_arrived(nxt);
-            DhFirBatch<NZ, FAST, B + 1, SG>::run(taps, addr, accp, w, nxt);
+            DhFirBatch<NZ, FAST, B + 1, SG, ZINIT>::run(taps, addr, accp, w, nxt);
         }
     }
 };
 
 template <int NZ, bool FAST, bool SG = false>
 __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
+    constexpr bool ZINIT = SG;                             // the stand-alone RRC kernel (scalar taps) materialises its output
     // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
     const uint32_t addr = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (xs_all + (DH_FIR_L + 1) * lane);
     dh_f2 accp[DH_FIR_H], w[DH_FIR_H], cur[DH_FIR_G];
@@ -327,9 +367,11 @@ __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, doub
     dh_fir_issue<NZ, 0>(addr, cur);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) :: "memory");
     dh_fir_arrived(cur);
+    if constexpr (ZINIT) {
 #pragma unroll
-    for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_make(0.0f, 0.0f);
-    DhFirBatch<NZ, FAST, 0, SG>::run(taps, addr, accp, w, cur);
+        for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_make(0.0f, 0.0f);
+    }
+    DhFirBatch<NZ, FAST, 0, SG, ZINIT>::run(taps, addr, accp, w, cur);
     float acc[DH_FIR_L];
 #pragma unroll
     for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
@@ -365,6 +407,24 @@ struct alignas(16) dh_f4a { float x, y, z, w; };     // 16-byte aligned: one ds_
 DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
 DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
 DH_HD void dh_store4_unaligned(float* q, const dh_f4& v) { __builtin_memcpy(q, &v, sizeof(v)); }   // global_store_dwordx4
+
+// Four consecutive floats to LDS at `base` + a compile-time offset (the padded window is only dword aligned, so the
+// widest store the hardware takes is a dword pair; the compiler adds the offset to the base with one VALU instruction
+// per pair because a ds_write2_b32 offset only reaches 255 dwords -- four ds_write_b32 with 16-bit byte offsets cost
+// LDS issue slots, which this kernel has to spare, and no VALU at all).  The stores are invisible to the compiler's
+// wait-count tracking: dh_lds_stores_done() must come before the barrier that publishes them.
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+template <int OFF_WORDS> __device__ __forceinline__ void dh_lds_store4_at(float* base, const dh_f4& v) {
+    static_assert(4 * OFF_WORDS + 12 < 65536, "ds_write_b32 offsets are 16-bit byte counts");
+    const uint32_t addr = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) base;
+    asm volatile("ds_write_b32 %0, %1 offset:%5\n\tds_write_b32 %0, %2 offset:%6\n\tds_write_b32 %0, %3 offset:%7\n\tds_write_b32 %0, %4 offset:%8"
+                 :: "v"(addr), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"(4 * OFF_WORDS), "n"(4 * OFF_WORDS + 4), "n"(4 * OFF_WORDS + 8), "n"(4 * OFF_WORDS + 12) : "memory");
+}
+__device__ __forceinline__ void dh_lds_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+template <int OFF_WORDS> inline void dh_lds_store4_at(float* base, const dh_f4& v) { dh_store4(base + OFF_WORDS, v); }
+inline void dh_lds_stores_done() {}
+#endif
 
 // virtual input stream of a channel for this push: carried tail followed by the new samples
 DH_HD float dh_virtual_sample(const float* tail, uint32_t tc, const float* in, uint32_t idx) {
@@ -484,6 +544,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     uint32_t* sth = (uint32_t*) st;
     const uint32_t sps = SPS ? (uint32_t) SPS : P.sps;
     const uint32_t ev_lo = SPS == 10 ? 3u : P.lo, ev_hi = SPS == 10 ? 7u : P.hi;
+    const float sps_rcp = 1.0f / (float) sps;           // correctly rounded (IEEE division, once per push)
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
     const float* in = P.in + (size_t) ch * P.in_stride;
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
@@ -558,22 +619,30 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             // below for why that matters), samples past the end of the stream zeroed afterwards
             const float* src = in + (p - tc);
             const uint32_t have = dh_min<uint32_t>(DH_FTILE + NZ, nv - p);
+            // Per lane ONE global base and ONE LDS base: group r sits 1024 bytes further in memory (immediate offset of
+            // the load) and DH_XP(4 lane + 256 r) = DH_XP(4 lane) + 272 r words further in the padded window -- written
+            // out, because the compiler otherwise rebuilds every address from the lane id (6 VALU per group).  Only the
+            // last group is partial (elements < DH_FTILE + NZ): its lanes beyond the window re-read group 0.
+            constexpr uint32_t GSTEP = NZ > 0 ? DH_XPAD(4u * DH_WAVE) : 4u * DH_WAVE;
+            constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;     // lanes of the last group inside the window
+            static_assert((DH_FTILE + NZ) % 4u == 0 && (DH_FTILE + NZ) >= 4u * DH_WAVE * (DH_PF_N - 1) && LAST_LANES <= DH_WAVE, "four full groups + a partial one cover the window");
             DH_FOR_LANES_FRESH(lane) {
                 dh_f4 v[DH_PF_N];
+                const uint32_t l4 = 4u * (uint32_t) lane;
+                const bool in_last = (uint32_t) lane < LAST_LANES;
+                const float* lsrc = src + l4;          // one 64-bit address per lane; the groups are immediate offsets of it
 #pragma unroll
-                for (int r = 0; r < DH_PF_N; r++) {
-                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                    v[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
-                }
+                for (int r = 0; r < DH_PF_N - 1; r++) v[r] = dh_load4_unaligned(lsrc + 4 * DH_WAVE * r);
+                if constexpr (LAST_LANES > 0) v[DH_PF_N - 1] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+                else v[DH_PF_N - 1] = v[0];
+                float* ldst = &S.xf[DH_XP(l4)];
                 if (have >= DH_FTILE + NZ) {
-#pragma unroll
-                    for (int r = 0; r < DH_PF_N; r++) {
-                        const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                        if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XP(e)], v[r]);
-                    }
+                    dh_lds_store4_at<0>(ldst, v[0]); dh_lds_store4_at<GSTEP>(ldst, v[1]);
+                    dh_lds_store4_at<2 * GSTEP>(ldst, v[2]); dh_lds_store4_at<3 * GSTEP>(ldst, v[3]);
+                    static_assert(DH_PF_N == 5, "four full groups + a partial one");
+                    if constexpr (LAST_LANES > 0) { if (in_last) dh_lds_store4_at<4 * GSTEP>(ldst, v[4]); }
+                    dh_lds_stores_done();
                 } else {
-                    uint32_t l4 = 4u * (uint32_t) lane;
-                    DH_TO_VGPR(l4);
 #pragma unroll
                     for (int r = 0; r < DH_PF_N; r++) {
                         const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
@@ -650,15 +719,28 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
                 float sum = 0.0f, volume_sum = 0.0f;
+                if (SPS == 10) {
+                    // all ten samples first (the ring stores below may alias them as far as the compiler knows: read one by
+                    // one, every sample would wait out its own LDS round trip before the next is even requested)
+                    float value[SPS ? SPS : 1];
 #pragma unroll
-                for (uint32_t i = 0; i < sps; i++) {
-                    const float value = DH_FB(s + i);
-                    if (i >= ev_lo && i < ev_hi) sum += value;
-                    volume_sum += value;
-                    S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;       // transposed ring: phase-major
+                    for (uint32_t i = 0; i < (SPS ? SPS : 1); i++) value[i] = DH_FB(s + i);
+#pragma unroll
+                    for (uint32_t i = 0; i < (SPS ? SPS : 1); i++) {
+                        if (i >= ev_lo && i < ev_hi) sum += value[i];
+                        volume_sum += value[i];
+                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
+                    }
+                } else {
+                    for (uint32_t i = 0; i < sps; i++) {
+                        const float value = DH_FB(s + i);
+                        if (i >= ev_lo && i < ev_hi) sum += value;
+                        volume_sum += value;
+                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;       // transposed ring: phase-major
+                    }
                 }
                 S.sum[q] = sum;
-                S.vol_new[k] = volume_sum / (float) sps;
+                S.vol_new[k] = dh_div_const(volume_sum, (float) sps, sps_rcp);
             }
         }
         DH_BARRIER();
@@ -687,10 +769,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // an explicit s_waitcnt follows the loop for the last one.
         if (pf_plain) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            const float* line = in + (p_next - tc) + 32u * threadIdx.x;
+            const uint32_t pf_lane = (uint32_t) dh_fresh_lane_id_();       // not loop-invariant: a hoisted address is spilled
+            const float* line = in + (p_next - tc) + 32u * pf_lane;
             const uint32_t sink = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) (S.xf + DH_PF_SINK);
             uint32_t keep_m0;
-            if (32u * threadIdx.x < DH_FTILE + NZ)
+            if (32u * pf_lane < DH_FTILE + NZ)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep_m0) : "s"(sink), "v"(line) : "memory");
 #endif
@@ -750,6 +833,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // u = 2^-24, mu / sigma^2 the exact mean / variance of the phase, A = mean |x|, F(m) = sum (m - x)^2 / 100
         // = sigma^2 + (m - mu)^2:
         //   |mean_ref - mu| <= 100.1 u A,  |mean' - mu| <= 25.2 u A   =>  |F(mean') - F(mean_ref)| <= (100.1 u A)^2
+        //   (the estimate's sums run as two interleaved chains of ten per lane -- packed adds / FMAs -- plus one add, so
+        //   they are shorter than the 20-long chains these constants were derived for: 16 u A and 18 u below)
         //   A^2 <= mean x^2 = sigma^2 + mu^2 <= 1.01 (F(mean') + 2 mean'^2)   =>  that difference < 1e-10 (V' + mean'^2)
         //   V_ref = F(mean_ref)(1 + 1.2e-14);  V' = F(mean')(1 + 28 u) up to 25 subnormal roundings (< 1e-42)
         // so |V' - V_ref| <= tol = 4e-6 V' + 1.2e-10 (V' + mean'^2) + 1e-42, provided nothing overflows (max |x|
@@ -762,65 +847,85 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             bool ordered = true;
             if (SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
-                float* psum = S.mn; float* pmax = S.mn + DH_WAVE; float* pd = S.mx;
+                float* psum = S.mn; float* pd = S.mx;
                 DH_LANE_ARRAY(float, pmean, 1);
+                DH_LANE_ARRAY(uint32_t, prow, 1);               // word offset of this lane's 20 ring entries
+                // pass 1: partial sums, two interleaved chains per lane (packed adds)
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
-                        const int i = lane % 10, g = lane / 10;
-                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
-                        float sx = 0.0f, ax = 0.0f;
+                        const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;     // lane / 10, lane % 10
+                        const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
+                        DH_LA(prow, lane)[0] = ro;
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
+                        dh_f2 s2 = dh_f2_make(0.0f, 0.0f);
 #pragma unroll
                         for (int q = 0; q < 5; q++) {
                             const dh_f4a v = row[q];
-                            sx += v.x; sx += v.y; sx += v.z; sx += v.w;
-                            ax = __builtin_fmaxf(__builtin_fmaxf(ax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
-                            ax = __builtin_fmaxf(__builtin_fmaxf(ax, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
+                            s2 = dh_f2_add(s2, dh_f2_make(v.x, v.y)); s2 = dh_f2_add(s2, dh_f2_make(v.z, v.w));
                         }
-                        psum[lane] = sx; pmax[lane] = ax;
+                        psum[lane] = s2.x + s2.y;
                     }
                 }
                 DH_BARRIER();
+                // pass 2: squared deviations from the float mean, again two chains per lane (packed subtract + FMA)
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
-                        const int i = lane % 10, g = lane / 10;
-                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20);
+                        const uint32_t ro = DH_LA(prow, lane)[0];
+                        const uint32_t i = ro / DH_VARIANCE_SYMBOLS;
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
                         const float total = (((psum[i] + psum[i + 10]) + psum[i + 20]) + psum[i + 30]) + psum[i + 40];
                         const float mean = total * 0.01f;
-                        float acc = 0.0f;
+                        const dh_f2 m2 = dh_f2_make(mean, mean);
+                        dh_f2 a2 = dh_f2_make(0.0f, 0.0f);
 #pragma unroll
                         for (int q = 0; q < 5; q++) {
                             const dh_f4a v = row[q];
-                            const float d0 = mean - v.x, d1 = mean - v.y, d2 = mean - v.z, d3 = mean - v.w;
-                            acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
-                            acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
+                            const dh_f2 d0 = dh_f2_sub(m2, dh_f2_make(v.x, v.y)), d1 = dh_f2_sub(m2, dh_f2_make(v.z, v.w));
+                            a2 = dh_f2_fma(d0, d0, a2); a2 = dh_f2_fma(d1, d1, a2);
                         }
-                        pd[lane] = acc;
+                        pd[lane] = a2.x + a2.y;
                         DH_LA(pmean, lane)[0] = mean;
                     }
                 }
                 DH_BARRIER();
                 // lanes 0..9 hold one phase each; the others hold neutral values
                 DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
-                uint64_t vote_guard = 0, vote_zero = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
+                uint64_t vote_guard = 0, vote_vzero = 0, vote_zero = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
                 DH_FOR_LANES_FRESH(lane) {
                     float l = DH_FLT_MAX, h = DH_FLT_MAX;
-                    bool guard = true, zero = false;
+                    bool guard = true, vzero = false;
                     if (lane < 10) {
                         const int i = lane;
                         const float v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) * 0.01f;
-                        const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(pmax[i], pmax[i + 10]), __builtin_fmaxf(pmax[i + 20], pmax[i + 30])), pmax[i + 40]);
                         const float mean = DH_LA(pmean, lane)[0];
                         const float e = __builtin_fmaf(mean, mean, v);
                         const float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
-                        guard = (e < 1e30f) && (amax < 1e16f);           // false for NaN
-                        zero = amax == 0.0f;
+                        guard = e < 1e30f;                           // false for NaN, and for samples beyond ~1e15 (e overflows first)
+                        vzero = v == 0.0f;
                         l = v - tol; h = v + tol;
                     }
                     DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
                     DH_BALLOT_ACC(vote_guard, guard, lane);
-                    DH_BALLOT_ACC(vote_zero, zero, lane);
+                    DH_BALLOT_ACC(vote_vzero, vzero, lane);
                     DH_BALLOT_ACC(vote_pos, l > 0.0f, lane);
                     DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
+                }
+                const uint32_t ten = 0x3FFu;
+                if ((uint32_t) vote_vzero & ten) {
+                    // an estimate of exactly 0: only a phase whose hundred samples are all (+-)0 has vmin == 0 for sure (tiny
+                    // samples square to 0 in float, not in the reference's double) -- look at the bits
+                    uint64_t vote_nz = 0;
+                    DH_FOR_LANES_FRESH(lane) {
+                        uint32_t any = 0;
+                        if (lane < 50) {
+                            const uint32_t* row = reinterpret_cast<const uint32_t*>(S.var_rb + DH_LA(prow, lane)[0]);
+#pragma unroll
+                            for (int q = 0; q < 20; q++) any |= row[q];
+                        }
+                        DH_BALLOT_ACC(vote_nz, (any << 1) != 0u, lane);
+                    }
+                    const uint32_t nz = (uint32_t) (vote_nz | (vote_nz >> 10) | (vote_nz >> 20) | (vote_nz >> 30) | (vote_nz >> 40));
+                    vote_zero = ~nz & ten;
                 }
                 float hmin;
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -830,7 +935,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 for (int q = 0; q < 10; q++) hmin = dh_fmin_(hmin, hi[q][0]);
 #endif
                 DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
-                const uint32_t ten = 0x3FFu;
                 const uint32_t above = (uint32_t) vote_above & ten;
                 const uint32_t cand = ~above & ten;                 // phases whose interval reaches below hmin
                 if (((uint32_t) vote_guard & ten) != ten) {

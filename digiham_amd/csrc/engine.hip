@@ -178,6 +178,11 @@ __global__ void k_div_gain(const float* in, float* out, size_t n, double gain, d
         out[i] = dh_div_gain(in[i], gain, rgain);
 }
 
+__global__ void k_div_const(const float* in, float* out, size_t n, float d, float r) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        out[i] = dh_div_const(in[i], d, r);
+}
+
 inline unsigned grid_for(size_t n, unsigned block) {
     const size_t g = (n + block - 1) / block;
     return (unsigned) (g < 1 ? 1 : (g > 8192 ? 8192 : g));      // 256 CUs x 32 resident workgroups, grid-stride beyond
@@ -411,6 +416,14 @@ static int dh_be_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n
 static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n, void* stream) {
     if (!B) return DH_OK;
     hipLaunchKernelGGL(k_dvfilter, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, out, state, B, stride, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+
+static int dh_be_div_const(const float* in, float* out, size_t n, unsigned divisor, void* stream) {
+    if (!n) return DH_OK;
+    const float d = (float) divisor;
+    hipLaunchKernelGGL(k_div_const, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, in, out, n, d, 1.0f / d);
     HIP_TRY(hipGetLastError());
     return DH_OK;
 }

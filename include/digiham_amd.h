@@ -215,6 +215,10 @@ int dh_dvfilter_s16(const int16_t* d_in, int16_t* d_out, float* d_state, size_t 
  * d_out[i] must equal (float)((double)d_in[i] / gain) for every float.
  * ---------------------------------------------------------------------- */
 int dh_debug_div_gain(const float* d_in, float* d_out, size_t n, int narrow, void* stream);
+/* The slicer's `volume_sum / samplesPerSymbol` (src/gfsk_demodulator/gfsk_demodulator.cpp:83) exactly as the kernels
+ * evaluate it (reciprocal multiply + exact FMA residual + correction; IEEE division for 0, tiny, huge and non-finite
+ * operands).  d_out[i] must equal d_in[i] / (float) divisor for every float. */
+int dh_debug_div_const(const float* d_in, float* d_out, size_t n, unsigned divisor, void* stream);
 
 #ifdef __cplusplus
 }

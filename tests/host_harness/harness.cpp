@@ -139,5 +139,11 @@ static int dh_be_div_gain(const float* in, float* out, size_t n, int narrow, voi
     return 0;
 }
 
+static int dh_be_div_const(const float* in, float* out, size_t n, unsigned divisor, void*) {
+    const float d = (float) divisor, r = 1.0f / d;
+    for (size_t i = 0; i < n; i++) out[i] = dh_div_const(in[i], d, r);
+    return 0;
+}
+
 #define DH_BACKEND HostBackend
 #include "../../digiham_amd/csrc/abi_impl.hpp"

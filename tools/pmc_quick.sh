@@ -2,7 +2,7 @@
 # tools/pmc_quick.sh <tag> [bench args]: instruction-count + clock PMC passes of the headline bench (no trace)
 TAG=${1:-q}; shift || true
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --verify 0 $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --verify 0 $*"
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
