@@ -124,6 +124,22 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps) {          // base: 16-
 #define DH_CLK(i) ((void) 0)
 #endif
 
+// Wave priority (s_setprio 0..3) around the FIR: the instruction arbiter of a SIMD serves its oldest wavefront first,
+// so left alone a young wavefront makes little progress until the older ones are gone.
+// DH_PRIO_MODE selects the policy (measured with tools/lib_ab.py): 0 = hardware default;
+// 3 (shipped) = priority 3 outside the FIR and in the decoder half (the short, latency-bound stretches get their few
+// instructions issued at once), inside the FIR 2 / 1 / 0 / 0 by the quarter of the push the wavefront has reached, so a
+// young wavefront catches up with its elders and the last ones of a launch finish closer together (DMR chain -1.8 %,
+// slicer alone -2.7 %; 1 = only FIR low, 2 = only progress, 6 / 7 = progress for the last 4 096 / 8 192 channels: worse).
+#ifndef DH_PRIO_MODE
+#define DH_PRIO_MODE 3
+#endif
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_PRIO_MODE
+#define DH_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define DH_SETPRIO(n) ((void) 0)
+#endif
+
 // per-lane values that must survive a barrier: registers on the GPU, [lane] arrays in the harness
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 #define DH_LANE_ARRAY(type, name, n) type name[n]
@@ -554,6 +570,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // (the samples are then used where they were staged, and the window sums sit right behind them)
 #define DH_XP(e) (NZ > 0 ? DH_XPAD(e) : (e))
     DH_CLK_BEGIN();
+#if defined(DH_WAVE_TIMELINE) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t dh_t_start = (uint32_t) wall_clock64();        // diagnostic build: when this channel's wavefront ran (100 MHz)
+#endif
     // ---- load carried state
     uint32_t k0 = sth[DH_ST_K];
     int32_t off = (int32_t) sth[DH_ST_OFF];
@@ -685,6 +704,22 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // only, and the LDS pipe has slack.  Without an RRC stage the staged (padded) samples are used as they are.
         if (NZ > 0) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
+#if DH_PRIO_MODE == 1
+            DH_SETPRIO(0);
+#elif DH_PRIO_MODE >= 2
+            {
+#if DH_PRIO_MODE >= 6
+                const bool dh_prio_on = ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels;     // the wavefronts dispatched last
+#else
+                const bool dh_prio_on = true;
+#endif
+                if (dh_prio_on) {
+                    const uint32_t quarter = nf / 4u + 1u; const uint32_t done = p / quarter;      // 0..3
+                    if (done == 0) DH_SETPRIO(DH_PRIO_MODE == 2 ? 3 : 2); else if (done == 1) DH_SETPRIO(DH_PRIO_MODE == 2 ? 2 : 1);
+                    else if (done == 2) DH_SETPRIO(DH_PRIO_MODE == 2 ? 1 : 0); else DH_SETPRIO(0);
+                }
+            }
+#endif
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
             float tv[NZ / 2 + 1];
 #pragma unroll
@@ -708,6 +743,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
             }
             DH_BARRIER();
+#if DH_PRIO_MODE == 1 || DH_PRIO_MODE == 3
+            DH_SETPRIO(3);
+#elif DH_PRIO_MODE >= 6
+            if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
+#endif
         }
         DH_CLK(1);
         const float* fbuf = S.xf;
@@ -1047,6 +1087,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             sth[DH_ST_NSYM] += nsym;
 #ifdef DH_PHASE_CLOCKS
             for (int i = 0; i < 8; i++) sth[6 + i] += S.clk[i] >> 6;
+#endif
+#if defined(DH_WAVE_TIMELINE) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            sth[14] = dh_t_start; sth[15] = (uint32_t) wall_clock64();
+            sth[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+            sth[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
 #endif
             sth[DH_ST_BLOCKS] += S.stats[0];
             sth[DH_ST_ORDERED] += S.stats[1];

@@ -66,6 +66,11 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     }
     __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
     __syncthreads();
+#if DH_PRIO_MODE >= 1 && DH_PRIO_MODE <= 5
+    DH_SETPRIO(3);
+#elif DH_PRIO_MODE >= 6
+    if (blockIdx.x + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
+#endif
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
     if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, blockIdx.x, S);
     else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, blockIdx.x, S);

@@ -49,12 +49,26 @@ def _insts(lines):
             yield l
 
 
+def _insts_asm(lines):
+    """(instruction, came from an inline-asm block) -- the compiler tracks its own loads; only asm ones need this test"""
+    in_asm = False
+    for l in lines:
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        t = l.split(";")[0].strip()
+        if t and not t.startswith(".") and not t.endswith(":"):
+            yield t, in_asm
+
+
 def test_fir_asm_loads_are_not_touched_before_their_wait(kernels):
     checked = 0
     for name, (lines, _) in kernels.items():
         if "k_chain" not in name and "k_rrc_demod" not in name and "k_rrc_tile" not in name:
             continue
-        insts = list(_insts(lines))
+        pairs = list(_insts_asm(lines))
+        insts = [a for a, _ in pairs]
         pk = [i for i, l in enumerate(insts) if l.startswith("v_pk_mul_f32") or l.startswith("v_pk_fma_f32")]
         if not pk:
             continue
@@ -69,7 +83,7 @@ def test_fir_asm_loads_are_not_touched_before_their_wait(kernels):
             touched = _regs(rest)
             bad = touched & set(pending)
             assert not bad, "%s: `%s` touches v%s while the ds_read2 at #%d is in flight" % (name, l, sorted(bad), pending[min(bad)])
-            if op == "ds_read2_b32":
+            if op == "ds_read2_b32" and pairs[i][1]:
                 for r in _regs(rest.split(",")[0]):
                     pending[r] = i
                 checked += 1
@@ -106,8 +120,19 @@ def test_exact_kernels_do_not_fuse_and_do_not_spill(kernels):
     assert len(exact) == 2                                            # DMR and YSF
     for name, (lines, meta) in kernels.items():
         if name in exact:                                             # exact wide-filter chain kernels
-            body = "\n".join(lines)
-            assert "v_pk_mul_f32" in body and "v_pk_add_f32" in body and "v_pk_fma_f32" not in body
+            # the FIR is one straight-line block (about 1 280 packed multiplies / adds): nothing fused in there.  (The
+            # error-bounded timing estimate elsewhere in the kernel does use packed FMAs: its bound covers them.)
+            blocks, cur = [], []
+            for l in lines:
+                t = l.split(";")[0].strip()
+                if t.endswith(":") and t.startswith(".LBB"):
+                    blocks.append(cur); cur = []
+                elif t and not t.startswith("."):
+                    cur.append(t)
+            blocks.append(cur)
+            fir = max(blocks, key=lambda b: sum(i.startswith("v_pk_mul_f32") for i in b))
+            assert sum(i.startswith("v_pk_mul_f32") for i in fir) >= 600 and sum(i.startswith("v_pk_add_f32") for i in fir) >= 600     # 81 taps x 8 pairs
+            assert not [i for i in fir if i.startswith(("v_pk_fma_f32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32"))], name + " fuses inside the FIR"
             insts = list(_insts(lines))
             pk = [i for i, l in enumerate(insts) if l.startswith("v_pk_mul_f32")]
             spills = [i for i, l in enumerate(insts) if "scratch_" in l]
