@@ -3,11 +3,11 @@
 #include "digiham/digitalvoice_filter.hpp"
 
 namespace {
-    class Cli: public Digiham::Cli<short, short> {
+    class Tool: public Digiham::Cli<short, short> {
         protected:
             std::string getName() override { return "digitalvoice_filter"; }
             Csdr::Module<short, short>* buildModule() override { return new Digiham::DigitalVoice::DigitalVoiceFilter(); }
     };
 }
 
-int main(int argc, char** argv) { Cli runner; return runner.main(argc, argv); }
+int main(int argc, char** argv) { Tool tool; return tool.main(argc, argv); }

@@ -1,10 +1,9 @@
-// dstar_decoder -- bits in (fsk_demodulator -s 10), 9-byte AMBE voice frames out, metadata lines to --fifo
-// (reference: src/dstar_decoder/dstar_cli.cpp, examples/dstar-decoder.sh)
+// dstar_decoder -- bits (fsk_demodulator -s 10) in, 9-byte AMBE voice frames out, metadata lines to --fifo (reference: src/dstar_decoder/dstar_cli.cpp, examples/dstar-decoder.sh)
 #include "digiham/cli.hpp"
 #include "digiham/dstar_decoder.hpp"
 
 namespace {
-    class Cli: public Digiham::DecoderCli {
+    class Tool: public Digiham::DecoderCli {
         protected:
             std::string getName() override { return "dstar_decoder"; }
             Csdr::Module<unsigned char, unsigned char>* buildModule() override {
@@ -15,4 +14,4 @@ namespace {
     };
 }
 
-int main(int argc, char** argv) { Cli runner; return runner.main(argc, argv); }
+int main(int argc, char** argv) { Tool tool; return tool.main(argc, argv); }

@@ -3,7 +3,7 @@
 #include "digiham/nxdn_decoder.hpp"
 
 namespace {
-    class Cli: public Digiham::DecoderCli {
+    class Tool: public Digiham::DecoderCli {
         protected:
             std::string getName() override { return "nxdn_decoder"; }
             Csdr::Module<unsigned char, unsigned char>* buildModule() override {
@@ -14,4 +14,4 @@ namespace {
     };
 }
 
-int main(int argc, char** argv) { Cli runner; return runner.main(argc, argv); }
+int main(int argc, char** argv) { Tool tool; return tool.main(argc, argv); }

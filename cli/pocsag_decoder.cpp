@@ -4,11 +4,11 @@
 #include "digiham/pocsag_decoder.hpp"
 
 namespace {
-    class Cli: public Digiham::Cli<unsigned char, unsigned char> {
+    class Tool: public Digiham::Cli<unsigned char, unsigned char> {
         protected:
             std::string getName() override { return "pocsag_decoder"; }
             Csdr::Module<unsigned char, unsigned char>* buildModule() override { return new Digiham::Pocsag::Decoder(); }
     };
 }
 
-int main(int argc, char** argv) { Cli runner; return runner.main(argc, argv); }
+int main(int argc, char** argv) { Tool tool; return tool.main(argc, argv); }

@@ -3,22 +3,12 @@
 #include "digiham/rrc_filter.hpp"
 
 namespace {
-    class Cli: public Digiham::Cli<float, float> {
+    class Tool: public Digiham::Cli<float, float> {
         protected:
             std::string getName() override { return "rrc_filter"; }
-            std::stringstream getUsageString() override {
-                std::stringstream result = Digiham::Cli<float, float>::getUsageString();
-                result << " -n, --narrow        use narrow (6.25kHz) filter version (default: wide / 12.5kHz)\n";
-                return result;
-            }
-            std::vector<struct option> getOptions() override {
-                std::vector<struct option> options = Digiham::Cli<float, float>::getOptions();
-                options.push_back({"narrow", no_argument, NULL, 'n'});
-                return options;
-            }
-            bool receiveOption(int c, char* optarg) override {
-                if (c == 'n') { narrow = true; return true; }
-                return Digiham::Cli<float, float>::receiveOption(c, optarg);
+            void declareOptions(std::vector<Digiham::CliOption>& table) override {
+                table.push_back({ 'n', "narrow", nullptr, "use narrow (6.25kHz) filter version (default: wide / 12.5kHz)",
+                                  [this] (const char*) { narrow = true; return true; } });
             }
             Csdr::Module<float, float>* buildModule() override {
                 if (narrow) return new Digiham::RrcFilter::NarrowRrcFilter();
@@ -29,4 +19,4 @@ namespace {
     };
 }
 
-int main(int argc, char** argv) { Cli runner; return runner.main(argc, argv); }
+int main(int argc, char** argv) { Tool tool; return tool.main(argc, argv); }

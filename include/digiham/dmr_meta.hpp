@@ -1,207 +1,134 @@
-// dmr_meta.hpp -- Digiham::Dmr::{Slot, MetaCollector, TalkerAliasCollector, Gps} on decoder events.
-// Reference: include/dmr_meta.hpp, src/dmr_decoder/dmr_meta.cpp:11-179 (slot state + `protocol:DMR;slot:N;...`
-// lines), talkeralias.cpp:20-144, gps.cpp:7-17, and the call sites in dmr_phase.cpp (:80, :111-114, :178-184,
-// :196-202, :233, :280, :295, :304-339).  PARITY UNPINNED (see meta.hpp).
+// dmr_meta.hpp -- DMR call metadata from decoder events: `protocol:DMR;slot:N;sync:..;type:..;source:..;target:..;
+// talkeralias:..;lat:..;lon:..` lines, one per change and slot.
+//
+// What the reference does while it parses bursts (call sites dmr_phase.cpp:80, :109-114, :178-184, :196-202, :233,
+// :279-282, :295, :304-339 into dmr_meta.cpp:11-179, talkeralias.cpp:20-144, gps.cpp:7-17) happens here after the
+// fact: the GPU decoder reports those calls as dh_events, and Dmr::MetaCollector replays them on two slot records.
+// A slot record is a FieldRecord (meta.hpp): seven text fields in wire order, one change flag; an event is a handful
+// of put()s and at most one line.
+//
+// Pinned against the reference's own classes (tests/golden/elements_ref.npz via tests/host_cpp/elements_test.cpp):
+// Gps::parse, TalkerAliasCollector (all four formats, partial and out-of-order blocks), Lc getters.  The event ->
+// line rules are restated from the cited lines (PARITY UNPINNED: dmr_meta.cpp / dmr_phase.cpp need csdr).
 #pragma once
 
+#include <cmath>
 #include <cstring>
 #include <string>
 
 #include "lc.hpp"
 #include "meta.hpp"
 
-#define META_TYPE_DIRECT 1
-#define META_TYPE_GROUP 2
 #define SYNCTYPE_DATA 1
 #define SYNCTYPE_VOICE 2
-
-#define TALKER_ALIAS_FORMAT_7BIT 0
-#define TALKER_ALIAS_FORMAT_8BIT 1
-#define TALKER_ALIAS_FORMAT_UTF8 2
-#define TALKER_ALIAS_FORMAT_UTF16 3
 
 namespace Digiham {
     namespace Dmr {
 
-        struct Gps {                                            // gps.cpp:7-17
-            static Coordinate* parse(const unsigned char* data) {
-                int32_t latitudeBits = ((data[4] & 0x7F) << 16) | (data[5] << 8) | data[6];
-                if (data[4] & 0x80) latitudeBits *= -1;
-                int32_t longitudeBits = (data[1] << 16) | (data[2] << 8) | data[3];
-                if (data[0] & 0x01) longitudeBits *= -1;
-                return new Coordinate(180.0f / (float) (1 << 24) * (float) latitudeBits,
-                                      360.0f / (float) (1 << 25) * (float) longitudeBits);
+        // GPS Info LC, bytes 2..8 of the LC word (Lc::getData()): longitude sign in bit 0 of byte 0, 24-bit magnitude in
+        // bytes 1-3, steps of 360 / 2^25 degrees; latitude sign in bit 7 of byte 4, 23-bit magnitude below it, steps of
+        // 180 / 2^24 degrees.  Both step sizes are exact binary fractions times 45, so magnitude * 45 scaled by a power
+        // of two rounds once -- the same float as the reference's `180.0f / (1 << 24) * (float) bits`.
+        struct Gps {
+            static Coordinate* parse(const unsigned char* d) {
+                const int32_t lat = (int32_t) (d[4] & 0x7F) << 16 | d[5] << 8 | d[6];
+                const int32_t lon = (int32_t) d[1] << 16 | d[2] << 8 | d[3];
+                return new Coordinate(std::ldexp((float) (45 * (d[4] & 0x80 ? -lat : lat)), -22),
+                                      std::ldexp((float) ((int64_t) 45 * (d[0] & 0x01 ? -lon : lon)), -22));
             }
         };
 
-        class TalkerAliasCollector {                            // talkeralias.cpp:20-144
+        // Talker alias: up to four 7-byte LC payloads (header block + 3), 28 bytes read as ONE bit string.
+        // Byte 0: format (2 bits), length in characters (5 bits), and the first payload bit.
+        class TalkerAliasCollector {
             public:
-                void reset() { blocks = 0; }
-                void setBlock(int block, const unsigned char* d) {
-                    std::memcpy(data + (size_t) block * 7, d, 7);
-                    blocks |= 1 << block;
+                enum Format { Bits7 = 0, Latin1 = 1, Utf8 = 2, Utf16 = 3 };
+                void reset() { have = 0; }
+                void setBlock(int block, const unsigned char* payload) {
+                    std::memcpy(bytes + 7 * block, payload, 7);
+                    have |= 1u << block;
                 }
+                // enough consecutive blocks (from the header on) for the announced length?  The per-format arithmetic is the
+                // reference's (talkeralias.cpp:32-51), including its 7-bit estimate (bytes * 7 / 8 - 1 characters)
                 bool isComplete() {
-                    if (!hasHeader()) return false;
-                    const unsigned char bytes = collectedBytes();
-                    switch (getDataFormat()) {
-                        case TALKER_ALIAS_FORMAT_7BIT: return ((bytes * 7) / 8) - 1 >= getLength();
-                        case TALKER_ALIAS_FORMAT_8BIT: return bytes - 1 >= getLength();
-                        case TALKER_ALIAS_FORMAT_UTF8: return getContents().length() >= getLength();
-                        case TALKER_ALIAS_FORMAT_UTF16: return (bytes - 1) / 2 >= getLength();
+                    if (!(have & 1u)) return false;
+                    const int n = usable(), want = length();
+                    switch (format()) {
+                        case Bits7: return n * 7 / 8 - 1 >= want;
+                        case Latin1: return n - 1 >= want;
+                        case Utf8: return (int) getContents().size() >= want;
+                        default: return (n - 1) / 2 >= want;
                     }
-                    return false;
                 }
                 std::string getContents() {
-                    if (!hasHeader()) return "";
-                    const unsigned char bytes = collectedBytes();
-                    std::string result;
-                    switch (getDataFormat()) {
-                        case TALKER_ALIAS_FORMAT_7BIT: {
-                            std::string all;
-                            for (size_t i = 0; i < bytes; i += 7) all += convert7BitData(data + i);
-                            result = all.substr(1);     // first character is built from the header bits
+                    if (!(have & 1u)) return std::string();
+                    const int n = usable();
+                    std::string text;
+                    switch (format()) {
+                        case Bits7:                            // n * 8 / 7 seven-bit characters, MSB first; the first one is header bits
+                            for (int bit = 7; bit + 7 <= 8 * n; bit += 7) text += (char) take(bit, 7);
                             break;
-                        }
-                        case TALKER_ALIAS_FORMAT_8BIT:
-                            result = Converter::convertToUtf8((const char*) data + 1, bytes - 1);
-                            break;
-                        case TALKER_ALIAS_FORMAT_UTF8:
-                            result = std::string((const char*) data + 1, bytes - 1);
-                            break;
-                        case TALKER_ALIAS_FORMAT_UTF16: {
-                            // big-endian UTF-16 code units to UTF-8 (std::codecvt_utf8_utf16 in the reference, :96-108)
-                            const unsigned int chars = (bytes - 1) / 2;
-                            const unsigned char* src = data + 1;
-                            for (unsigned int k = 0; k < chars; k++) {
-                                uint32_t cp = (uint32_t) (src[k * 2] << 8) | src[k * 2 + 1];
-                                if (cp >= 0xD800 && cp < 0xDC00 && k + 1 < chars) {
-                                    const uint32_t lo = (uint32_t) (src[k * 2 + 2] << 8) | src[k * 2 + 3];
-                                    if (lo >= 0xDC00 && lo < 0xE000) { cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); k++; }
+                        case Latin1: text = Converter::convertToUtf8((const char*) bytes + 1, (size_t) n - 1); break;
+                        case Utf8: text.assign((const char*) bytes + 1, (size_t) n - 1); break;
+                        default:                               // UTF-16BE code units; a surrogate pair is one character
+                            for (int at = 1; at + 2 <= n; at += 2) {
+                                uint32_t cp = take(8 * at, 16);
+                                if ((cp & 0xFC00) == 0xD800 && at + 4 <= n && (take(8 * at + 16, 16) & 0xFC00) == 0xDC00) {
+                                    cp = 0x10000 + ((cp & 0x3FF) << 10) + (take(8 * at + 16, 16) & 0x3FF);
+                                    at += 2;
                                 }
-                                appendUtf8(result, cp);
+                                appendUtf8(text, cp);
                             }
-                            break;
-                        }
                     }
-                    if (result.length() > getLength()) result = result.substr(0, getLength());
-                    return result;
+                    if ((int) text.size() > length()) text.resize((size_t) length());          // bytes, not characters (talkeralias.cpp:104-106)
+                    return text;
                 }
             private:
-                bool hasHeader() const { return blocks & 1; }
-                unsigned char getDataFormat() const { return data[0] >> 6; }
-                unsigned char getLength() const { return (data[0] & 0x3E) >> 1; }
-                unsigned char collectedBytes() const {
-                    int i;
-                    for (i = 0; i < 4; i++) {
-                        const unsigned char mask = (unsigned char) ((1 << (i + 1)) - 1);
-                        if ((blocks & mask) != mask) break;
-                    }
-                    return (unsigned char) (i * 7);
+                int format() const { return bytes[0] >> 6; }
+                int length() const { return (bytes[0] >> 1) & 0x1F; }
+                int usable() const {                           // bytes of the blocks present without a gap, header first
+                    int blocks = 0;
+                    while (blocks < 4 && (have >> blocks & 1u)) blocks++;
+                    return 7 * blocks;
                 }
-                static std::string convert7BitData(const unsigned char* s) {   // :131-142
-                    unsigned char r[8];
-                    r[0] = (s[0] & 0xFE) >> 1;
-                    r[1] = (unsigned char) ((s[0] & 0x01) << 6 | (s[1] & 0xFC) >> 2);
-                    r[2] = (unsigned char) ((s[1] & 0x03) << 5 | (s[2] & 0xF8) >> 3);
-                    r[3] = (unsigned char) ((s[2] & 0x07) << 4 | (s[3] & 0xF0) >> 4);
-                    r[4] = (unsigned char) ((s[3] & 0x0F) << 3 | (s[4] & 0xE0) >> 5);
-                    r[5] = (unsigned char) ((s[4] & 0x1F) << 2 | (s[5] & 0xC0) >> 6);
-                    r[6] = (unsigned char) ((s[5] & 0x3F) << 1 | (s[6] & 0x80) >> 7);
-                    r[7] = s[6] & 0x7F;
-                    return std::string((const char*) r, 8);
+                uint32_t take(int bit, int count) const {      // `count` bits of the 224-bit string from position `bit`, MSB first
+                    uint32_t v = 0;
+                    for (int i = bit; i < bit + count; i++) v = v << 1 | (bytes[i >> 3] >> (7 - (i & 7)) & 1u);
+                    return v;
                 }
-                static void appendUtf8(std::string& out, uint32_t cp) {
-                    if (cp < 0x80) out.push_back((char) cp);
-                    else if (cp < 0x800) { out.push_back((char) (0xC0 | (cp >> 6))); out.push_back((char) (0x80 | (cp & 0x3F))); }
-                    else if (cp < 0x10000) {
-                        out.push_back((char) (0xE0 | (cp >> 12))); out.push_back((char) (0x80 | ((cp >> 6) & 0x3F)));
-                        out.push_back((char) (0x80 | (cp & 0x3F)));
-                    } else {
-                        out.push_back((char) (0xF0 | (cp >> 18))); out.push_back((char) (0x80 | ((cp >> 12) & 0x3F)));
-                        out.push_back((char) (0x80 | ((cp >> 6) & 0x3F))); out.push_back((char) (0x80 | (cp & 0x3F)));
-                    }
-                }
-                unsigned char data[28] = { 0 };
-                unsigned char blocks = 0;
+                unsigned char bytes[28] = { 0 };
+                unsigned have = 0;
         };
 
-        class Slot {                                            // dmr_meta.cpp:7-131
-            public:
-                ~Slot() { delete coordinate; }
-                void setSync(int v) { if (sync == v) return; sync = v; dirty = true; }
-                void setType(int v) { if (type == v) return; type = v; dirty = true; }
-                void setSource(uint32_t v) { if (source == v) return; source = v; dirty = true; }
-                void setTarget(uint32_t v) { if (target == v) return; target = v; dirty = true; }
-                void setFromLc(Lc* lc) {
-                    switch (lc->getOpCode()) {
-                        case LC_OPCODE_GROUP: setType(META_TYPE_GROUP); break;
-                        case LC_OPCODE_UNIT_TO_UNIT: setType(META_TYPE_DIRECT); break;
-                        default: break;
-                    }
-                    setTarget(lc->getTarget());
-                    setSource(lc->getSource());
-                }
-                void setTalkerAlias(const std::string& alias) { if (talkerAlias == alias) return; talkerAlias = alias; dirty = true; }
-                void setCoordinate(Coordinate* coord) {
-                    if (coordinate == coord || (coordinate != nullptr && coord != nullptr && *coordinate == *coord)) { delete coord; return; }
-                    auto old = coordinate; coordinate = coord; delete old;
-                    dirty = true;
-                }
-                bool isDirty() const { return dirty; }
-                void setClean() { dirty = false; }
-                void softReset() { setType(-1); setSource(0); setTarget(0); setTalkerAlias(""); setCoordinate(nullptr); }
-                void reset() { softReset(); setSync(-1); }
-                std::map<std::string, std::string> collect() {
-                    std::map<std::string, std::string> result;
-                    if (sync > 0) result["sync"] = sync == SYNCTYPE_DATA ? "data" : sync == SYNCTYPE_VOICE ? "voice" : "unknown";
-                    if (type > 0) result["type"] = type == META_TYPE_DIRECT ? "direct" : type == META_TYPE_GROUP ? "group" : "unknown";
-                    if (source > 0) result["source"] = std::to_string(source);
-                    if (target > 0) result["target"] = std::to_string(target);
-                    if (!talkerAlias.empty()) result["talkeralias"] = talkerAlias;
-                    if (coordinate != nullptr) {
-                        result["lat"] = std::to_string(coordinate->lat);
-                        result["lon"] = std::to_string(coordinate->lon);
-                    }
-                    return result;
-                }
-            private:
-                bool dirty = false;
-                int sync = -1, type = -1;
-                uint32_t source = 0, target = 0;
-                std::string talkerAlias;
-                Coordinate* coordinate = nullptr;
-        };
-
-        class MetaCollector: public Digiham::MetaCollector {    // dmr_meta.cpp:133-179 + the call sites in dmr_phase.cpp
+        class MetaCollector: public Digiham::MetaCollector {
             public:
                 void consume(const dh_event& ev) override {
-                    const int slot = ev.a & 1;
+                    const int s = ev.a & 1;
+                    Call& call = calls[s];
                     switch (ev.type) {
-                        case DH_EV_DMR_SYNC:                    // dmr_phase.cpp:109-114
-                            slots[slot].setSync(ev.b);
-                            if (ev.len > 0 && ev.payload[0]) slots[slot].softReset();
-                            if (ev.b != SYNCTYPE_VOICE) aliases[slot].reset();     // :233 (every non-voice burst of the slot)
-                            sendMetaDataForSlot(slot);
+                        case DH_EV_DMR_SYNC:                   // a burst with a sync pattern (dmr_phase.cpp:109-114)
+                            call.fields.put(SYNC, ev.b == SYNCTYPE_DATA ? "data" : ev.b == SYNCTYPE_VOICE ? "voice" : "unknown");
+                            if (ev.len > 0 && ev.payload[0]) call.endCall();       // voice -> data on this slot
+                            if (ev.b != SYNCTYPE_VOICE) call.alias.reset();        // :233: every non-voice burst
+                            publish(s);
                             break;
-                        case DH_EV_DMR_SLOT_RESET:              // :80, :178-180, :196-198, :295
-                            slots[slot].reset();
-                            aliases[slot].reset();
-                            sendMetaDataForSlot(slot);
+                        case DH_EV_DMR_SLOTTYPE:               // a data burst (:233)
+                            call.alias.reset();
                             break;
-                        case DH_EV_DMR_SLOTTYPE:                // a data burst: :233
-                            aliases[slot].reset();
+                        case DH_EV_DMR_SLOT_RESET:             // the slot lost its sync (:80, :178-180, :196-198, :295)
+                            call.lose();
+                            publish(s);
                             break;
-                        case DH_EV_DMR_META_RESET:              // :184, :202
-                            for (int i = 0; i < 2; i++) slots[i].reset();
-                            for (int i = 0; i < 2; i++) sendMetaDataForSlot(i);
+                        case DH_EV_DMR_META_RESET:             // the decoder fell back to its sync search (:184, :202)
+                            for (Call& c : calls) { c.fields.wipe(); c.alias.reset(); }     // a new FramePhase starts with empty alias collectors
+                            publish(0); publish(1);
                             break;
-                        case DH_EV_DMR_SOFT_RESET:              // :279-282 (terminator LC / idle)
-                            slots[slot].softReset();
-                            sendMetaDataForSlot(slot);
+                        case DH_EV_DMR_SOFT_RESET:             // terminator LC / idle burst (:279-282)
+                            call.endCall();
+                            publish(s);
                             break;
-                        case DH_EV_DMR_LC:                      // handleLc, :304-339
-                            if (ev.len >= 9) handleLc(slot, ev.payload);
+                        case DH_EV_DMR_LC:                     // a link control word, voice header or embedded (:304-339)
+                            if (ev.len >= 9) { linkControl(call, Lc(ev.payload)); publish(s); }
                             break;
                         default:
                             break;
@@ -210,44 +137,41 @@ namespace Digiham {
             protected:
                 std::string getProtocol() override { return "DMR"; }
             private:
-                void handleLc(int slot, const unsigned char* bytes) {
-                    Lc lc(bytes);
-                    const unsigned char opcode = lc.getOpCode();
-                    switch (opcode) {
-                        case LC_OPCODE_GROUP:
-                        case LC_OPCODE_UNIT_TO_UNIT:
-                            slots[slot].setFromLc(&lc);
-                            sendMetaDataForSlot(slot);
-                            break;
-                        case LC_TALKER_ALIAS_HDR: case LC_TALKER_ALIAS_BLK1: case LC_TALKER_ALIAS_BLK2: case LC_TALKER_ALIAS_BLK3:
-                            aliases[slot].setBlock(opcode - LC_TALKER_ALIAS_HDR, lc.getData());
-                            if (aliases[slot].isComplete()) {
-                                std::string alias = aliases[slot].getContents();
-                                const auto end = alias.find_last_not_of('\0');
-                                alias = end == std::string::npos ? "" : alias.substr(0, end + 1);
-                                slots[slot].setTalkerAlias(alias);
-                                sendMetaDataForSlot(slot);
-                            }
-                            break;
-                        case LC_GPS_INFO:
-                            slots[slot].setCoordinate(Gps::parse(lc.getData()));
-                            sendMetaDataForSlot(slot);
-                            break;
-                        default:
-                            break;
+                enum Field { LAT, LON, SOURCE, SYNC, ALIAS, TARGET, TYPE, N_FIELDS };          // wire (= key) order
+                struct Call {
+                    FieldRecord<N_FIELDS> fields { { { "lat", "lon", "source", "sync", "talkeralias", "target", "type" } } };
+                    TalkerAliasCollector alias;
+                    void endCall() { for (Field f : { TYPE, SOURCE, TARGET, ALIAS, LAT, LON }) fields.put(f, std::string()); }   // Slot::softReset
+                    void lose() { endCall(); fields.put(SYNC, std::string()); alias.reset(); }                               // Slot::reset
+                };
+                static std::string number(uint32_t v) { return v ? std::to_string(v) : std::string(); }      // 0 = not known
+                void linkControl(Call& call, Lc lc) {
+                    const unsigned op = lc.getOpCode();
+                    if (op == LC_OPCODE_GROUP || op == LC_OPCODE_UNIT_TO_UNIT) {
+                        call.fields.put(TYPE, op == LC_OPCODE_GROUP ? "group" : "direct");
+                        call.fields.put(TARGET, number(lc.getTarget()));
+                        call.fields.put(SOURCE, number(lc.getSource()));
+                    } else if (op >= LC_TALKER_ALIAS_HDR && op <= LC_TALKER_ALIAS_BLK3) {
+                        call.alias.setBlock((int) (op - LC_TALKER_ALIAS_HDR), lc.getData());
+                        if (call.alias.isComplete()) {
+                            std::string text = call.alias.getContents();
+                            text.erase(text.find_last_not_of('\0') + 1);           // padding NULs (dmr_phase.cpp:325-327)
+                            call.fields.put(ALIAS, text);
+                        }
+                    } else if (op == LC_GPS_INFO) {
+                        std::unique_ptr<Coordinate> c(Gps::parse(lc.getData()));
+                        call.fields.put(LAT, std::to_string(c->lat));
+                        call.fields.put(LON, std::to_string(c->lon));
                     }
                 }
-                void sendMetaDataForSlot(int i) {               // dmr_meta.cpp:157-170
-                    if (!slots[i].isDirty()) return;
-                    auto metadata = Digiham::MetaCollector::collect();
-                    metadata["slot"] = std::to_string(i);
-                    auto slotMetadata = slots[i].collect();
-                    metadata.insert(slotMetadata.begin(), slotMetadata.end());
-                    Digiham::MetaCollector::sendMetaData(metadata);
-                    slots[i].setClean();
+                void publish(int s) {                          // one line for this slot if anything changed (dmr_meta.cpp:157-170)
+                    if (!calls[s].fields.takeChanged()) return;
+                    MetaMap m = collect();
+                    m["slot"] = std::to_string(s);
+                    calls[s].fields.addTo(m);
+                    sendMetaData(std::move(m));
                 }
-                Slot slots[2];
-                TalkerAliasCollector aliases[2];
+                Call calls[2];
         };
 
     }

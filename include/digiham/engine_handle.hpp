@@ -10,8 +10,11 @@
 namespace Digiham {
     namespace Amd {
 
+        // every ABI failure is an exception -- DH_ECAPACITY too: a read that reports it has copied NOTHING and only
+        // says how much room it wanted, so carrying on would hand stale bytes downstream.  The operator classes size
+        // their pushes so that it cannot happen.
         inline void check(int rc, const char* what) {
-            if (rc != DH_OK && rc != DH_ECAPACITY) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + dh_last_error());
+            if (rc != DH_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + dh_last_error());
         }
 
         class Engine {

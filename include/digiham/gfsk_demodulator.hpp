@@ -22,15 +22,17 @@ namespace Digiham {
                 bool canProcess() override {
                     std::lock_guard<std::mutex> lock(processMutex);
                     // +1 for variance calculation "jumps" (gfsk_demodulator.cpp:18-22)
-                    return reader->available() > samplesPerSymbol + 1 && writer->writeable() > 0;
+                    return reader->available() > samplesPerSymbol + 1 && writer->writeable() >= minRoom;
                 }
                 void process() override {
                     std::lock_guard<std::mutex> lock(processMutex);
                     if (!engine) engine.reset(new Amd::Engine(DH_RRC_NONE, levels, samplesPerSymbol, DH_PROTO_NONE, invert ? DH_FLAG_FSK_INVERT : 0, chunk));
-                    // never produce more symbols than the writer can take: a symbol needs at least sps - 1 samples
+                    // never produce more symbols than the writer can take: a symbol needs at least sps - 1 samples, and the
+                    // engine may still hold up to sps + 1 samples of the previous call: n samples give at most
+                    // (n + sps + 1) / (sps - 1) + 1 <= n / (sps - 1) + 3 symbols
                     size_t n = reader->available();
                     size_t room = writer->writeable();
-                    size_t cap = room * (samplesPerSymbol - 1);
+                    size_t cap = (room - 3) * (samplesPerSymbol - 1);
                     if (n > cap) n = cap;
                     if (n > chunk) n = chunk;
                     if (n == 0) return;
@@ -44,6 +46,7 @@ namespace Digiham {
                 SlicerBase(int levels, unsigned int samplesPerSymbol, bool invert): levels(levels), samplesPerSymbol(samplesPerSymbol), invert(invert) {}
             private:
                 static constexpr size_t chunk = 65536;
+                static constexpr size_t minRoom = 4;
                 int levels;
                 unsigned int samplesPerSymbol;
                 bool invert;

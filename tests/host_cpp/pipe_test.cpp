@@ -69,17 +69,34 @@ int main(int argc, char** argv) {
         MemReader<unsigned char> sin; sin.data.assign(syms.data.begin(), syms.data.begin() + syms.pos);
         MemWriter<unsigned char> out(syms.pos + (1 << 16));
         std::vector<dh_event> events;
+        // metadata through a PipelineMetaWriter (include/meta.hpp:42-46): the decoder's lines arrive in a Csdr::Writer the
+        // way pycsdr / OpenWebRX consume them; a second, tiny writer shows that a line that does not fit is dropped whole
+        auto* pipeMeta = new Digiham::PipelineMetaWriter(new Digiham::StringSerializer());
+        MemWriter<unsigned char> metaOut(1 << 16);
+        pipeMeta->setWriter(&metaOut);
         if (proto == "dmr") {
             Digiham::Dmr::Decoder dec;
             dec.setEventCallback([&](const dh_event& e) { events.push_back(e); });
+            dec.setMetaWriter(pipeMeta);
             run(dec, sin, out, chunk / 4 + 1);
         } else {
             Digiham::Ysf::Decoder dec;
             dec.setEventCallback([&](const dh_event& e) { events.push_back(e); });
+            dec.setMetaWriter(pipeMeta);
             run(dec, sin, out, chunk / 4 + 1);
         }
         dump(prefix + ".out", out.data.data(), out.pos);
         dump(prefix + ".events", events.data(), events.size());
+        dump(prefix + ".meta", metaOut.data.data(), metaOut.pos);
+        {
+            Digiham::PipelineMetaWriter small(new Digiham::StringSerializer());
+            MemWriter<unsigned char> tiny(16);
+            small.sendMetaData({ { "protocol", "DMR" } });                                   // no writer attached yet: dropped
+            small.setWriter(&tiny);
+            small.sendMetaData({ { "protocol", "DMR" }, { "slot", "0" }, { "sync", "voice" } });   // 31 bytes > 16: dropped whole
+            small.sendMetaData({ { "a", "b" } });                                             // "a:b\n" fits
+            dump(prefix + ".smallmeta", tiny.data.data(), tiny.pos);
+        }
 
         // digital voice filter on a synthetic s16 ramp of the same length class
         MemReader<short> vin; vin.data.resize(8000);

@@ -232,3 +232,81 @@ def test_cli_tools_fail_loudly_without_a_device():
     if not has_gpu:
         r = subprocess.run([os.path.join(ROOT, "cli", "bin", "rrc_filter")], input=np.zeros(64, np.float32).tobytes(), capture_output=True)
         assert r.returncode != 0 and b"rrc_filter:" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Metadata lines from ENGINE events (CPU wave emulation / -m gpu: libdigiham_amd.so): a DMR call whose embedded signalling
+# carries a talker alias and a GPS position, a YSF call whose data frames carry a GPS position.  What the lines must say
+# comes from the REFERENCE's own classes (tests/golden/elements_ref.npz: TalkerAliasCollector, Dmr::Gps, Ysf::Gps).
+def _dmr_call_with_embedded(rng, lcs, cc=1, dst=1234, src=5678901):
+    """bursts of one voice call on slot 0 (idle bursts on slot 1): LC header, one superframe per entry of `lcs` whose
+    embedded signalling carries that 9-byte LC, terminator"""
+    head = synth.dmr_lc(0, 0, 0, dst, src)
+    bursts = [synth.dmr_data_burst(0, cc, 1, head + bytes(3), "bs_data", rng)]
+    for lc9 in lcs:
+        frags = synth.dmr_embedded_lc_fragments(lc9)
+        for f in range(6):
+            mid = synth.DMR_SYNC["bs_voice"] if f == 0 else synth.dmr_emb_mid(cc, [1, 3, 3, 2][f - 1], frags[f - 1]) if f <= 4 \
+                else synth.dmr_emb_mid(cc, 0, [0] * 16)
+            bursts.append(synth.dmr_voice_burst(0, list(rng.integers(0, 4, 108)), mid, rng))
+    bursts.append(synth.dmr_data_burst(0, cc, 2, head + bytes(3), "bs_data", rng))
+    out = list(rng.integers(0, 4, 41))
+    for b in bursts:
+        out += b + synth.dmr_idle_burst(1, cc, rng)
+    return np.array(out + [0] * 200, np.uint8)
+
+
+def _lines_from_engine(ctx, tmp_path, proto, syms):
+    eng = api.Engine(1, len(syms), rrc="none", demod="none", proto=proto, ctx=ctx)
+    batches = []
+    for lo in range(0, len(syms), 5000):                        # several decoder calls, as a pipe would deliver them
+        part = np.ascontiguousarray(syms[None, lo:lo + 5000])
+        eng.push_symbols(part, np.array([part.shape[1]], np.uint32))
+        e, ec = eng.events()
+        batches.append([e[0, i:i + 1] for i in range(ec[0])])
+    eng.close()
+    exe = _meta_test(tmp_path)
+    return subprocess.run([exe, proto], input=_batches(batches), capture_output=True, check=True).stdout.split(b"\n")
+
+
+def test_dmr_talker_alias_and_gps_lines_from_engine_events(ctx, tmp_path):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "elements_ref.npz"))
+    # a golden talker alias vector: 8-bit format, all four blocks in order, complete, printable
+    pick = [i for i in range(len(g["ta_len"])) if g["ta_blocks"][i, 0] >> 6 == 1 and tuple(g["ta_order"][i]) == (0, 1, 2, 3)
+            and g["ta_complete"][i] & 8 and g["ta_len"][i] >= 20 and 0 not in g["ta_blocks"][i, 1:]][0]
+    blocks = g["ta_blocks"][pick]
+    alias = bytes(g["ta_text"][pick, :g["ta_len"][pick]])       # bytes: the reference cuts at a byte count, possibly inside a character
+    k = 77
+    gps_bytes, (lat, lon) = g["dmr_gps_in"][k], g["dmr_gps_out"][k]
+    group = synth.dmr_lc(0, 0, 0, 1234, 5678901)
+    lcs = [group] + [bytes([4 + b, 0]) + bytes(blocks[7 * b:7 * b + 7]) for b in range(4)] + [bytes([8, 0]) + bytes(gps_bytes), group]
+    lines = _lines_from_engine(ctx, tmp_path, "dmr", _dmr_call_with_embedded(np.random.default_rng(3), lcs))
+    slot0 = [l for l in lines if b";slot:0" in l]
+    assert b"protocol:DMR;slot:0;source:5678901;sync:voice;target:1234;type:group" in slot0
+    with_alias = b"protocol:DMR;slot:0;source:5678901;sync:voice;talkeralias:" + alias + b";target:1234;type:group"
+    assert with_alias in slot0, slot0
+    pos = ("lat:%f;lon:%f;" % (lat, lon)).encode()
+    assert pos + with_alias in slot0, slot0
+    assert slot0.index(with_alias) < slot0.index(pos + with_alias)
+    assert slot0[-1] in (b"protocol:DMR;slot:0;sync:data", b"protocol:DMR;slot:0")      # the terminator ends the call
+
+
+def test_ysf_gps_lines_from_engine_events(ctx, tmp_path):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "elements_ref.npz"))
+    k = int(np.nonzero(g["ysf_gps_ok"])[0][5])
+    lat, lon = g["ysf_gps_out"][k]
+    dt = bytearray(20)
+    dt[1:4] = bytes([0x22, 0x62, 0x5F])                                   # COMMAND_SHORT_GPS (data.hpp:8)
+    dt[4] = 0x28
+    dt[5:14] = bytes(g["ysf_gps_in"][k])
+    dt[18] = 0x03
+    dt[19] = sum(dt[:19]) & 0xFF
+    rng = np.random.default_rng(4)
+    dch = {0: b"CQCQCQ    ", 1: b"DL1ABC    ", 2: b"DB0XYZ    ", 3: b"DB0XYZ    ", 6: bytes(dt[:10]), 7: bytes(dt[10:])}
+    out = list(rng.integers(0, 4, 53)) + synth.ysf_frame(rng, 0, 2)
+    for fn in range(8):
+        out += synth.ysf_frame(rng, 1, 2, fn, dch=dch.get(fn))
+    out += synth.ysf_frame(rng, 2, 2) + [0] * 600
+    lines = _lines_from_engine(ctx, tmp_path, "ysf", np.array(out, np.uint8))
+    assert any((";lat:%f;lon:%f;mode:DN;protocol:YSF" % (lat, lon)).encode() in b";" + l for l in lines), lines
+    assert any(b"source:DL1ABC" in l and b"target:CQCQCQ" in l for l in lines)

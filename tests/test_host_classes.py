@@ -40,7 +40,8 @@ def run_pipe(exe, proto, x, tmp_path, chunk, gpu):
     subprocess.run([exe, proto, str(inp), prefix, str(chunk)], check=True, env=env)
     rd = lambda suffix, dt: np.fromfile(prefix + suffix, dt)
     return {"filtered": rd(".filtered", np.float32), "syms": rd(".syms", np.uint8), "out": rd(".out", np.uint8),
-            "events": rd(".events", api.EVENT_DTYPE), "dvin": rd(".dvin", np.int16), "dvout": rd(".dvout", np.int16)}
+            "events": rd(".events", api.EVENT_DTYPE), "dvin": rd(".dvin", np.int16), "dvout": rd(".dvout", np.int16),
+            "meta": rd(".meta", np.uint8).tobytes(), "smallmeta": rd(".smallmeta", np.uint8).tobytes()}
 
 
 @pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
@@ -62,6 +63,17 @@ def test_module_classes_match_oracle(oracle, tmp_path, proto, gpu):
         assert (got["out"] == o).all()
         assert got["events"].tobytes() == ev.tobytes()
         assert (got["dvout"] == oracle.DvFilter().process(got["dvin"])).all()
+        # PipelineMetaWriter: whole `k:v;k:v\n` lines of this protocol in the pipeline buffer; too-long lines dropped whole
+        lines = got["meta"].split(b"\n")
+        assert lines[-1] == b"" and len(lines) > 2
+        assert all((b"protocol:%s" % proto.upper().encode()) in l.split(b";") for l in lines[:-1])
+        if proto == "dmr":
+            lcs = ev[ev["type"] == 4]
+            f = api.parse_lc(bytes(lcs[0]["payload"][:9]))
+            assert any(b"source:%d;" % f["source"] in l and b"target:%d;type:group" % f["target"] in l for l in lines)
+        else:
+            assert b"mode:DN;protocol:YSF" in got["meta"]
+        assert got["smallmeta"] == b"a:b\n"
 
 
 def test_rrc_rejects_foreign_tap_tables(tmp_path):
