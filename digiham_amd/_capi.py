@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdigiham_amd.so")
 
 DH_OK, DH_EINVAL, DH_ENOMEM, DH_EDEVICE, DH_ENODEV, DH_ECAPACITY = 0, -1, -2, -3, -4, -5
-RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2}
+RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2, "custom": 3}
 DEMOD = {"none": 0, None: 0, "fsk": 2, "fsk2": 2, "gfsk": 4, "gfsk4": 4}
 PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3, "pocsag": 4, "dstar": 5}
 FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED_TIMING, FLAG_SPLIT_STAGES = 1, 2, 4, 8, 16, 32
@@ -20,7 +20,8 @@ FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED
 class EngineConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("n_channels", C.c_uint32),
                 ("max_samples", C.c_uint32), ("rrc", C.c_int32), ("demod", C.c_int32), ("sps", C.c_uint32),
-                ("proto", C.c_int32), ("flags", C.c_uint32), ("slot_filter", C.c_uint32), ("stream", C.c_void_p)]
+                ("proto", C.c_int32), ("flags", C.c_uint32), ("slot_filter", C.c_uint32), ("stream", C.c_void_p),
+                ("rrc_taps", C.POINTER(C.c_float)), ("rrc_nzeros", C.c_uint32), ("rrc_gain", C.c_double)]
 
 
 class DhError(RuntimeError):

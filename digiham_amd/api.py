@@ -1,8 +1,9 @@
 """Python front-end over the C ABI (include/digiham_amd.h).
 
 Device memory and streams come from PyTorch-ROCm (plumbing only): inputs are
-``torch`` CUDA tensors, the engine enqueues its HIP kernels on torch's current
-stream, outputs are fetched into numpy arrays on request.  All compute happens
+``torch`` CUDA tensors, an engine enqueues its HIP kernels on the stream that was
+torch's current stream WHEN THE ENGINE WAS CREATED (inputs produced on another stream
+must be ordered against it by the caller), outputs are fetched into numpy arrays on request.  All compute happens
 in ``libdigiham_amd.so``; nothing here computes or falls back.
 """
 import ctypes as C
@@ -154,7 +155,10 @@ class Engine:
     """B independent `rrc_filter | gfsk_demodulator | dmr_decoder` pipes with state resident in HBM."""
 
     def __init__(self, n_channels, max_samples, rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=False,
-                 keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False, split_stages=False):
+                 keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False, split_stages=False,
+                 taps=None, gain=None):
+        """rrc = "custom" takes the caller's coefficient table: `taps` (nZeros + 1 floats, any shape) and `gain`, as
+        Digiham::RrcFilter::RrcFilter(nZeros, gain, coeffs[]) does (include/rrc_filter.hpp:12)."""
         self.ctx = ctx if ctx is not None else Context(device=device)
         lib, mem = self.ctx.lib, self.ctx.mem
         flags = (_capi.FLAG_FAST_FIR if fast_fir else 0) | (_capi.FLAG_KEEP_FILTERED if keep_filtered else 0) | \
@@ -163,12 +167,16 @@ class Engine:
         cfg = _capi.EngineConfig(C.sizeof(_capi.EngineConfig), getattr(mem, "index", 0), n_channels, max_samples,
                                  _capi.RRC[rrc], _capi.DEMOD[demod], sps, _capi.PROTO[proto], flags, slot_filter,
                                  mem.stream())
+        if rrc == "custom":
+            t = np.ascontiguousarray(taps, np.float32).ravel()
+            cfg.rrc_taps = t.ctypes.data_as(C.POINTER(C.c_float))         # copied by dh_engine_create
+            cfg.rrc_nzeros, cfg.rrc_gain = len(t) - 1, float(gain)
         h = C.c_void_p()
         _check(lib.dh_engine_create(C.byref(cfg), C.byref(h)), "dh_engine_create", lib)
         self._h = h
         self.B, self.max_samples = n_channels, max_samples
         self.has_demod, self.has_proto = _capi.DEMOD[demod] != 0, _capi.PROTO[proto] != 0
-        self.keep_filtered = keep_filtered and _capi.RRC[rrc] != 0
+        self.keep_filtered = (keep_filtered or rrc == "custom") and _capi.RRC[rrc] != 0
         self._keep = None
 
     def close(self):
@@ -189,8 +197,17 @@ class Engine:
         mem = self.ctx.mem
         if not mem.is_device_array(x):
             x = mem.from_numpy(np.ascontiguousarray(x, np.float32).reshape(self.B, -1))
-        stride = x.shape[1]
-        n = stride if n is None else n
+        elif getattr(mem, "torch", None) is not None and mem.torch.is_tensor(x):
+            # the library reads raw float32 rows: anything else would be silent garbage or an out-of-bounds read
+            if x.dtype != mem.torch.float32 or x.dim() != 2 or x.shape[0] != self.B or (x.shape[1] > 1 and x.stride(1) != 1):
+                raise ValueError("Engine.push: need a float32 [%d][n] device array with contiguous rows, got %s %s strides %s"
+                                 % (self.B, x.dtype, tuple(x.shape), tuple(x.stride())))
+            if x.device.index != mem.index:
+                raise ValueError("Engine.push: the array lives on cuda:%s, the engine on cuda:%s" % (x.device.index, mem.index))
+        stride = x.stride(0) if callable(getattr(x, "stride", None)) else x.strides[0] // x.itemsize
+        if x.shape[0] == 1:
+            stride = x.shape[1]                 # a single row: its "row stride" is arbitrary (numpy reports 0 for a new axis)
+        n = x.shape[1] if n is None else n
         self._keep = x          # the launch is asynchronous: keep the input alive
         _check(self.ctx.lib.dh_engine_push(self._h, mem.ptr(x), stride, n), "dh_engine_push", self.ctx.lib)
 

@@ -81,24 +81,30 @@ int dh_engine_create(const dh_engine_config* cfg, dh_engine** out) {
     dh_engine* e = new (std::nothrow) dh_engine;
     if (!e) return DH_ENOMEM;
     int rc = e->impl.be.open(cfg->device, cfg->stream);
-    if (rc == DH_OK) rc = e->impl.init(*cfg);
-    if (rc != DH_OK) { e->impl.destroy(); delete e; return rc; }
+    if (rc == DH_OK) { auto on_device = e->impl.be.scope(); (void) on_device; rc = e->impl.init(*cfg); if (rc != DH_OK) e->impl.destroy(); }
+    if (rc != DH_OK) { delete e; return rc; }
     *out = e;
     return DH_OK;
 }
 
 void dh_engine_destroy(dh_engine* e) {
     if (!e) return;
-    e->impl.be.sync();
-    e->impl.destroy();
+    {
+        auto on_device = e->impl.be.scope(); (void) on_device;
+        e->impl.be.sync();
+        e->impl.be.close();
+        e->impl.destroy();
+    }
     delete e;
 }
 
-int dh_engine_reset(dh_engine* e) { return e ? e->impl.reset() : DH_EINVAL; }
-int dh_engine_set_slot_filter(dh_engine* e, uint32_t f) { return e ? e->impl.set_slot_filter(f) : DH_EINVAL; }
-int dh_engine_push(dh_engine* e, const float* d, size_t stride, size_t n) { return e ? e->impl.push(d, stride, n) : DH_EINVAL; }
-int dh_engine_push_host(dh_engine* e, const float* h, size_t stride, size_t n) { return e ? e->impl.push_host(h, stride, n) : DH_EINVAL; }
-int dh_engine_push_symbols(dh_engine* e, const uint8_t* d, size_t stride, const uint32_t* cnt) { return e ? e->impl.push_symbols(d, stride, cnt) : DH_EINVAL; }
+// every entry below runs on the engine's device whatever the calling thread's current device is (HipBackend::Scope)
+#define DH_ON_DEVICE(e) auto dh_on_device_ = (e)->impl.be.scope(); (void) dh_on_device_
+int dh_engine_reset(dh_engine* e) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.reset(); }
+int dh_engine_set_slot_filter(dh_engine* e, uint32_t f) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.set_slot_filter(f); }
+int dh_engine_push(dh_engine* e, const float* d, size_t stride, size_t n) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.push(d, stride, n); }
+int dh_engine_push_host(dh_engine* e, const float* h, size_t stride, size_t n) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.push_host(h, stride, n); }
+int dh_engine_push_symbols(dh_engine* e, const uint8_t* d, size_t stride, const uint32_t* cnt) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.push_symbols(d, stride, cnt); }
 
 int dh_engine_filtered(dh_engine* e, const float** d, size_t* stride) {
     if (!e || !e->impl.filtered) return DH_EINVAL;
@@ -129,39 +135,47 @@ int dh_engine_events(dh_engine* e, const dh_event** d, size_t* stride, const uin
 }
 int dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out) {
     if (!e) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     return e->impl.debug_header(word, h_out);
 }
 int dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered) {
     if (!e) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     return e->impl.timing_stats(h_blocks, h_ordered);
 }
 int dh_engine_read_symbols(dh_engine* e, uint32_t ch, uint8_t* h, size_t* n) {
     if (!e || !e->impl.syms) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     return e->impl.read_row(e->impl.syms, e->impl.L.sym_stride, ch, e->impl.sym_count, 1, h, n);
 }
 int dh_engine_read_frames(dh_engine* e, uint32_t ch, uint8_t* h, size_t* n) {
     if (!e || !e->impl.frames) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     return e->impl.read_row(e->impl.frames, e->impl.L.out_cap, ch, e->impl.frame_count, 1, h, n);
 }
 int dh_engine_read_events(dh_engine* e, uint32_t ch, dh_event* h, size_t* n) {
     if (!e || !e->impl.events) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     return e->impl.read_row(e->impl.events, sizeof(dh_event) * e->impl.L.ev_cap, ch, e->impl.ev_count, sizeof(dh_event), h, n);
 }
 int dh_engine_read_filtered(dh_engine* e, uint32_t ch, float* h, size_t* n) {
     if (!e || !e->impl.filtered || !n || ch >= e->impl.L.B) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     const size_t cnt = e->impl.last_n, cap = *n;
     *n = cnt;
     if (cnt > cap) return DH_ECAPACITY;
     if (cnt && h && e->impl.be.download(h, e->impl.filtered + (size_t) ch * e->impl.L.max_samples, sizeof(float) * cnt)) return DH_EDEVICE;
     return DH_OK;
 }
-int dh_engine_timing_enable(dh_engine* e, uint32_t max_pushes) { return e ? e->impl.be.timing_enable(max_pushes) : DH_EINVAL; }
+int dh_engine_timing_enable(dh_engine* e, uint32_t max_pushes) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.be.timing_enable(max_pushes); }
 int dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float* decoder_ms, uint32_t* n) {
     if (!e || !n) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     return e->impl.be.timing_read(rrc_ms, slicer_ms, decoder_ms, n);
 }
 int dh_engine_sync(dh_engine* e) {
     if (!e) return DH_EINVAL;
+    DH_ON_DEVICE(e);
     if (e->impl.be.sync()) return DH_EDEVICE;
     return e->impl.check_overflow();
 }

@@ -88,6 +88,12 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_TILE_LB)) voi
         dh_rrc_tile<NZ, FAST>(R, blockIdx.y, t, S);
 }
 
+__global__ __launch_bounds__(DH_WAVE) void k_rrc_generic(const DhRrcGenParams G) {
+    __shared__ float win[DH_GEN_WINDOW];
+    __shared__ float taps[DH_MAX_NZ + 1];
+    dh_rrc_generic_tile(G, blockIdx.y, blockIdx.x, win, taps);
+}
+
 __global__ __launch_bounds__(DH_WAVE) void k_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz) {
     __shared__ float sh[DH_MAX_NZ];
     dh_rrc_hist_channel(hist, in, in_stride, n, nz, blockIdx.x, sh);
@@ -222,17 +228,32 @@ struct HipBackend {
     int device = 0;
     hipStream_t stream = nullptr;
 
+    // Every ABI entry that allocates, enqueues or copies runs inside a Scope: the calling thread's current device becomes
+    // the engine's for the duration of the call and is put back afterwards.  Without it a thread whose current device is
+    // another GPU (a new thread starts on device 0; torch may have selected any) would launch on that device's NULL
+    // stream with this engine's pointers -- and the engine would leave the caller's (torch's) device changed.
+    struct Scope {
+        int prev = -1; bool switched = false;
+        explicit Scope(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess; }
+        ~Scope() { if (switched) (void) hipSetDevice(prev); }
+        Scope(const Scope&) = delete;
+        Scope& operator=(const Scope&) = delete;
+    };
+    Scope scope() const { return Scope(device); }
+
     int open(int dev, void* s) {
         int count = 0;
         if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) return DH_ENODEV;
         if (dev < 0 || dev >= count) return DH_EINVAL;
         device = dev; stream = (hipStream_t) s;
-        HIP_TRY(hipSetDevice(device));
         return DH_OK;
+    }
+    void close() {                                   // engine teardown: the timing events go with it
+        for (hipEvent_t e : ev) if (e) (void) hipEventDestroy(e);
+        ev.clear(); ev_cap = ev_n = 0;
     }
     void* alloc(size_t bytes) {
         void* p = nullptr;
-        if (hipSetDevice(device) != hipSuccess) return nullptr;
         if (hip_fail(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc")) return nullptr;
         return p;
     }
@@ -262,10 +283,10 @@ struct HipBackend {
     std::vector<hipEvent_t> ev;
     uint32_t ev_cap = 0, ev_n = 0;
     int timing_enable(uint32_t max_pushes) {
-        for (hipEvent_t e : ev) (void) hipEventDestroy(e);
-        ev.clear(); ev_cap = max_pushes; ev_n = 0;
-        ev.resize((size_t) max_pushes * 4);
-        for (auto& e : ev) if (hip_fail(hipEventCreate(&e), "hipEventCreate")) return DH_EDEVICE;
+        close();
+        ev.assign((size_t) max_pushes * 4, nullptr);
+        for (auto& e : ev) if (hip_fail(hipEventCreate(&e), "hipEventCreate")) { close(); return DH_EDEVICE; }   // all or nothing
+        ev_cap = max_pushes;
         return DH_OK;
     }
     void timing_mark(int k) { if (ev_n < ev_cap) (void) hipEventRecord(ev[(size_t) ev_n * 4 + k], stream); }
@@ -335,6 +356,10 @@ struct HipBackend {
         if (nz == 80) return fast ? go_rrc_tiles<80, true>(R) : go_rrc_tiles<80, false>(R);
         if (nz == 160) return fast ? go_rrc_tiles<160, true>(R) : go_rrc_tiles<160, false>(R);
         return -1;
+    }
+    int launch_rrc_generic(const DhRrcGenParams& G) {
+        hipLaunchKernelGGL(k_rrc_generic, dim3((G.n + DH_FTILE - 1) / DH_FTILE, G.n_channels), dim3(DH_WAVE), 0, stream, G);
+        return launched("k_rrc_generic");
     }
     int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {
         hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, stream, hist, in, in_stride, n, nz);

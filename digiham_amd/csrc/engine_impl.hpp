@@ -8,7 +8,7 @@
 //   dsp_state     [B][state_words] u32 slicer rings + timing state + raw tail (dsp_core.hpp)
 //   syms          [B][sym_stride] u8   this push's symbols (dibits)
 //   sym_carry     [B][512] u8          symbols the decoder left unread (< one frame)
-//   dec_state     [B][32] u32          decoder phase state (decoder_core.hpp)
+//   dec_state     [B][64] u32          decoder phase state (DH_DEC_STATE_WORDS, decoder_core.hpp)
 //   frames        [B][out_cap] u8      decoder output bytes of this push
 //   events        [B][ev_cap] dh_event decoder events of this push
 //   filtered      [B][max_samples] f32 only with DH_FLAG_KEEP_FILTERED (unfused path)
@@ -38,20 +38,24 @@ struct Layout {
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 inline int make_layout(const dh_engine_config& c, Layout& L) {
-    if (c.struct_size != sizeof(dh_engine_config)) return DH_EINVAL;
+    if (c.struct_size != sizeof(dh_engine_config) && c.struct_size != DH_ENGINE_CONFIG_V1_SIZE) return DH_EINVAL;
     if (c.n_channels == 0 || c.max_samples == 0) return DH_EINVAL;
-    if (c.rrc < DH_RRC_NONE || c.rrc > DH_RRC_NARROW) return DH_EINVAL;
+    if (c.rrc < DH_RRC_NONE || c.rrc > DH_RRC_CUSTOM) return DH_EINVAL;
+    if (c.rrc == DH_RRC_CUSTOM) {
+        if (c.struct_size != sizeof(dh_engine_config) || !c.rrc_taps || c.rrc_nzeros < 1 || c.rrc_nzeros > DH_MAX_NZ) return DH_EINVAL;
+        if (!(c.rrc_gain == c.rrc_gain) || c.rrc_gain == 0.0 || (c.flags & DH_FLAG_FAST_FIR)) return DH_EINVAL;      // exact arithmetic only
+    }
     if (c.demod != DH_DEMOD_NONE && c.demod != DH_DEMOD_FSK2 && c.demod != DH_DEMOD_GFSK4) return DH_EINVAL;
     if (c.proto < DH_PROTO_NONE || c.proto > DH_PROTO_DSTAR) return DH_EINVAL;
     if (c.demod != DH_DEMOD_NONE && (c.sps < 3 || c.sps > DH_MAX_SPS)) return DH_EINVAL;
     if (c.demod == DH_DEMOD_NONE && c.rrc == DH_RRC_NONE && c.proto == DH_PROTO_NONE) return DH_EINVAL;
     L.B = c.n_channels; L.max_samples = c.max_samples; L.sps = c.demod ? c.sps : 1;
     L.rrc = c.rrc; L.demod = c.demod; L.proto = c.proto; L.flags = c.flags;
-    L.nz = c.rrc == DH_RRC_WIDE ? DH_RRC_WIDE_NZEROS : c.rrc == DH_RRC_NARROW ? DH_RRC_NARROW_NZEROS : 0;
+    L.nz = c.rrc == DH_RRC_WIDE ? DH_RRC_WIDE_NZEROS : c.rrc == DH_RRC_NARROW ? DH_RRC_NARROW_NZEROS : c.rrc == DH_RRC_CUSTOM ? c.rrc_nzeros : 0;
     // GfskDemodulator ctor: lowestEval = round(sps/3), highestEval = round(2*sps/3)  (gfsk_demodulator.cpp:8-9)
     L.lo = (uint32_t) (int) __builtin_roundf((float) L.sps / 3);
     L.hi = (uint32_t) (int) __builtin_roundf((float) L.sps * 2 / 3);
-    L.fused = L.rrc != DH_RRC_NONE && L.demod != DH_DEMOD_NONE && !(L.flags & DH_FLAG_KEEP_FILTERED);
+    L.fused = L.rrc != DH_RRC_NONE && L.rrc != DH_RRC_CUSTOM && L.demod != DH_DEMOD_NONE && !(L.flags & DH_FLAG_KEEP_FILTERED);
     // a symbol consumes at least sps-1 samples
     L.sym_cap = L.demod ? (L.max_samples + DH_TAIL_MAX) / (L.sps - 1) + 4 : L.max_samples;
     L.sym_stride = round_up(L.sym_cap, 64);
@@ -113,6 +117,7 @@ struct Engine {
     uint32_t* zero_counts = nullptr;
     uint32_t last_n = 0;
     DhDspParams dsp{}; DhRrcParams rrcp{}; DhDecParams dec{};
+    float* custom_taps = nullptr; double custom_gain = 0.0;      // DH_RRC_CUSTOM: device copy of the caller's table
 
     int init(const dh_engine_config& c) {
         int rc = make_layout(c, L);
@@ -144,13 +149,18 @@ struct Engine {
             DH_ALLOC(filtered, float, B * (size_t) L.max_samples);
             DH_ALLOC(rrc_hist, float, B * (size_t) L.nz);
         }
+        if (L.rrc == DH_RRC_CUSTOM) {
+            DH_ALLOC(custom_taps, float, L.nz + 1);
+            custom_gain = c.rrc_gain;
+            if (be.upload(custom_taps, c.rrc_taps, sizeof(float) * (L.nz + 1)) || be.sync()) return DH_EDEVICE;   // the caller's table may go away
+        }
 #undef DH_ALLOC
         return reset();
     }
 
     void destroy() {
         void* ptrs[] = { dsp_state, syms, sym_count, sym_carry, dec_state, frames, frame_count, events, ev_count,
-                         overflow, filtered, rrc_hist, staging, tables };
+                         overflow, filtered, rrc_hist, staging, tables, custom_taps };
         for (void* p : ptrs) if (p) be.free(p);
     }
 
@@ -197,7 +207,14 @@ struct Engine {
         const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;
         bool decoder_done = false;
         be.timing_mark(0);
-        if (L.rrc && !L.fused) {
+        if (L.rrc == DH_RRC_CUSTOM) {
+            DhRrcGenParams G{};
+            G.in = d_in; G.in_stride = stride; G.out = filtered; G.out_stride = L.max_samples; G.hist = rrc_hist; G.taps = custom_taps;
+            G.n = (uint32_t) n; G.n_channels = L.B; G.nz = L.nz; G.gain = custom_gain;
+            if (n) rc |= be.launch_rrc_generic(G);
+            if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, L.nz, L.B);
+            demod_in = filtered; demod_stride = L.max_samples;
+        } else if (L.rrc && !L.fused) {
             rrcp.in = d_in; rrcp.in_stride = stride; rrcp.out = filtered; rrcp.out_stride = L.max_samples;
             rrcp.hist = rrc_hist; rrcp.n = (uint32_t) n; rrcp.n_channels = L.B; rrcp.nz = L.nz; rrcp.fast = fast;
             fill_taps(L.rrc, rrcp.taps, &rrcp.gain); rrcp.rgain = 1.0 / rrcp.gain; rrcp.inv_gain = (float) rrcp.rgain;

@@ -50,6 +50,51 @@ DH_HD void dh_rrc_hist_channel(float* hist, const float* in, size_t in_stride, u
     DH_BARRIER();
 }
 
+// Stand-alone FIR with the caller's coefficient table (DH_RRC_CUSTOM): any shape, 1 <= nz <= 160, exact arithmetic
+// only.  One 1024-output tile of one channel per wavefront; lane l produces outputs l, l + 64, ... (LDS reads of a
+// tap step are then 64 consecutive words, so the window needs no padding) and every tap is an LDS broadcast.
+// A compatibility path -- the reference only ever instantiates its two built-in designs -- not a tuned one.
+struct DhRrcGenParams {
+    const float* in; size_t in_stride;
+    float* out; size_t out_stride;
+    const float* hist;                                  // [B][nz] previous inputs (zeros after reset)
+    const float* taps;                                  // [nz + 1] device copy of the caller's table
+    uint32_t n, n_channels, nz;
+    double gain;
+};
+#define DH_GEN_WINDOW (DH_FTILE + DH_MAX_NZ)
+DH_HD void dh_rrc_generic_tile(const DhRrcGenParams& G, uint32_t ch, uint32_t tile, float* win /* [DH_GEN_WINDOW] */, float* taps /* [DH_MAX_NZ + 1] */) {
+    const float* in = G.in + (size_t) ch * G.in_stride;
+    const float* hist = G.hist + (size_t) ch * G.nz;
+    float* out = G.out + (size_t) ch * G.out_stride;
+    const uint32_t t0 = tile * DH_FTILE, nz = G.nz;
+    const uint32_t cnt = dh_min<uint32_t>(DH_FTILE, G.n - t0);
+    DH_FOR_LANES(lane) {
+        for (uint32_t e = lane; e < cnt + nz; e += DH_WAVE) {       // virtual stream = hist (nz samples) ++ in
+            const uint32_t v = t0 + e;
+            win[e] = v < nz ? hist[v] : in[v - nz];
+        }
+        for (uint32_t i = lane; i <= nz; i += DH_WAVE) taps[i] = G.taps[i];
+    }
+    DH_BARRIER();
+    DH_FOR_LANES(lane) {
+        float acc[DH_FTILE / DH_WAVE];
+        for (int j = 0; j < DH_FTILE / DH_WAVE; j++) acc[j] = 0.0f;
+        for (uint32_t i = 0; i <= nz; i++) {
+            const float c = taps[i];
+            for (int j = 0; j < DH_FTILE / DH_WAVE; j++) {
+                const uint32_t o = (uint32_t) lane + DH_WAVE * (uint32_t) j;
+                if (o < cnt) { const float p = c * win[o + i]; acc[j] = acc[j] + p; }      // rounded product, rounded sum (-ffp-contract=off)
+            }
+        }
+        for (int j = 0; j < DH_FTILE / DH_WAVE; j++) {
+            const uint32_t o = (uint32_t) lane + DH_WAVE * (uint32_t) j;
+            if (o < cnt) out[t0 + o] = dh_div_gain_exact(acc[j], G.gain);
+        }
+    }
+    DH_BARRIER();
+}
+
 // ---- batch FEC: one word per lane --------------------------------------------------------------
 DH_HD void dh_fec_block_item(const DhFecTables& T, int code, void* words, uint8_t* ok, size_t i) {
     bool r = false;

@@ -27,6 +27,15 @@ namespace Digiham {
                     check(dh_engine_create(&cfg, &handle), "dh_engine_create");
                     max = maxSamples;
                 }
+                // a stand-alone FIR with the caller's table (DH_RRC_CUSTOM), filtered output kept
+                Engine(const float* taps, unsigned int nZeros, double gain, unsigned int maxSamples) {
+                    dh_engine_config cfg{};
+                    cfg.struct_size = sizeof(cfg); cfg.device = 0; cfg.n_channels = 1; cfg.max_samples = maxSamples;
+                    cfg.rrc = DH_RRC_CUSTOM; cfg.demod = DH_DEMOD_NONE; cfg.proto = DH_PROTO_NONE; cfg.flags = DH_FLAG_KEEP_FILTERED;
+                    cfg.slot_filter = 3; cfg.rrc_taps = taps; cfg.rrc_nzeros = nZeros; cfg.rrc_gain = gain;
+                    check(dh_engine_create(&cfg, &handle), "dh_engine_create");
+                    max = maxSamples;
+                }
                 ~Engine() { dh_engine_destroy(handle); }
                 Engine(const Engine&) = delete;
                 Engine& operator=(const Engine&) = delete;

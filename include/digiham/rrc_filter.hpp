@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <memory>
+#include <vector>
 
 #include "csdr_compat.hpp"
 #include "engine_handle.hpp"
@@ -14,18 +15,17 @@ namespace Digiham {
 
         class RrcFilter: public Csdr::AnyLengthModule<float, float> {
             public:
-                // The reference takes an arbitrary coefficient table; it only ever builds the two mkshape designs
-                // below (rrc_filter.cpp:38-40, 86-88).  The engine carries exactly those two, so any other table is
-                // rejected instead of being filtered with the wrong taps.
-                RrcFilter(unsigned int nZeros, double gain, const float coeffs[]) {
-                    (void) coeffs;
-                    if (nZeros == 80 && std::fabs(gain - 8.337797030e+00) < 1e-9) kind = DH_RRC_WIDE;
-                    else if (nZeros == 160 && std::fabs(gain - 1.667711971e+01) < 1e-9) kind = DH_RRC_NARROW;
-                    else throw std::invalid_argument("Digiham::RrcFilter: only the wide (81-tap) and narrow (161-tap) designs are available");
+                // Any coefficient table, as in the reference (include/rrc_filter.hpp:12): nZeros + 1 coefficients, applied
+                // oldest sample first, sum / gain.  The reference itself only ever builds the two mkshape designs below
+                // (rrc_filter.cpp:38-40, 86-88), which have their own tuned kernels; a foreign table runs on the engine's
+                // generic FIR (exact arithmetic, up to 161 taps).
+                RrcFilter(unsigned int nZeros, double gain, const float coeffs[]): kind(DH_RRC_CUSTOM), gain(gain), taps(coeffs, coeffs + nZeros + 1) {
+                    if (nZeros < 1 || nZeros > 160) throw std::invalid_argument("Digiham::RrcFilter: 2 to 161 coefficients");
                 }
                 ~RrcFilter() override = default;
                 void process(float* input, float* output, size_t length) override {
-                    if (!engine) engine.reset(new Amd::Engine(kind, DH_DEMOD_NONE, 0, DH_PROTO_NONE, DH_FLAG_KEEP_FILTERED, chunk));
+                    if (!engine) engine.reset(kind == DH_RRC_CUSTOM ? new Amd::Engine(taps.data(), (unsigned int) taps.size() - 1, gain, chunk)
+                                                                   : new Amd::Engine(kind, DH_DEMOD_NONE, 0, DH_PROTO_NONE, DH_FLAG_KEEP_FILTERED, chunk));
                     while (length > 0) {
                         size_t n = length < chunk ? length : chunk;
                         Amd::check(dh_engine_push_host(engine->get(), input, n, n), "dh_engine_push_host");
@@ -39,6 +39,8 @@ namespace Digiham {
             private:
                 static constexpr size_t chunk = 65536;
                 int kind;
+                double gain = 0.0;
+                std::vector<float> taps;
                 std::unique_ptr<Amd::Engine> engine;
         };
 

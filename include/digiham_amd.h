@@ -95,7 +95,8 @@ int dh_whitening(const uint8_t* d_in, uint8_t* d_out, size_t stride, int n_bits,
  * ---------------------------------------------------------------------- */
 typedef struct dh_engine dh_engine;
 
-enum { DH_RRC_NONE = 0, DH_RRC_WIDE = 1, DH_RRC_NARROW = 2 };
+enum { DH_RRC_NONE = 0, DH_RRC_WIDE = 1, DH_RRC_NARROW = 2,
+       DH_RRC_CUSTOM = 3 };   /* the caller's coefficient table: RrcFilter(nZeros, gain, coeffs[]), include/rrc_filter.hpp:12 */
 enum { DH_DEMOD_NONE = 0, DH_DEMOD_FSK2 = 2, DH_DEMOD_GFSK4 = 4 };
 enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3, DH_PROTO_POCSAG = 4, DH_PROTO_DSTAR = 5 };
 
@@ -119,7 +120,16 @@ typedef struct {
     uint32_t flags;
     uint32_t slot_filter;     /* Dmr::Decoder::setSlotFilter initial value (3 = both slots) */
     void*    stream;          /* hipStream_t all work is enqueued on (NULL: default stream) */
+    /* rrc == DH_RRC_CUSTOM only (struct_size must cover these fields): y[n] = (float)((double) sum_i rrc_taps[i] x[n - nZeros + i] / rrc_gain),
+     * products and sums rounded to float one by one in tap order (src/rrc_filter/rrc_filter.cpp:22-34).  The table
+     * (host memory, rrc_nzeros + 1 floats, 1 <= rrc_nzeros <= 160, any shape) is copied at create time.  A custom filter
+     * is never fused into the slicer: the filtered signal is materialised and the demodulator (if any) reads it. */
+    const float* rrc_taps;
+    uint32_t rrc_nzeros;
+    double   rrc_gain;
 } dh_engine_config;
+/* sizeof(dh_engine_config) before the custom-filter fields were added: still accepted as struct_size */
+#define DH_ENGINE_CONFIG_V1_SIZE offsetof(dh_engine_config, rrc_taps)
 
 /* Decoder event: one record per call the reference makes into its MetaCollector,
  * plus the FEC-corrected words feeding it (BPTC LC, slot type, EMB, FICH, DCH). */
@@ -188,7 +198,7 @@ int  dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float*
  * blocks = 100-symbol variance blocks evaluated (gfsk_demodulator.cpp:41-80), ordered = those in which the
  * error-bounded estimate could not separate the phases and the reference's in-order sums decided. Synchronises. */
 int  dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered);
-/* Diagnostic: word `word` (0..15) of every channel's slicer state header, or word `word - 100` (0..31) of its
+/* Diagnostic: word `word` (0..15) of every channel's slicer state header, or word `word - 100` (0..63) of its
  * decoder state, into h_out[n_channels]. Synchronises. */
 int  dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out);
 /* wait for all enqueued work; returns DH_ECAPACITY if any channel overflowed an output buffer */

@@ -64,6 +64,7 @@ void orc_trellis_encode(const uint8_t* bits, int nbits, uint8_t* out);
 /* ------------------------------------------------------------------ dsp.c */
 typedef struct orc_rrc orc_rrc;
 orc_rrc* orc_rrc_new(int narrow);
+orc_rrc* orc_rrc_new_custom(unsigned n_zeros, double gain, const float* coeffs);
 void orc_rrc_free(orc_rrc*);
 void orc_rrc_process(orc_rrc*, const float* in, float* out, size_t n);
 const float* orc_rrc_taps(int narrow, unsigned* n_zeros, double* gain);

@@ -52,6 +52,15 @@ orc_rrc* orc_rrc_new(int narrow) {
     return f;
 }
 
+/* RrcFilter(nZeros, gain, coeffs[]) with any table (include/rrc_filter.hpp:12, rrc_filter.cpp:6-14) */
+orc_rrc* orc_rrc_new_custom(unsigned n_zeros, double gain, const float* coeffs) {
+    if (n_zeros + 1 > DH_RRC_MAX_TAPS) return NULL;
+    orc_rrc* f = (orc_rrc*) calloc(1, sizeof(orc_rrc));
+    f->n_zeros = n_zeros; f->gain = gain;
+    memcpy(f->coeffs, coeffs, sizeof(float) * (n_zeros + 1));
+    return f;
+}
+
 void orc_rrc_free(orc_rrc* f) { free(f); }
 
 /* rrc_filter.cpp:22-34 */

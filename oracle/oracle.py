@@ -56,6 +56,7 @@ def ref():
 def _declare(L):
     vp = C.c_void_p
     L.orc_rrc_new.restype = vp; L.orc_rrc_new.argtypes = [C.c_int]
+    L.orc_rrc_new_custom.restype = vp; L.orc_rrc_new_custom.argtypes = [C.c_uint, C.c_double, vp]
     L.orc_rrc_free.argtypes = [vp]
     L.orc_rrc_process.argtypes = [vp, vp, vp, C.c_size_t]
     L.orc_rrc_taps.restype = C.POINTER(C.c_float)
@@ -203,8 +204,14 @@ def rrc_taps(narrow=False):
 
 
 class Rrc:
-    def __init__(self, narrow=False):
-        self._h = lib().orc_rrc_new(int(narrow))
+    """RrcFilter: the wide / narrow design, or any table (taps = nZeros + 1 coefficients, gain)."""
+
+    def __init__(self, narrow=False, taps=None, gain=None):
+        if taps is None:
+            self._h = lib().orc_rrc_new(int(narrow))
+        else:
+            t = np.ascontiguousarray(taps, np.float32)
+            self._h = lib().orc_rrc_new_custom(len(t) - 1, float(gain), _p(t))
 
     def process(self, x):
         x = np.ascontiguousarray(x, np.float32)

@@ -23,6 +23,9 @@ const DhFecTables& host_tables() {
 }
 
 struct HostBackend {
+    struct Scope {};
+    Scope scope() const { return Scope(); }
+    void close() {}
     int open(int, void*) { return 0; }
     void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
     void free(void* p) { ::free(p); }
@@ -67,6 +70,12 @@ struct HostBackend {
         if (nz == 80) { if (fast) run_rrc_tiles<80, true>(R); else run_rrc_tiles<80, false>(R); }
         else if (nz == 160) { if (fast) run_rrc_tiles<160, true>(R); else run_rrc_tiles<160, false>(R); }
         else return -1;
+        return 0;
+    }
+    int launch_rrc_generic(const DhRrcGenParams& G) {
+        static float win[DH_GEN_WINDOW], taps[DH_MAX_NZ + 1];
+        for (uint32_t ch = 0; ch < G.n_channels; ch++)
+            for (uint32_t t = 0; t * DH_FTILE < G.n; t++) dh_rrc_generic_tile(G, ch, t, win, taps);
         return 0;
     }
     int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {

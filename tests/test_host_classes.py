@@ -76,14 +76,51 @@ def test_module_classes_match_oracle(oracle, tmp_path, proto, gpu):
         assert got["smallmeta"] == b"a:b\n"
 
 
-def test_rrc_rejects_foreign_tap_tables(tmp_path):
+@pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
+def test_rrc_filter_with_a_foreign_tap_table(oracle, tmp_path, gpu):
+    """Digiham::RrcFilter::RrcFilter(nZeros, gain, coeffs[]) (include/rrc_filter.hpp:12) with a table that is neither of
+    the built-in designs: 41 random, non-symmetric coefficients -- bit-exact against the oracle's FIR with the same table."""
+    rng = np.random.default_rng(5)
+    taps = rng.normal(0, 1, 41).astype(np.float32)
+    gain = 3.217
+    x = (rng.normal(0, 1, 20000) * 10.0 ** rng.uniform(-3, 1, 20000)).astype(np.float32)
     src = tmp_path / "t.cpp"
-    src.write_text('#include "digiham/rrc_filter.hpp"\nint main(){ float c[3]={1,2,1}; try { Digiham::RrcFilter::RrcFilter f(2, 4.0, c); } '
-                   'catch (const std::invalid_argument&) { return 0; } return 1; }\n')
-    import hostemu
-    hostemu.build()
-    libdir = os.path.join(ROOT, "tests", "host_harness")
+    src.write_text("""
+#include <cstdio>
+#include <vector>
+#include "digiham/rrc_filter.hpp"
+int main() {
+    std::vector<float> taps(41), x(20000), y(20000);
+    if (fread(taps.data(), 4, 41, stdin) != 41 || fread(x.data(), 4, x.size(), stdin) != x.size()) return 2;
+    try {
+        Digiham::RrcFilter::RrcFilter f(40, %r, taps.data());
+        struct R: Csdr::Reader<float> { std::vector<float>* v; size_t pos = 0, lim = 0; size_t available() override { return lim - pos; }
+            float* getReadPointer() override { return v->data() + pos; } void advance(size_t n) override { pos += n; } } r;
+        struct W: Csdr::Writer<float> { std::vector<float>* v; size_t pos = 0; size_t writeable() override { return v->size() - pos; }
+            float* getWritePointer() override { return v->data() + pos; } void advance(size_t n) override { pos += n; } } w;
+        r.v = &x; w.v = &y;
+        Csdr::Module<float, float>* m = &f;
+        m->setReader(&r); m->setWriter(&w);
+        for (size_t step : { 3000, 17, 5000, 11983 }) { r.lim += step; while (m->canProcess()) m->process(); }
+        fwrite(y.data(), 4, w.pos, stdout);
+    } catch (const std::exception& e) { fprintf(stderr, "%%s\\n", e.what()); return 1; }
+    return 0;
+}
+""" % gain)
+    if gpu:
+        libdir, lib = os.path.join(ROOT, "digiham_amd"), "digiham_amd"
+    else:
+        import hostemu
+        hostemu.build()
+        libdir, lib = os.path.join(ROOT, "tests", "host_harness"), "dh_hostemu"
     exe = str(tmp_path / "t")
-    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, "-L" + libdir, "-ldh_hostemu",
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, "-L" + libdir, "-l" + lib,
                     "-Wl,-rpath," + libdir], check=True)
-    assert subprocess.run([exe]).returncode == 0
+    env = dict(os.environ)
+    if gpu:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], input=taps.tobytes() + x.tobytes(), capture_output=True, check=True, env=env).stdout
+    got = np.frombuffer(out, np.float32)
+    ref = oracle.Rrc(taps=taps, gain=gain).process(x)
+    assert len(got) == len(x) and got.tobytes() == ref.tobytes()
