@@ -59,6 +59,10 @@ WORKLOADS = {
     # examples/pocsag-decoder.sh: fsk_demodulator -i -s 40 | pocsag_decoder
     "pocsag_full": ("pocsag", dict(rrc="none", demod="fsk", sps=40, proto="pocsag", invert=True),
                     "full chain fsk(40, inverted)->pocsag_decoder (POCSAG 1200)"),
+    # the receiver front-end in front of the chain -- int16 I / Q in, polar discriminator + DC
+    # blocker (dh_frontend_s16, own specification) as a pre-stage kernel, then the headline chain
+    "dmr_iq_full": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
+                    "int16 I/Q -> front-end (FM discriminator + DC block) -> rrc(wide)->gfsk(10)->dmr_decoder"),
     # BASELINE configs[4]: half the channels DMR, half YSF, one engine (and one launch per push) each
     "mixed": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr"),
               "half DMR + half YSF channels, full chains (BASELINE configs[4])"),
@@ -186,11 +190,27 @@ class Job:
                     eng = api.Engine(B, T, ctx=ctx, **k)
             else:
                 eng = api.Engine(B, T, ctx=ctx, **k)
-            self.parts.append({"proto": p, "kw": k, "B": B, "T": T, "x": x, "eng": eng, "stream": stream})
+            part = {"proto": p, "kw": k, "B": B, "T": T, "x": x, "eng": eng, "stream": stream}
+            if workload.endswith("_iq_full"):                       # the same audio as FM on a carrier, int16 I / Q, resident in HBM
+                iq = torch.empty((B, 2 * T), dtype=torch.int16, device=device)
+                for c0 in range(0, B, 1024):
+                    ph = torch.cumsum(x[c0:c0 + 1024].double() * (math.pi * 0.35) + math.pi * 0.01, dim=1)
+                    iq[c0:c0 + 1024, 0::2] = (12000.0 * torch.cos(ph)).round().to(torch.int16)
+                    iq[c0:c0 + 1024, 1::2] = (12000.0 * torch.sin(ph)).round().to(torch.int16)
+                    del ph
+                part["iq"] = iq
+                part["fe_state"] = torch.zeros((B, 4), dtype=torch.float32, device=device)
+                part["x"] = torch.empty_like(x)                     # the front-end's output buffer = the engine's input
+                part["ctx"] = ctx
+            self.parts.append(part)
         self.samples_per_step = float(sum(p["B"] * p["T"] for p in self.parts))
 
     def step(self):
         for p in self.parts:
+            if "iq" in p:
+                c, mem = p["ctx"], p["ctx"].mem
+                rc = c.lib.dh_frontend_s16(mem.ptr(p["iq"]), 2 * p["T"], mem.ptr(p["x"]), p["T"], mem.ptr(p["fe_state"]), p["B"], p["T"], 2, 1, mem.stream())
+                assert rc == 0, "dh_frontend_s16 failed"
             p["eng"].push(p["x"])
 
     def sync(self):

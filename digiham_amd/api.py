@@ -127,6 +127,19 @@ class Context:
                "dh_debug_div_gain", self.lib)
         return self.mem.to_numpy(out)
 
+    def frontend(self, x, mode, dcblock=True, state=None):
+        """The receiver front-end (dh_frontend_s16): x int16 [B][n] audio (mode "audio") or [B][2 n] interleaved I / Q ("iq").
+        Returns (float32 device array [B][n] for Engine.push, state) -- pass the state back in to continue the streams."""
+        a = x if self.mem.is_device_array(x) else self.mem.from_numpy(np.ascontiguousarray(x, np.int16))
+        B, w = a.shape
+        n = w if mode == "audio" else w // 2
+        out = self.mem.zeros((B, n), np.float32)
+        if state is None:
+            state = self.mem.zeros((B, 4), np.float32)
+        _check(self.lib.dh_frontend_s16(self.mem.ptr(a), w, self.mem.ptr(out), n, self.mem.ptr(state), B, n,
+                                        1 if mode == "audio" else 2, int(bool(dcblock)), self.mem.stream()), "dh_frontend_s16", self.lib)
+        return out, state
+
     def debug_div_const(self, x, divisor):
         """x (numpy float32, or a device array) / float(divisor) as the slicer kernels compute it; returns what it was given."""
         dev = self.mem.is_device_array(x)

@@ -70,6 +70,12 @@ int dh_debug_div_gain(const float* in, float* out, size_t n, int narrow, void* s
     return dh_be_div_gain(in, out, n, narrow, s);
 }
 
+int dh_frontend_s16(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock, void* s) {
+    if (mode != DH_FE_AUDIO_S16 && mode != DH_FE_IQ_S16) return DH_EINVAL;
+    if (((!in || !out) && n) || !state || out_stride < n || in_stride < n * (mode == DH_FE_IQ_S16 ? 2u : 1u)) return DH_EINVAL;
+    return dh_be_frontend(in, in_stride, out, out_stride, state, B, n, mode, dcblock, s);
+}
+
 int dh_debug_div_const(const float* in, float* out, size_t n, unsigned divisor, void* s) {
     if (((!in || !out) && n) || divisor == 0) return DH_EINVAL;
     return dh_be_div_const(in, out, n, divisor, s);

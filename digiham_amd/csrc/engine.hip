@@ -184,6 +184,11 @@ __global__ void k_dvfilter(const int16_t* in, int16_t* out, float* state, size_t
     if (ch < B) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
 }
 
+__global__ void k_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock) {
+    const size_t ch = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (ch < B) dh_frontend_channel(in + ch * in_stride, out + ch * out_stride, state + ch * DH_FE_STATE_WORDS, n, mode, dcblock);
+}
+
 __global__ void k_div_gain(const float* in, float* out, size_t n, double gain, double rgain) {
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
         out[i] = dh_div_gain(in[i], gain, rgain);
@@ -446,6 +451,13 @@ static int dh_be_whitening(const uint8_t* in, uint8_t* out, size_t stride, int n
 static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t B, size_t stride, size_t n, void* stream) {
     if (!B) return DH_OK;
     hipLaunchKernelGGL(k_dvfilter, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, out, state, B, stride, n);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+
+static int dh_be_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock, void* stream) {
+    if (!B || !n) return DH_OK;
+    hipLaunchKernelGGL(k_frontend, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
     HIP_TRY(hipGetLastError());
     return DH_OK;
 }

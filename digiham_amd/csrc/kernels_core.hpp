@@ -4,6 +4,7 @@
 #pragma once
 
 #include "dsp_core.hpp"
+#include "frontend_core.hpp"
 #include "decoder_core.hpp"
 
 // ---- engine state initialisation: what the reference's constructors leave behind ------------

@@ -219,6 +219,19 @@ int  dh_engine_push_symbols(dh_engine* e, const uint8_t* d_syms, size_t stride, 
 int dh_dvfilter_s16(const int16_t* d_in, int16_t* d_out, float* d_state, size_t n_channels, size_t stride, size_t n, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Receiver front-end, B independent streams, state carried: what examples/dmr-decoder.sh:13-17 runs in front of
+ * rrc_filter -- `rtl_fm -M fm -s 48000 | csdr convert -i s16 -o float | csdr dcblock` (third-party tools, no source in the
+ * reference: the arithmetic is this library's own specification, digiham_amd/csrc/frontend_core.hpp).
+ *   mode DH_FE_AUDIO_S16  d_in [B][in_stride] int16 FM-discriminator audio            -> x = s16 / 32768
+ *   mode DH_FE_IQ_S16     d_in [B][in_stride] int16, interleaved I / Q (2 n values)    -> x = arg(z[n] conj(z[n-1])) / pi
+ *   dcblock != 0          y[n] = (x[n] - x[n-1]) + 0.995 y[n-1]
+ * d_out [B][out_stride] float32 is what dh_engine_push takes.  d_state: [B][4] floats, zero-initialised by the caller.
+ * ---------------------------------------------------------------------- */
+enum { DH_FE_AUDIO_S16 = 1, DH_FE_IQ_S16 = 2 };
+int dh_frontend_s16(const int16_t* d_in, size_t in_stride, float* d_out, size_t out_stride, float* d_state,
+                    size_t n_channels, size_t n, int mode, int dcblock, void* stream);
+
+/* ------------------------------------------------------------------------
  * Diagnostics: the RRC output scaling `(float)((double)sum / gain)` of
  * src/rrc_filter/rrc_filter.cpp:33 exactly as the FIR kernels evaluate it
  * (reciprocal multiply + exact-division fallback near float rounding ties).

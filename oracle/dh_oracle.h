@@ -69,6 +69,11 @@ void orc_rrc_free(orc_rrc*);
 void orc_rrc_process(orc_rrc*, const float* in, float* out, size_t n);
 const float* orc_rrc_taps(int narrow, unsigned* n_zeros, double* gain);
 
+/* ------------------------------------------------------------- frontend.c */
+/* the receiver front-end of examples/dmr-decoder.sh:13-17 (own specification, parity unpinned) */
+float orc_fe_atan2_over_pi(int32_t im, int32_t re);
+void orc_frontend_process(float* state4, const int16_t* in, size_t n, float* out, int mode, int dcblock);
+
 typedef struct orc_demod orc_demod;
 /* levels = 4 -> GfskDemodulator(sps); levels = 2 -> FskDemodulator(sps, invert) */
 orc_demod* orc_demod_new(unsigned sps, int levels, int invert);

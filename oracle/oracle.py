@@ -224,6 +224,18 @@ class Rrc:
             lib().orc_rrc_free(self._h); self._h = None
 
 
+def frontend(x, mode, dcblock=True, state=None):
+    """Front-end oracle over one channel: x = int16 audio (mode "audio") or interleaved int16 I / Q ("iq").
+    Returns (float32 samples, state) -- pass the state back in to continue the stream."""
+    a = np.ascontiguousarray(x, np.int16).ravel()
+    n = a.size if mode == "audio" else a.size // 2
+    st = np.zeros(4, np.float32) if state is None else np.ascontiguousarray(state, np.float32).copy()
+    out = np.zeros(n, np.float32)
+    lib().orc_frontend_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    lib().orc_frontend_process(_p(st), _p(a), C.c_size_t(n), _p(out), 1 if mode == "audio" else 2, int(bool(dcblock)))
+    return out, st
+
+
 class Demod:
     """Streaming GfskDemodulator (levels=4) / FskDemodulator (levels=2): keeps the unread tail like a csdr reader."""
 

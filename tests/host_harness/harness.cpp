@@ -148,6 +148,11 @@ static int dh_be_div_gain(const float* in, float* out, size_t n, int narrow, voi
     return 0;
 }
 
+static int dh_be_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock, void*) {
+    for (size_t ch = 0; ch < B; ch++) dh_frontend_channel(in + ch * in_stride, out + ch * out_stride, state + ch * DH_FE_STATE_WORDS, n, mode, dcblock);
+    return 0;
+}
+
 static int dh_be_div_const(const float* in, float* out, size_t n, unsigned divisor, void*) {
     const float d = (float) divisor, r = 1.0f / d;
     for (size_t i = 0; i < n; i++) out[i] = dh_div_const(in[i], d, r);
