@@ -184,9 +184,43 @@ __global__ void k_dvfilter(const int16_t* in, int16_t* out, float* state, size_t
     if (ch < B) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
 }
 
-__global__ void k_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock) {
+// Front-end in two launches: the conversion / discriminator has no dependence between samples (every sample looks at its
+// predecessor's I / Q only) and runs one sample per lane over the whole batch; only the DC blocker is a recurrence, one
+// channel per lane, four samples per load and store.  Same arithmetic as dh_frontend_channel (the CPU harness runs that).
+__global__ __launch_bounds__(256) void k_fe_convert(const int16_t* in, size_t in_stride, float* out, size_t out_stride, const float* state, size_t n, int mode) {
+    const size_t ch = blockIdx.y;
+    const int16_t* row = in + ch * in_stride;
+    const int32_t ip0 = (int32_t) state[ch * DH_FE_STATE_WORDS + 2], qp0 = (int32_t) state[ch * DH_FE_STATE_WORDS + 3];
+    for (size_t t = blockIdx.x * (size_t) blockDim.x + threadIdx.x; t < n; t += (size_t) gridDim.x * blockDim.x)
+        out[ch * out_stride + t] = dh_fe_convert(row, t, mode, ip0, qp0);
+}
+__global__ __launch_bounds__(64) void k_fe_dcblock(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock) {
     const size_t ch = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
-    if (ch < B) dh_frontend_channel(in + ch * in_stride, out + ch * out_stride, state + ch * DH_FE_STATE_WORDS, n, mode, dcblock);
+    if (ch >= B) return;
+    float* row = out + ch * out_stride;
+    float* st = state + ch * DH_FE_STATE_WORDS;
+    float xp = st[0], yp = st[1];
+    size_t t = 0;
+    if (dcblock) {
+#define DH_FE_STEP(c) do { const float d_ = (c) - xp; const float f_ = 0.995f * yp; yp = d_ + f_; xp = (c); (c) = yp; } while (0)
+        // 32 samples per trip, their eight loads in flight together, and the next trip's loads issued before this
+        // trip's arithmetic: a lane walks its own row (nothing coalesces across lanes), so latency is what has to be hidden
+        constexpr int U = 8;
+        dh_f4 cur[U], nxt[U];
+        if (n >= 4 * U) for (int u = 0; u < U; u++) cur[u] = dh_load4_unaligned(row + 4 * u);
+        for (; t + 4 * U <= n; t += 4 * U) {
+            const bool more = t + 8 * U <= n;
+            if (more) for (int u = 0; u < U; u++) nxt[u] = dh_load4_unaligned(row + t + 4 * U + 4 * u);
+            for (int u = 0; u < U; u++) {
+                DH_FE_STEP(cur[u].x); DH_FE_STEP(cur[u].y); DH_FE_STEP(cur[u].z); DH_FE_STEP(cur[u].w);
+                dh_store4_unaligned(row + t + 4 * u, cur[u]);
+            }
+            if (more) for (int u = 0; u < U; u++) cur[u] = nxt[u];
+        }
+        for (; t < n; t++) { const float x = row[t]; const float d = x - xp; const float f = 0.995f * yp; yp = d + f; xp = x; row[t] = yp; }
+    } else if (n) { xp = row[n - 1]; yp = xp; }
+    st[0] = xp; st[1] = yp;
+    if (mode == DH_FE_IQ_S16 && n) { st[2] = (float) in[ch * in_stride + 2 * n - 2]; st[3] = (float) in[ch * in_stride + 2 * n - 1]; }
 }
 
 __global__ void k_div_gain(const float* in, float* out, size_t n, double gain, double rgain) {
@@ -457,7 +491,10 @@ static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t 
 
 static int dh_be_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock, void* stream) {
     if (!B || !n) return DH_OK;
-    hipLaunchKernelGGL(k_frontend, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
+    const unsigned gx = (unsigned) std::min<size_t>((n + 1023) / 1024, 64);
+    hipLaunchKernelGGL(k_fe_convert, dim3(gx, (unsigned) B), dim3(256), 0, (hipStream_t) stream, in, in_stride, out, out_stride, (const float*) state, n, mode);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_fe_dcblock, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
     HIP_TRY(hipGetLastError());
     return DH_OK;
 }

@@ -44,6 +44,14 @@ DH_HD float dh_fe_atan2_over_pi(int32_t im, int32_t re) {
     return a * 0.31830988618379067154f;
 }
 
+// sample t of a channel before the DC blocker; (ip, qp) = the I / Q pair before it (from the state for t = 0)
+DH_HD float dh_fe_convert(const int16_t* in, size_t t, int mode, int32_t ip0, int32_t qp0) {
+    if (mode == DH_FE_AUDIO_S16) return (float) in[t] * 0.000030517578125f;
+    const int32_t i = in[2 * t], q = in[2 * t + 1];
+    const int32_t ip = t ? (int32_t) in[2 * t - 2] : ip0, qp = t ? (int32_t) in[2 * t - 1] : qp0;
+    return dh_fe_atan2_over_pi(q * ip - i * qp, i * ip + q * qp);
+}
+
 // n new samples of one channel; `in` points at its first new sample (int16 audio, or interleaved I / Q pairs)
 DH_HD void dh_frontend_channel(const int16_t* in, float* out, float* st, size_t n, int mode, int dcblock) {
     float xp = st[0], yp = st[1];
