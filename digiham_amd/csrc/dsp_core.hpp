@@ -32,8 +32,9 @@
 #endif
 #define DH_MAX_NZ 160
 #define DH_MAX_SPS 40
-#define DH_TAIL_MAX 256              // raw samples carried between pushes (>= nz + sps + 2)
-#define DH_STATE_HDR 16              // u32 words of per-channel header
+#define DH_HISTORY 1152              // raw samples kept BEHIND the read position by the error-bounded kernels (see DH_BOUNDED_FIR)
+#define DH_TAIL_MAX (256 + DH_HISTORY)   // raw samples carried between pushes: history + the last nz inputs + not yet consumed ones
+#define DH_STATE_HDR 32              // u32 words of per-channel header
 
 // per-channel state block in HBM (floats / u32 words, AoS, `state_stride` words apart):
 //   [0..15]                      header: k, pending offset, tail count, symbols produced (lo),
@@ -41,7 +42,13 @@
 //   [16 .. 16+100)               volume ring  (volume_rb)
 //   [116 .. 116+100*sps)         variance ring (variance_rb), phase-major: [sample i][symbol k]
 //   [.. + DH_TAIL_MAX)           raw-sample tail: the last nz inputs + not yet consumed samples
-enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED = 4, DH_ST_BLOCKS = 5 };
+enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED = 4, DH_ST_BLOCKS = 5,
+       DH_ST_P0 = 6,                 // read position inside the tail at the start of the next push (= history samples in front of it)
+       DH_ST_CUR_START = 7, DH_ST_CUR_OFF = 8, DH_ST_PREV_START = 9, DH_ST_PREV_OFF = 10,   // filtered positions of symbol 0 of the current / previous variance block, their offsets
+       DH_ST_BLOCK_FLAGS = 11,       // bit 0: the current block's start is known, bit 1: the previous block's
+       DH_ST_E_CUR = 12, DH_ST_E_PREV = 13, DH_ST_E_COUNT = 14, DH_ST_E_BLOCK = 15,          // error radii of the ring entries (floats), symbols in the current bucket
+       DH_ST_UNCERTAIN = 16, DH_ST_EXACT_RUNS = 17,                                             // statistics: symbols / runs decided by exact arithmetic
+       DH_ST_DIAG = 20 };            // 20..31: diagnostic builds (phase clocks 20..27, wave timeline 28..31)
 #define DH_ST_VOL DH_STATE_HDR
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
 
@@ -58,6 +65,8 @@ struct DhDspParams {
     uint32_t nz;                                       // FIR order (0 = no RRC stage)
     int32_t fast;                                      // 1 = FMA FIR
     int32_t ordered_timing;                            // 1 = always run the ordered variance chain (DH_FLAG_ORDERED_TIMING)
+    int32_t exact_mode;                                // error-bounded kernels: 0 normal, 1 every symbol decided by exact arithmetic, 2 exact FIR in every run
+    float err_coef;                                    // error radius of a filtered sample per unit of max |x| (dh_fir_error_coefficient)
     double gain, rgain; float inv_gain;                // rgain = 1/gain rounded to double
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
 };
@@ -274,10 +283,16 @@ inline dh_f2 dh_f2_fma(dh_f2 a, dh_f2 b, dh_f2 c) { return dh_f2_make(__builtin_
 
 // (float)((double)acc / gain) for the 16 accumulators of a lane, see dh_div_gain_fast
 template <bool FAST>
-DH_HD void dh_fir_finish(const float* acc, double gain, double rgain, float inv_gain, float* out16) {
+DH_HD void dh_fir_finish(const float* acc, double gain, double rgain, float inv_gain, float* out16, bool* nonfinite = nullptr) {
     if (FAST) {
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) out16[j] = acc[j] * inv_gain;
+        if (nonfinite) {                                  // NaN or infinity in any accumulator: 0 * acc is then NaN
+            float t = 0.0f;
+#pragma unroll
+            for (int j = 0; j < DH_FIR_L; j++) t = __builtin_fmaf(acc[j], 0.0f, t);
+            *nonfinite = !(t == 0.0f);
+        }
     } else {
         uint32_t tmin = 0xFFFFFFFFu, rmin = 0xFFFFFFFFu;
 #pragma unroll
@@ -371,7 +386,7 @@ template <int NZ, bool FAST, int B, bool SG = false, bool ZINIT = true> struct D
 };
 
 template <int NZ, bool FAST, bool SG = false>
-__device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
+__device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16, bool* nonfinite = nullptr) {
     constexpr bool ZINIT = SG;                             // the stand-alone RRC kernel (scalar taps) materialises its output
     // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
     const uint32_t addr = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (xs_all + (DH_FIR_L + 1) * lane);
@@ -391,11 +406,11 @@ __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, doub
     float acc[DH_FIR_L];
 #pragma unroll
     for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
-    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16);
+    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16, nonfinite);
 }
 #else
 template <int NZ, bool FAST>
-inline void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16) {
+inline void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16, bool* nonfinite = nullptr) {
     const float* xs = xs_all + (DH_FIR_L + 1) * lane;
 #define DH_XL(e) xs[DH_XLOFF(e)]
     dh_f2 accp[DH_FIR_H], w[DH_FIR_H];
@@ -413,7 +428,7 @@ inline void dh_fir_lane(const float* taps, double gain, double rgain, float inv_
     }
     float acc[DH_FIR_L];
     for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
-    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16);
+    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16, nonfinite);
 }
 #endif
 
@@ -549,6 +564,196 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// Error-bounded FIR (DH_BOUNDED_FIR; the exact wide-filter kernels at sps 10, i.e. the DMR / YSF pipes).
+//
+// The reference's dibits and timing steps depend on the filtered samples only through comparisons.  The kernel therefore
+// filters with the fused multiply-add FIR (half the vector instructions of the rounded-product chain), carries a proven
+// bound on how far each value can be from the reference's, decides every comparison that the bound leaves no doubt about,
+// and evaluates the rest -- a few symbols in ten thousand on noise, none on a clean signal -- with the reference's own
+// arithmetic (dh_exact_filtered: rounded products, rounded sums in tap order, the double division).  Outputs are the
+// reference's bits; only values that never leave the kernel (AGC ring, variance ring) are approximations.
+//
+// Bound.  u = 2^-24, A = sum |c_i| |x_i| <= ||c||_1 max|x| over the run's raw window, y = value the reference computes.
+//   reference chain: |acc_ref - sum c_i x_i| <= g82 A;  FMA chain: |acc_fma - sum c_i x_i| <= g81 A   (g_k = k u / (1 - k u))
+//   y_ref = acc_ref / gain (1 + d1), |d1| <= u (1 + 2^-29) (double division, then one rounding to float)
+//   y_fma = acc_fma fl32(1 / gain) (1 + d3) = acc_fma / gain (1 + d2)(1 + d3), |d2|, |d3| <= u (1 + 2^-29)
+//   => |y_fma - y_ref| <= (g82 + g81 + 3.1 u (1 + g82)) A / gain <= 167 u A / gain           (no overflow, no underflow:
+//   runs whose max |x| is 0 are exact, runs with max |x| outside [1e-25, 1e15] or a non-finite sample use the exact FIR)
+// The slicer's own float operations (window sums, /10, (max + min) / 2, the 0.625 thresholds) run on both sides with the
+// same operation sequence; on perturbed operands they add at most 62 u A / gain between a mid-symbol average and a
+// threshold (3 + 9 + 2 + 2 + 6 roundings of values <= 10 A / gain, worked out in DESIGN.md section 4.1).  With
+//   e = 240 u (||c||_1 / gain) max|x|      (dh_fir_error_coefficient: 240 u ||c||_1 / gain, rounded up)
+// an average and a threshold computed from values with radii <= e differ from the reference's difference by at most
+// (1 + 2.25) 167/240 e + 62/240 e < 2.53 e; a comparison is DECIDED when they are further apart than T = 3.5 e.
+// e of a ring entry is the e of the run that produced it: kept as two maxima over >= 100-symbol buckets (DH_ST_E_*).
+#ifndef DH_BOUNDED_FIR
+#define DH_BOUNDED_FIR 1
+#endif
+#define DH_BOUND_T_FACTOR 3.5f
+#define DH_BOUND_XMAX_LO 1e-25f
+#define DH_BOUND_XMAX_HI 1e15f
+
+// 240 u ||c||_1 / gain, rounded up (host side, once per engine)
+inline float dh_fir_error_coefficient(const float* taps_half, uint32_t nz, double gain) {
+    double l1 = 0.0;
+    for (uint32_t i = 0; i <= nz; i++) { const double c = taps_half[i <= nz / 2 ? i : nz - i]; l1 += c < 0 ? -c : c; }
+    const double coef = 240.0 * 5.9604644775390625e-08 * l1 / (gain < 0 ? -gain : gain) * 1.0001;
+    float f = (float) coef;
+    if ((double) f < coef) { union { float f; uint32_t u; } b; b.f = f; b.u++; f = b.f; }
+    return f;
+}
+
+// The reference's filtered sample at filtered position f of this push's virtual stream V = tail ++ in
+// (rrc_filter.cpp:22-34 for one output): needs V[f .. f + NZ].  Per lane, no barriers.  tapsf = first half + centre.
+template <int NZ>
+DH_HD float dh_exact_filtered(const float* tail, uint32_t tc, const float* in, uint32_t nv, const float* tapsf, double gain, double rgain, int32_t f) {
+    if (f < 0 || (uint32_t) f + (uint32_t) NZ >= nv) return 0.0f;       // not available (callers only ask for positions they hold)
+    float acc = 0.0f;
+    for (int i = 0; i <= NZ; i++) {
+        const float c = tapsf[i <= NZ / 2 ? i : NZ - i];
+        const float x = dh_virtual_sample(tail, tc, in, (uint32_t) f + (uint32_t) i);
+        const float prod = c * x;
+        acc = acc + prod;
+    }
+    return dh_div_gain(acc, gain, rgain);
+}
+
+// maximum over the wavefront of a per-lane value (device: six ds_swizzle / bpermute exchanges)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float dh_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+#endif
+
+// The rare paths of the error-bounded kernels (inlined: as real calls they would force the kernel's argument block into
+// scratch memory).  What they need to know lives in LDS between runs (DhBoundState), not in registers: every scalar that
+// stays live across the FIR -- where all 128 registers are taken -- is a spill in the hot loop.
+#define DH_COLD DH_HD
+
+// bookkeeping of the error-bounded kernels between runs, in LDS (words 48.. of the tap block: the wide filter uses 41)
+struct DhBoundState {
+    int32_t cur_start, cur_off, prev_start, prev_off;   // filtered positions of symbol 0 of the current / previous variance block, their offsets
+    uint32_t blk_flags;                                 // bit 0: the current block's start is known, bit 1: the previous block's
+    uint32_t e_count, n_uncertain, n_exact_runs;
+    float e_cur, e_prev, e_blk;                         // error radii: current / previous >= 100-symbol bucket, current variance block
+};
+#define DH_BOUND_STATE(S) (reinterpret_cast<DhBoundState*>((S).tapsf + 48))
+DH_HD float dh_uniform_f(float x) { union { float f; uint32_t u; } b; b.f = x; b.u = dh_uniform(b.u); return b.f; }
+
+// What the exact evaluation of one symbol needs to know about the stream (error-bounded kernels)
+struct DhExactCtx {
+    const float* tail; uint32_t tc; const float* in; uint32_t nv;      // the virtual stream V = tail ++ in
+    const float* tapsf; double gain, rgain; float sps_rcp;
+    int32_t cur_start, cur_off, prev_start, prev_off; uint32_t blk_flags;
+    uint32_t k0;                                                        // ring slots [k0, k] hold this run's volumes (S.vol_new)
+    float e_eff; int32_t levels, invert;
+};
+// filtered position of sample 0 of ring slot j as seen from symbol k of the current block: slots <= k belong to the
+// current block, the others still hold the previous block's symbols; INT32_MIN = a slot never written (exact zero)
+DH_HD int32_t dh_slot_position(const DhExactCtx& C, uint32_t j, uint32_t k, uint32_t sps) {
+    if (j <= k) return (C.blk_flags & 1u) ? C.cur_start + (int32_t) (j * sps) + (j ? C.cur_off : 0) : INT32_MIN;
+    return (C.blk_flags & 2u) ? C.prev_start + (int32_t) (j * sps) + (j ? C.prev_off : 0) : INT32_MIN;
+}
+
+// Symbol k of the current block decided with the reference's arithmetic (gfsk_demodulator.cpp:82-122): its mid-symbol
+// average from exact filtered samples, and the exact minimum / maximum of the volume ring -- only ring slots whose
+// approximate volume lies within 2.5 e of the approximate extreme can hold the exact one, so only those are recomputed
+// (ten exact samples each, summed in order, / sps).  Wave-level: all lanes call it; `scratch` = 64 floats of LDS.
+template <int NZ, int SPS>
+DH_COLD uint8_t dh_exact_symbol(const DhExactCtx& C, DhDspShared& S, uint32_t k, float* scratch) {
+    constexpr uint32_t sps = SPS, LO = 3, HI = 7;
+    const float mn_a = S.mn[k], mx_a = S.mx[k];
+    const float lo_thr = mn_a + 2.5f * C.e_eff, hi_thr = mx_a - 2.5f * C.e_eff;
+    uint64_t cand_lo[2] = { 0, 0 }, cand_hi[2] = { 0, 0 };
+    for (int h = 0; h < 2; h++) {
+        uint64_t vlo = 0, vhi = 0;
+        DH_FOR_LANES_FRESH(lane) {
+            const uint32_t j = (uint32_t) lane + 64u * (uint32_t) h;
+            bool lo = false, hi = false;
+            if (j < DH_VOLUME_RB_SIZE) {
+                const float v = (j >= C.k0 && j <= k) ? S.vol_new[j] : S.vol_old[j];
+                lo = v <= lo_thr; hi = v >= hi_thr;
+            }
+            DH_BALLOT_ACC(vlo, lo, lane); DH_BALLOT_ACC(vhi, hi, lane);
+        }
+        cand_lo[h] = vlo; cand_hi[h] = vhi;
+    }
+    float exact_min = DH_FLT_MAX, exact_max = DH_FLT_MIN;            // the reference's seeds (gfsk_demodulator.cpp:110-111)
+    float avg_sum = 0.0f;
+    bool first = true;
+    uint64_t todo[2] = { cand_lo[0] | cand_hi[0], cand_lo[1] | cand_hi[1] };
+    while (first || todo[0] || todo[1]) {
+        uint32_t slot[6]; int n = 0;
+        for (int h = 0; h < 2 && n < 6; h++)
+            while (todo[h] && n < 6) { const int b = dh_ffs64(todo[h]); todo[h] &= todo[h] - 1; slot[n++] = (uint32_t) b + 64u * (uint32_t) h; }
+        DH_BARRIER();                                                  // the scratch of the previous round has been read
+        DH_FOR_LANES_FRESH(lane) {
+            int32_t f = INT32_MIN;
+            if (lane < 4) { if (first) f = dh_slot_position(C, k, k, sps) + (int32_t) LO + lane; }
+            else {
+                const int c = (lane - 4) / 10, i = (lane - 4) % 10;
+                if (c < n) { const int32_t s0 = dh_slot_position(C, slot[c], k, sps); if (s0 != INT32_MIN) f = s0 + i; }
+            }
+            scratch[lane] = f == INT32_MIN ? 0.0f : dh_exact_filtered<NZ>(C.tail, C.tc, C.in, C.nv, C.tapsf, C.gain, C.rgain, f);
+        }
+        DH_BARRIER();
+        if (first) { for (int i = 0; i < (int) (HI - LO); i++) avg_sum += scratch[i]; first = false; }
+        for (int c = 0; c < n; c++) {
+            float vol = 0.0f;
+            for (int i = 0; i < 10; i++) vol += scratch[4 + 10 * c + i];
+            vol = dh_div_const(vol, (float) sps, C.sps_rcp);
+            const uint32_t j = slot[c];
+            if ((cand_lo[j >> 6] >> (j & 63u)) & 1u) exact_min = dh_fmin_(exact_min, vol);
+            if ((cand_hi[j >> 6] >> (j & 63u)) & 1u) exact_max = dh_fmax_(exact_max, vol);
+        }
+    }
+    const float center = (exact_max + exact_min) / 2.0f;
+    const float average = avg_sum / (float) (HI - LO);
+    if (C.levels == 4) {
+        const float umid = __builtin_fmaf(exact_max - center, 0.625f, center);
+        const float lmid = __builtin_fmaf(exact_min - center, 0.625f, center);
+        if (average > center) return average > umid ? 1 : 0;
+        return average < lmid ? 3 : 2;
+    }
+    return average > center ? (uint8_t) !C.invert : (uint8_t) (C.invert != 0);
+}
+
+// the rounded-product FIR over the staged window (runs the bound does not cover): outputs into fo[16] per lane
+template <int NZ>
+DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t need, float (*fo_all)[DH_FIR_L], float* fo_dev) {
+    float tv[NZ / 2 + 1];
+    for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
+    DH_FOR_LANES_FRESH(lane) {
+        if ((uint32_t) (lane * DH_FIR_L) < need) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            (void) fo_all;
+            dh_fir_lane<NZ, false>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, fo_dev);
+#else
+            (void) fo_dev;
+            dh_fir_lane<NZ, false>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, fo_all[lane]);
+#endif
+        }
+    }
+}
+
+// the variance ring of the block that just ended, recomputed with the reference's arithmetic (ordered timing chain)
+template <int NZ>
+DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps) {
+    for (uint32_t r = 0; r * DH_WAVE < DH_VARIANCE_SYMBOLS * sps; r++) {
+        DH_FOR_LANES_FRESH(lane) {
+            const uint32_t e = r * DH_WAVE + (uint32_t) lane;
+            if (e < DH_VARIANCE_SYMBOLS * sps) {
+                const uint32_t j = e / sps, i = e - j * sps;
+                const int32_t f = C.cur_start + (int32_t) (j * sps) + (j ? C.cur_off : 0) + (int32_t) i;
+                S.var_rb[i * DH_VARIANCE_SYMBOLS + j] = dh_exact_filtered<NZ>(C.tail, C.tc, C.in, C.nv, C.tapsf, C.gain, C.rgain, f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
 // once (host harness; the DH_FOR_LANES loops then iterate the lanes).
 // SPS = 10 bakes the DMR / YSF samples-per-symbol (and its evaluation window 3..6) into the code so the
@@ -556,6 +761,8 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 template <int NZ, bool FAST, int SPS>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
     static_assert(SPS == 0 || SPS == 10, "only sps 10 is specialised");
+    constexpr bool BOUNDED = DH_BOUNDED_FIR && NZ == 80 && !FAST && SPS == 10;      // see "Error-bounded FIR" above
+    DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
     const uint32_t sps = SPS ? (uint32_t) SPS : P.sps;
@@ -590,6 +797,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 
     // FIR taps are parked in LDS and pulled into VGPRs at the start of every FIR pass (see P2): their live range
     // must end with the FIR, or they pin ~80 registers through the latency-bound phases where the prefetch lives.
+    if (BOUNDED) {
+        BS->cur_start = (int32_t) sth[DH_ST_CUR_START]; BS->cur_off = (int32_t) sth[DH_ST_CUR_OFF];
+        BS->prev_start = (int32_t) sth[DH_ST_PREV_START]; BS->prev_off = (int32_t) sth[DH_ST_PREV_OFF];
+        BS->blk_flags = sth[DH_ST_BLOCK_FLAGS]; BS->e_count = sth[DH_ST_E_COUNT]; BS->n_uncertain = 0; BS->n_exact_runs = 0;
+        BS->e_cur = st[DH_ST_E_CUR]; BS->e_prev = st[DH_ST_E_PREV]; BS->e_blk = st[DH_ST_E_BLOCK];
+    }
     DH_FOR_LANES(lane) {
         for (int i = lane; i <= NZ / 2; i += DH_WAVE) S.tapsf[i] = P.taps[i];
         if (lane < 2) S.stats[lane] = 0;
@@ -598,7 +811,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #endif
     }
 
-    uint32_t p = 0;                                     // read position in the filtered stream
+    // error-bounded mode (see DH_BOUNDED_FIR above): the tail then starts with DH_ST_P0 samples of HISTORY, so that the
+    // raw samples behind every entry of the 100-symbol rings are still at hand when a comparison has to be settled exactly
+    uint32_t p = BOUNDED ? sth[DH_ST_P0] : 0u;          // read position in the filtered stream
     bool staged = false; uint32_t staged_p = 0;         // the LDS window already holds V[staged_p ...) (prefetch)
     uint32_t nsym = 0;
     bool overflow = false;
@@ -627,6 +842,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         const uint32_t last_start = p + (m - 1) * sps + (m > 1 ? (uint32_t) step_off : 0u);
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
+        if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags |= 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
+        bool use_exact = BOUNDED && P.exact_mode == 2;  // this run through the exact FIR (odd samples, odd staging path)
+        DH_LANE_ARRAY(float, xmax_lane, 1);
 
         // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window (zeros beyond)
         // After the first run of a push the whole window comes straight from `in`: 16 B per lane per load,
@@ -655,6 +873,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 if constexpr (LAST_LANES > 0) v[DH_PF_N - 1] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
                 else v[DH_PF_N - 1] = v[0];
                 float* ldst = &S.xf[DH_XP(l4)];
+                if (BOUNDED) {                         // max |x| of the window (a NaN is skipped here and caught behind the FIR)
+                    float mx = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < DH_PF_N; r++) {
+                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)));
+                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w)));
+                    }
+                    DH_LA(xmax_lane, lane)[0] = mx;
+                }
                 if (have >= DH_FTILE + NZ) {
                     dh_lds_store4_at<0>(ldst, v[0]); dh_lds_store4_at<GSTEP>(ldst, v[1]);
                     dh_lds_store4_at<2 * GSTEP>(ldst, v[2]); dh_lds_store4_at<3 * GSTEP>(ldst, v[3]);
@@ -675,6 +902,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
             }
         } else if (p >= tc) {
+            use_exact = BOUNDED;
             const float* src = in + (p - tc);
             const uint32_t have = dh_min<uint32_t>(DH_FTILE + NZ, nv - p);
             DH_FOR_LANES_FRESH(lane) {
@@ -689,12 +917,26 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
             }
         } else {
+            use_exact = BOUNDED;
             DH_FOR_LANES_FRESH(lane) {
                 for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
                     S.xf[DH_XP(e)] = p + e < nv ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
             }
         }
         DH_BARRIER();
+        float e_run = 0.0f;                             // error radius of this run's filtered samples (0: exact)
+        if (BOUNDED && !use_exact) {
+            float xmax;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            xmax = dh_wave_max(xmax_lane[0]);
+#else
+            xmax = 0.0f;
+            for (int l = 0; l < DH_WAVE; l++) xmax = __builtin_fmaxf(xmax, xmax_lane[l][0]);
+#endif
+            if (xmax == 0.0f) e_run = 0.0f;             // all zeros in, all zeros out of either FIR
+            else if (xmax >= DH_BOUND_XMAX_LO && xmax <= DH_BOUND_XMAX_HI) e_run = P.err_coef * xmax;
+            else use_exact = true;                      // tiny, huge or infinite samples: outside the bound's assumptions
+        }
         DH_CLK(0);
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
@@ -726,9 +968,29 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             // (from the LDS copy into vector registers: taps as scalar operands free 40 VGPRs but cost this kernel 5 %,
             // see DhFirBatch)
             for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
-            DH_FOR_LANES_FRESH(lane) {
-                if ((uint32_t) (lane * DH_FIR_L) < need)
-                    dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
+            if (BOUNDED) {
+                uint64_t vote_bad = 0;
+                if (!use_exact) {
+                    DH_FOR_LANES_FRESH(lane) {
+                        bool bad = false;
+                        if ((uint32_t) (lane * DH_FIR_L) < need)
+                            dh_fir_lane<NZ, true>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane), &bad);
+                        DH_BALLOT_ACC(vote_bad, bad, lane);
+                    }
+                }
+                if (use_exact || vote_bad) {            // a NaN / infinity among the samples: the reference's arithmetic decides
+                    use_exact = true; e_run = 0.0f; BS->n_exact_runs++;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                    dh_exact_fir_pass<NZ>(P, S, need, nullptr, fo);
+#else
+                    dh_exact_fir_pass<NZ>(P, S, need, fo, nullptr);
+#endif
+                }
+            } else {
+                DH_FOR_LANES_FRESH(lane) {
+                    if ((uint32_t) (lane * DH_FIR_L) < need)
+                        dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
+                }
             }
             DH_BARRIER();
             DH_FOR_LANES_FRESH(lane) {
@@ -841,8 +1103,19 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_CLK(3);
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
+        // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
+        // reference's; those symbols are not stored here but decided exactly below
+        DH_COMPILER_FENCE();                            // the bookkeeping in LDS is read here, not carried across the FIR
+        float e_blk = 0.0f;
+        if (BOUNDED) { e_blk = dh_uniform_f(__builtin_fmaxf(BS->e_blk, e_run)); BS->e_blk = e_blk; }
+        const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
+        const float T = DH_BOUND_T_FACTOR * e_eff;
+        uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
+        for (uint32_t h = 0; h * DH_WAVE < m; h++) {
+        uint64_t vote_unsure = 0;
         DH_FOR_LANES_FRESH(lane) {
-            for (uint32_t q = lane; q < m; q += DH_WAVE) {
+            bool doubt = false;
+            for (uint32_t q = h * DH_WAVE + (uint32_t) lane; q < dh_min<uint32_t>(m, (h + 1u) * DH_WAVE); q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const float mn = S.mn[k], mx = S.mx[k];
                 const float center = (mx + mn) / 2.0f;
@@ -857,10 +1130,33 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     const float lmid = __builtin_fmaf(mn - center, 0.625f, center);
                     if (average > center) sym = average > umid ? 1 : 0;
                     else sym = average < lmid ? 3 : 2;
+                    if (BOUNDED) doubt = __builtin_fabsf(average - umid) <= T || __builtin_fabsf(average - lmid) <= T;
                 } else {
                     sym = average > center ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
                 }
-                syms[nsym + q] = sym;
+                if (BOUNDED) doubt = (e_eff > 0.0f && (doubt || __builtin_fabsf(average - center) <= T)) || P.exact_mode == 1;
+                if (!doubt) syms[nsym + q] = sym;
+            }
+            DH_BALLOT_ACC(vote_unsure, doubt, lane);
+        }
+        if (h < 2) unsure[h] = vote_unsure;
+        }
+        if (BOUNDED && (unsure[0] | unsure[1])) {
+            DhExactCtx C;
+            C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
+            C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
+            C.prev_start = (int32_t) dh_uniform((uint32_t) BS->prev_start); C.prev_off = (int32_t) dh_uniform((uint32_t) BS->prev_off);
+            C.blk_flags = dh_uniform(BS->blk_flags);
+            C.k0 = k0; C.e_eff = e_eff; C.levels = P.levels; C.invert = P.invert;
+            for (int h = 0; h < 2; h++) {
+                uint64_t todo = unsure[h];
+                while (todo) {
+                    const uint32_t q = (uint32_t) dh_ffs64(todo) + 64u * (uint32_t) h;
+                    todo &= todo - 1;
+                    const uint8_t sym = dh_exact_symbol<NZ, SPS ? SPS : 10>(C, S, k0 + q, S.xf + 640);
+                    DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
+                    BS->n_uncertain++;
+                }
             }
         }
 
@@ -939,7 +1235,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         const float v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) * 0.01f;
                         const float mean = DH_LA(pmean, lane)[0];
                         const float e = __builtin_fmaf(mean, mean, v);
-                        const float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
+                        float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
+                        // error-bounded mode: the ring holds values within e_blk of the reference's; moving every sample by
+                        // up to e_blk moves the mean by <= e_blk, every deviation by <= 2 e_blk and the variance by
+                        // <= 4 e_blk sqrt(V) + 4 e_blk^2 (Cauchy-Schwarz); taken twice over for the float mean's own rounding
+                        if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * __builtin_sqrtf(v + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
                         guard = e < 1e30f;                           // false for NaN, and for samples beyond ~1e15 (e overflows first)
                         vzero = v == 0.0f;
                         l = v - tol; h = v + tol;
@@ -951,7 +1251,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
                 }
                 const uint32_t ten = 0x3FFu;
-                if ((uint32_t) vote_vzero & ten) {
+                if (((uint32_t) vote_vzero & ten) && !(BOUNDED && e_blk > 0.0f)) {       // (approximate samples prove nothing about exact zeros)
                     // an estimate of exactly 0: only a phase whose hundred samples are all (+-)0 has vmin == 0 for sure (tiny
                     // samples square to 0 in float, not in the reference's double) -- look at the bits
                     uint64_t vote_nz = 0;
@@ -991,6 +1291,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
                 // ring and fetched 16 bytes at a time
                 DH_BARRIER();
+                if (BOUNDED && e_blk > 0.0f) {          // the chain needs the reference's samples: all thousand of this block, exactly
+                    DhExactCtx C;
+                    C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
+                    C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
+                    C.prev_start = 0; C.prev_off = 0; C.blk_flags = dh_uniform(BS->blk_flags);
+                    C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
+                    dh_exact_var_ring<NZ>(C, S, sps);
+                    DH_BARRIER();
+                }
                 DH_FOR_LANES_FRESH(lane) {
                     if ((uint32_t) lane < sps) {
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
@@ -1063,35 +1372,62 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         if (k0 == 0) off = 0;                           // the pending step has been consumed (:36-38)
         k0 += m;
         if (block_done) { k0 = 0; off = new_off; }
+        if (BOUNDED) {
+            // radii of the ring entries: the last 100 symbols always lie inside the current bucket + the one before it
+            const float ec = __builtin_fmaxf(BS->e_cur, e_run);
+            const uint32_t cnt = dh_uniform(BS->e_count) + m;
+            if (cnt >= DH_VOLUME_RB_SIZE) { BS->e_prev = ec; BS->e_cur = 0.0f; BS->e_count = 0; }
+            else { BS->e_cur = ec; BS->e_count = cnt; }
+            if (block_done) { BS->prev_start = BS->cur_start; BS->prev_off = BS->cur_off; BS->blk_flags = (BS->blk_flags & 1u) ? 2u : 0u; }
+        }
         DH_CLK(6);
     }
 
 #if DH_PF_L2 && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // a last L2-touch load may still be writing into the window block
 #endif
-    // ---- write back state: rings, header, and the raw tail V[p .. nv)
-    const uint32_t new_tc = nv - p;                    // = unread filtered samples + NZ
+    // ---- write back state: rings, header, and the raw tail V[base .. nv): the unread samples (from p) and, in the
+    // error-bounded kernels, up to DH_HISTORY samples behind them
+    const uint32_t keep = BOUNDED ? dh_min<uint32_t>(DH_HISTORY, p) : 0u;
+    const uint32_t base = p - keep;
+    const uint32_t new_tc = nv - base;                 // = history + unread filtered samples + NZ
     DH_FOR_LANES(lane) {
         for (uint32_t j = lane; j < DH_VOLUME_RB_SIZE; j += DH_WAVE) st[DH_ST_VOL + j] = S.vol_old[j];
         for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) st[DH_ST_VAR + j] = S.var_rb[j];
-        // tail may overlap its own source when p < tc: go through LDS
-        for (uint32_t j = lane; j < new_tc && j < DH_TAIL_MAX; j += DH_WAVE) S.xf[j] = dh_virtual_sample(tail, tc, in, p + j);
     }
-    DH_BARRIER();
+    // the tail may overlap its own source when base < tc: in chunks through LDS (a chunk is read completely before any of
+    // it is written, and later chunks only read further ahead)
+    for (uint32_t c0 = 0; c0 < new_tc && c0 < DH_TAIL_MAX; c0 += DH_FTILE) {
+        DH_BARRIER();
+        DH_FOR_LANES(lane) {
+            for (uint32_t j = c0 + lane; j < new_tc && j < DH_TAIL_MAX && j < c0 + DH_FTILE; j += DH_WAVE) S.xf[j - c0] = dh_virtual_sample(tail, tc, in, base + j);
+        }
+        DH_BARRIER();
+        DH_FOR_LANES(lane) {
+            for (uint32_t j = c0 + lane; j < new_tc && j < DH_TAIL_MAX && j < c0 + DH_FTILE; j += DH_WAVE) tail[j] = S.xf[j - c0];
+        }
+    }
     DH_FOR_LANES(lane) {
-        for (uint32_t j = lane; j < new_tc && j < DH_TAIL_MAX; j += DH_WAVE) tail[j] = S.xf[j];
         if (DH_IS_LANE0(lane)) {
             sth[DH_ST_K] = k0;
             sth[DH_ST_OFF] = (uint32_t) off;
             sth[DH_ST_TAIL] = new_tc < DH_TAIL_MAX ? new_tc : DH_TAIL_MAX;
             sth[DH_ST_NSYM] += nsym;
+            if (BOUNDED) {
+                sth[DH_ST_P0] = keep;
+                sth[DH_ST_CUR_START] = (uint32_t) (BS->cur_start - (int32_t) base); sth[DH_ST_CUR_OFF] = (uint32_t) BS->cur_off;
+                sth[DH_ST_PREV_START] = (uint32_t) (BS->prev_start - (int32_t) base); sth[DH_ST_PREV_OFF] = (uint32_t) BS->prev_off;
+                sth[DH_ST_BLOCK_FLAGS] = BS->blk_flags; sth[DH_ST_E_COUNT] = BS->e_count;
+                st[DH_ST_E_CUR] = BS->e_cur; st[DH_ST_E_PREV] = BS->e_prev; st[DH_ST_E_BLOCK] = BS->e_blk;
+                sth[DH_ST_UNCERTAIN] += BS->n_uncertain; sth[DH_ST_EXACT_RUNS] += BS->n_exact_runs;
+            }
 #ifdef DH_PHASE_CLOCKS
-            for (int i = 0; i < 8; i++) sth[6 + i] += S.clk[i] >> 6;
+            for (int i = 0; i < 8; i++) sth[DH_ST_DIAG + i] += S.clk[i] >> 6;
 #endif
 #if defined(DH_WAVE_TIMELINE) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            sth[14] = dh_t_start; sth[15] = (uint32_t) wall_clock64();
-            sth[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
-            sth[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+            sth[DH_ST_DIAG + 10] = dh_t_start; sth[DH_ST_DIAG + 11] = (uint32_t) wall_clock64();
+            sth[DH_ST_DIAG + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+            sth[DH_ST_DIAG + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
 #endif
             sth[DH_ST_BLOCKS] += S.stats[0];
             sth[DH_ST_ORDERED] += S.stats[1];

@@ -232,7 +232,11 @@ struct Engine {
             dsp.levels = L.demod; dsp.invert = (L.flags & DH_FLAG_FSK_INVERT) ? 1 : 0;
             dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast;
             dsp.ordered_timing = (L.flags & DH_FLAG_ORDERED_TIMING) ? 1 : 0;
-            if (L.fused) { fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain; }
+            dsp.exact_mode = (L.flags & DH_FLAG_EXACT_FIR) ? 2 : (L.flags & DH_FLAG_EXACT_SYMBOLS) ? 1 : 0;
+            if (L.fused) {
+                fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain;
+                dsp.err_coef = dh_fir_error_coefficient(dsp.taps, L.nz, dsp.gain);
+            }
             // slicer and decoder of a channel in one wavefront where the backend has that kernel (sps 10, wide or
             // no RRC); DH_FLAG_SPLIT_STAGES keeps the two launches (per-stage timing, A/B measurements)
             int chained = 1;

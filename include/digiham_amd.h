@@ -107,6 +107,8 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3,
 #define DH_FLAG_NO_EVENTS       0x8   /* do not record decoder events */
 #define DH_FLAG_SPLIT_STAGES    0x20  /* launch slicer and decoder as two kernels even where the one-wavefront chain kernel exists */
 #define DH_FLAG_ORDERED_TIMING  0x10  /* always run the in-order variance chain of the timing recovery (diagnostic; results are identical) */
+#define DH_FLAG_EXACT_SYMBOLS   0x40  /* error-bounded kernels: decide EVERY symbol with the reference's arithmetic (diagnostic; results are identical) */
+#define DH_FLAG_EXACT_FIR       0x80  /* error-bounded kernels: run the rounded-product FIR in every run (diagnostic / A-B; results are identical) */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(dh_engine_config) */
@@ -198,7 +200,7 @@ int  dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float*
  * blocks = 100-symbol variance blocks evaluated (gfsk_demodulator.cpp:41-80), ordered = those in which the
  * error-bounded estimate could not separate the phases and the reference's in-order sums decided. Synchronises. */
 int  dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered);
-/* Diagnostic: word `word` (0..15) of every channel's slicer state header, or word `word - 100` (0..63) of its
+/* Diagnostic: word `word` (0..31) of every channel's slicer state header, or word `word - 100` (0..63) of its
  * decoder state, into h_out[n_channels]. Synchronises. */
 int  dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out);
 /* wait for all enqueued work; returns DH_ECAPACITY if any channel overflowed an output buffer */

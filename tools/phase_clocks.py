@@ -31,7 +31,7 @@ def main():
     eng.timing_enable(4)
     eng.push(x); eng.sync()
     _, ms, _ = eng.timing_read()
-    clk = np.stack([eng.debug_header(6 + i).astype(np.float64) * 64 for i in range(8)])     # [phase][channel]
+    clk = np.stack([eng.debug_header(20 + i).astype(np.float64) * 64 for i in range(8)])     # [phase][channel]
     runs = T / (100.0 * sps)
     tot = clk.sum(0).mean()
     print("kernel %.2f ms; wave cycles per channel %.3g; per run %.0f" % (float(ms[0]), tot, tot / runs))

@@ -24,8 +24,8 @@ for _ in range(3):
     eng.push(x)
 eng.sync()
 _, ms, _ = eng.timing_read()
-t0 = eng.debug_header(14).astype(np.int64)
-t1 = eng.debug_header(15).astype(np.int64)
+t0 = eng.debug_header(30).astype(np.int64)
+t1 = eng.debug_header(31).astype(np.int64)
 base = t0.min()
 t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0          # microseconds
 dur = t1 - t0
@@ -39,7 +39,7 @@ order = np.argsort(t0)
 rounds = [dur[order[i:i + 4096]].mean() for i in range(0, B, 4096)]
 print("mean duration by start order (groups of 4096):", ["%.0f" % r for r in rounds])
 
-hw = eng.debug_header(12); xcc = eng.debug_header(13) & 15
+hw = eng.debug_header(28); xcc = eng.debug_header(29) & 15
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; slot = hw & 15
 key = (((xcc.astype(np.int64) * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
 print("distinct SIMDs seen: %d, wave slots used: %s" % (len(np.unique(key)), sorted(set(slot.tolist()))))
