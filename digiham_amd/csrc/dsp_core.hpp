@@ -406,7 +406,14 @@ __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, doub
     float acc[DH_FIR_L];
 #pragma unroll
     for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
-    dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16, nonfinite);
+    if (FAST && nonfinite) {                               // 0 * acc is NaN for a NaN or infinite accumulator: eight packed FMAs
+        dh_f2 t = dh_f2_make(0.0f, 0.0f);
+        const dh_f2 zero = dh_f2_make(0.0f, 0.0f);
+#pragma unroll
+        for (int j = 0; j < DH_FIR_H; j++) t = __builtin_elementwise_fma(accp[j], zero, t);
+        *nonfinite = !(t.x + t.y == 0.0f);
+        dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16, nullptr);
+    } else dh_fir_finish<FAST>(acc, gain, rgain, inv_gain, out16, nonfinite);
 }
 #else
 template <int NZ, bool FAST>
@@ -620,10 +627,21 @@ DH_HD float dh_exact_filtered(const float* tail, uint32_t tc, const float* in, u
 
 // maximum over the wavefront of a per-lane value (device: six ds_swizzle / bpermute exchanges)
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// (row_shr 1/2/4/8 inside each row of 16, row_bcast:15 / :31 across rows -- the running maximum ends up in lane 63;
+// v_max_f32 skips a NaN operand, which is what the caller wants: NaN samples are caught behind the FIR)
 __device__ __forceinline__ float dh_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
-    return v;
+#define DH_MAX_STEP(ctrl) "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl "\n\t"
+    asm volatile("s_nop 4\n\t"
+                 DH_MAX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") DH_MAX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 DH_MAX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") DH_MAX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 DH_MAX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") DH_MAX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1" : "+v"(v));
+#undef DH_MAX_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// max(|a|, |b|, c) in one instruction
+__device__ __forceinline__ float dh_max3_abs(float a, float b, float c) {
+    float r; asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
 #endif
 
@@ -877,8 +895,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     float mx = 0.0f;
 #pragma unroll
                     for (int r = 0; r < DH_PF_N; r++) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                        mx = dh_max3_abs(v[r].x, v[r].y, mx); mx = dh_max3_abs(v[r].z, v[r].w, mx);
+#else
                         mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)));
                         mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w)));
+#endif
                     }
                     DH_LA(xmax_lane, lane)[0] = mx;
                 }
