@@ -1056,11 +1056,24 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
                     }
                 } else {
-                    for (uint32_t i = 0; i < sps; i++) {
+                    // four samples at a time, all four requested before the first is used (see above); sums in sample order
+                    uint32_t i = 0;
+                    for (; i + 4u <= sps; i += 4u) {
+                        float value[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++) value[j] = DH_FB(s + i + j);
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++) {
+                            if (i + j >= ev_lo && i + j < ev_hi) sum += value[j];
+                            volume_sum += value[j];
+                            S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
+                        }
+                    }
+                    for (; i < sps; i++) {
                         const float value = DH_FB(s + i);
                         if (i >= ev_lo && i < ev_hi) sum += value;
                         volume_sum += value;
-                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;       // transposed ring: phase-major
+                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
                     }
                 }
                 S.sum[q] = sum;

@@ -27,6 +27,11 @@ def init_process_group(backend=None):
     # DH_FORCE_DIST=1 initialises the process group even for a single rank (exercises the RCCL path on a 1-GPU box)
     if (world > 1 or os.environ.get("DH_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:             # only without a launcher (DH_FORCE_DIST on one rank): any free port
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
