@@ -588,7 +588,7 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 //   runs whose max |x| is 0 are exact, runs with max |x| outside [1e-25, 1e15] or a non-finite sample use the exact FIR)
 // The slicer's own float operations (window sums, /10, (max + min) / 2, the 0.625 thresholds) run on both sides with the
 // same operation sequence; on perturbed operands they add at most 62 u A / gain between a mid-symbol average and a
-// threshold (3 + 9 + 2 + 2 + 6 roundings of values <= 10 A / gain, worked out in DESIGN.md section 4.1).  With
+// threshold (counted operation by operation in DESIGN.md section 3: 39.8 u A / gain for both sides together).  With
 //   e = 240 u (||c||_1 / gain) max|x|      (dh_fir_error_coefficient: 240 u ||c||_1 / gain, rounded up)
 // an average and a threshold computed from values with radii <= e differ from the reference's difference by at most
 // (1 + 2.25) 167/240 e + 62/240 e < 2.53 e; a comparison is DECIDED when they are further apart than T = 3.5 e.
