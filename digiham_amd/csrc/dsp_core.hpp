@@ -596,6 +596,11 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 #ifndef DH_BOUNDED_FIR
 #define DH_BOUNDED_FIR 1
 #endif
+// Diagnostic builds only (tools/phase_budget.sh): -DDH_STOP_AFTER=n leaves out the phases after Pn of every run (the
+// results are then wrong; the instruction counters of such builds, subtracted from each other, give the per-phase budget)
+#ifndef DH_STOP_AFTER
+#define DH_STOP_AFTER 99
+#endif
 #define DH_BOUND_T_FACTOR 3.5f
 #define DH_BOUND_XMAX_LO 1e-25f
 #define DH_BOUND_XMAX_HI 1e15f
@@ -966,7 +971,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // windows of P3 then sit at compile-time offsets from one per-lane base, which saves two address
         // instructions per sample on the VALU; the bank conflicts of the 16-words-apart stores cost LDS cycles
         // only, and the LDS pipe has slack.  Without an RRC stage the staged (padded) samples are used as they are.
-        if (NZ > 0) {
+        if (NZ > 0 && DH_STOP_AFTER >= 2) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
 #if DH_PRIO_MODE == 1
             DH_SETPRIO(0);
@@ -1038,7 +1043,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #define DH_FB(n) fbuf[n]
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
-        DH_FOR_LANES_FRESH(lane) {
+        if (DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
@@ -1129,11 +1134,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #endif
 
         // ---- P4: sliding AGC min/max as two wave scans
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-        dh_agc_scan(S, k0, k0 + m);
-#else
-        dh_agc_scan(S, k0, k0 + m);
-#endif
+        if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
         DH_BARRIER();
         DH_CLK(3);
 
@@ -1146,7 +1147,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
         const float T = DH_BOUND_T_FACTOR * e_eff;
         uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
-        for (uint32_t h = 0; h * DH_WAVE < m; h++) {
+        for (uint32_t h = 0; h * DH_WAVE < m && DH_STOP_AFTER >= 5; h++) {
         uint64_t vote_unsure = 0;
         DH_FOR_LANES_FRESH(lane) {
             bool doubt = false;
@@ -1214,7 +1215,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // Anything else (ties, constant input, non-finite or huge samples) is decided by the ordered chain.
         int32_t new_off = 0;
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
-        if (block_done) {
+        if (block_done && DH_STOP_AFTER >= 6) {
             bool ordered = true;
             if (SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
