@@ -70,19 +70,21 @@ WORKLOADS = {
 UNITS = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}     # bursts / frames per step: ~3.96-4 s
 
 
-def profiled_traffic(workload, channels, T):
+def profiled_traffic(workload, channels, T, part0=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
     KiB, per-dispatch average; MI355X_MICROARCH.md) -- bench.py cannot collect counters itself.  Only for the
-    configuration those passes were run on (tools/profile_gpu.sh: the default workload); newest round first."""
+    configuration those passes were run on (tools/profile_gpu.sh: the default workload); newest round first.
+    part0: the push goes out as two launches; take the lines of the first one (kernel template argument PART = 0)."""
     if workload != "dmr_full" or channels != 16384 or T != 190080:
         return None, None
     pdir = os.path.join(ROOT, "profiles")
+    want = lambda line: "k_chain" in line and (not part0 or ", 10, 0>" in line)
     for name in sorted((f for f in os.listdir(pdir) if f.endswith("_chain_pmc.txt")), reverse=True):
         fetch = write = None
         for line in open(os.path.join(pdir, name)):
-            if "k_chain" in line and " FETCH_SIZE " in line:
+            if want(line) and " FETCH_SIZE " in line:
                 fetch = float(line.split("avg=")[1].split()[0])
-            if "k_chain" in line and " WRITE_SIZE " in line:
+            if want(line) and " WRITE_SIZE " in line:
                 write = float(line.split("avg=")[1].split()[0])
         if fetch is not None and write is not None:
             return fetch * 2.0 * 1024.0 + write * 1024.0, \
@@ -169,12 +171,14 @@ def respawn_under_torchrun(args):
 class Job:
     """The engines of one workload on this rank's GPU, with their inputs resident in HBM."""
 
-    def __init__(self, torch, ctx, device, workload, channels, rank, split_stages=False, streams=1, units=0):
+    def __init__(self, torch, ctx, device, workload, channels, rank, split_stages=False, streams=1, units=0, overlap=False):
         from digiham_amd import api, synth_torch
         self.torch, self.workload = torch, workload
         proto, kw, self.desc = WORKLOADS[workload]
         if split_stages:
             kw = dict(kw, split_stages=True)
+        if overlap:
+            kw = dict(kw, overlap_pushes=True)
         self.kw, self.proto = kw, proto
         parts = [(proto, kw, channels)] if workload != "mixed" else \
                 [("dmr", kw, channels[0]), ("ysf", dict(kw, proto="ysf"), channels[1])]
@@ -242,12 +246,13 @@ class Job:
         self.sync()
         return dt
 
-    def roofline(self, split_stages=False):
+    def roofline(self, split_stages=False, step_ms=None):
         """Dominant kernel of the first part: its algorithmic bytes per launch over its average
         launch duration, from the HIP events the engine records on its own stream around every launch."""
         import numpy as np
         p = self.parts[0]
         kw, B, T = p["kw"], p["B"], p["T"]
+        first_ms, first_ch = p["eng"].timing_read_split()     # pushes that went out as two launches (large DMR / YSF engines)
         rrc_ms, slicer_ms, dec_ms = p["eng"].timing_read()
         frame_bytes = int(p["eng"].frames()[1].sum()) if kw["proto"] != "none" else 0      # decoder output of the last step
         alg_bytes = B * T * 4.0 + B * (T / float(kw["sps"]))          # input f32 (4 B/sample) + dibits out (1 B per sps samples)
@@ -263,16 +268,33 @@ class Job:
             dom_name = "k_chain" if chained else "k_rrc_demod"
             if chained:
                 alg_bytes += frame_bytes            # + decoder output (<= 27 B per 1440 samples for DMR)
+        group = None
+        if dom_name == "k_chain" and len(first_ch) and first_ch.min() > 0:
+            # the push is two launches of the same kernel (template argument PART 0 / 1, listed apart by rocprofv3): the
+            # dominant one is PART 0 on the engine's high-priority stream; bytes and duration are ITS share and ITS events
+            share = float(first_ch[0]) / B
+            group = {"launches_per_push": 2, "first_launch_channels": int(first_ch[0]),
+                     "note": "overlapped pushes (DH_FLAG_OVERLAP_PUSHES): the two launches of a push and those of its neighbours "
+                             "share the chip, so a launch's own duration includes time it spends beside the others",
+                     "whole_push_algorithmic_bytes": alg_bytes, "step_period_ms": step_ms,
+                     "whole_push_frac": (alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_ms else None}
+            alg_bytes *= share
+            dom_ms = float(np.mean(first_ms))
+            B = int(first_ch[0])
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         taps = {"wide": 81, "narrow": 161, "none": 0}[kw["rrc"]]
         fir_flops = B * T * 2.0 * taps              # one mul + one add per tap and sample, unfused
-        traffic, traffic_src = profiled_traffic(self.workload, B, T) if dom_name == "k_chain" else (None, None)
+        traffic, traffic_src = profiled_traffic(self.workload, p["B"], T, part0=group is not None) if dom_name == "k_chain" else (None, None)
         mean = lambda a: float(np.mean(a)) if len(a) else None
-        return {"bound": "hbm", "kernel": dom_name + ("<%s>" % kw["proto"] if dom_name == "k_chain" else ""),
+        bounded = dom_name == "k_chain" and kw["rrc"] == "wide" and kw["sps"] == 10 and not kw.get("fast_fir")
+        return {"bound": "hbm", "kernel": dom_name + ("<%s>" % kw["proto"] if dom_name == "k_chain" else "") + (" PART 0" if group else ""),
+                "launch_group": group,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                "co_limit": {"what": "fp32 VALU (%d-tap FIR, %s)" % (taps, "FMA" if kw.get("fast_fir") else "unfused mul+add for bit-exactness"),
+                "co_limit": {"what": "fp32 VALU (%d-tap FIR, %s)" % (taps, "FMA" if kw.get("fast_fir") else
+                                                                       "FMA with a proven error radius, undecided comparisons re-evaluated with the reference's rounded arithmetic: bit-exact output"
+                                                                       if bounded else "unfused mul+add for bit-exactness"),
                              "achieved_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops": 157.3}}, \
                {"rrc": mean(rrc_ms), "slicer": mean(slicer_ms), "decoder": mean(dec_ms)}
 
@@ -335,12 +357,16 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
     """The remaining single-GPU BASELINE configs on the same lease (each its own engines, inputs resident, same timing
     method as the headline)."""
     out = []
-    for workload, channels in (("rrc_gfsk", 4096), ("rrc_gfsk_fast", 4096), ("ysf_full", 16384), ("mixed", (8192, 8192))):
+    for workload, channels, overlap in (("rrc_gfsk", 4096, False), ("rrc_gfsk_fast", 4096, False), ("ysf_full", 16384, False),
+                                        ("mixed", (8192, 8192), False), ("dmr_full", 16384, True), ("ysf_full", 16384, True)):
         t_start = time.perf_counter()
-        job = Job(torch, ctx, device, workload, channels, rank=0)
+        job = Job(torch, ctx, device, workload, channels, rank=0, overlap=overlap)
         dt = job.timed(steps, warmup)
-        roof, stage = job.roofline()
-        entry = {"workload": workload, "config": "%s channels x %d samples: %s" % (channels, job.parts[0]["T"], job.desc),
+        roof, stage = job.roofline(step_ms=dt / steps * 1e3)
+        entry = {"workload": workload + (" --overlap" if overlap else ""),
+                 "config": "%s channels x %d samples: %s%s" % (channels, job.parts[0]["T"], job.desc,
+                                                              "; pushes overlapped on the engine's own streams (DH_FLAG_OVERLAP_PUSHES)" if overlap else ""),
+                 "launch_group": roof.get("launch_group"),
                  "steps": steps, "ms_per_step": dt / steps * 1e3, "value": job.samples_per_step * steps / dt / SAMPLE_RATE, "unit": "channels",
                  "kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "frac": roof["frac"], "stage_ms": stage}
         if verify:
@@ -368,6 +394,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--split-stages", action="store_true", help="slicer and decoder as two kernels (per-stage timing)")
+    ap.add_argument("--overlap", action="store_true", help="DH_FLAG_OVERLAP_PUSHES: pushes as two launches on the engine's own streams, joined at the end")
     ap.add_argument("--verify", type=int, default=8, help="channels checked bit-exact against the oracle after the run")
     args = ap.parse_args()
 
@@ -397,12 +424,12 @@ def main():
             channels = hi - lo
     else:
         channels = (args.channels // 2, args.channels - args.channels // 2) if mixed else args.channels
-    job = Job(torch, ctx, device, args.workload, channels, rank, split_stages=args.split_stages, streams=args.streams, units=args.units)
+    job = Job(torch, ctx, device, args.workload, channels, rank, split_stages=args.split_stages, streams=args.streams, units=args.units, overlap=args.overlap)
 
     dt = job.timed(args.steps, args.warmup, barrier=shard.barrier)
     samples = job.samples_per_step * args.steps
     dt_max, samples_all = shard.reduce_report(dt, samples, device)
-    roof, stage = job.roofline(args.split_stages)
+    roof, stage = job.roofline(args.split_stages, step_ms=dt / args.steps * 1e3)
 
     verified = None
     if args.verify and not (job.kw["proto"] == "none" and not job.kw.get("keep_filtered")):
@@ -429,7 +456,7 @@ def main():
                        "channels_per_gpu": sum(per_gpu), "samples_per_channel_per_step": T,
                        "total_channels": int(round(samples_all / args.steps / T)) if not mixed else
                                          (args.total_channels if args.scaling == "strong" else sum(per_gpu) * world),
-                       "sharding": "channels, no collective", "streams": args.streams},
+                       "sharding": "channels, no collective", "streams": args.streams, "overlap_pushes": bool(args.overlap)},
             "msamples_per_s": rate / 1e6,
             "roofline": roof, "stage_ms": stage, "verified": verified,
         }

@@ -15,7 +15,7 @@ RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2, "custom": 3}
 DEMOD = {"none": 0, None: 0, "fsk": 2, "fsk2": 2, "gfsk": 4, "gfsk4": 4}
 PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3, "pocsag": 4, "dstar": 5}
 FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED_TIMING, FLAG_SPLIT_STAGES = 1, 2, 4, 8, 16, 32
-FLAG_EXACT_SYMBOLS, FLAG_EXACT_FIR = 64, 128
+FLAG_EXACT_SYMBOLS, FLAG_EXACT_FIR, FLAG_OVERLAP_PUSHES = 64, 128, 256
 
 
 class EngineConfig(C.Structure):
@@ -65,6 +65,7 @@ def declare(L, lenient=False):
         "dh_engine_sync": [vp],
         "dh_engine_timing_enable": [vp, u32],
         "dh_engine_timing_read": [vp, vp, vp, vp, C.POINTER(u32)],
+        "dh_engine_timing_read_split": [vp, vp, vp, C.POINTER(u32)],
         "dh_engine_timing_stats": [vp, vp, vp],
         "dh_engine_debug_header": [vp, u32, vp],
     }
@@ -87,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "dh_engine_set_slot_filter", "dh_engine_push", "dh_engine_push_host", "dh_engine_push_symbols",
     "dh_engine_filtered", "dh_engine_symbols", "dh_engine_frames", "dh_engine_events", "dh_engine_read_symbols",
     "dh_engine_read_frames", "dh_engine_read_events", "dh_engine_read_filtered", "dh_engine_sync",
-    "dh_engine_timing_enable", "dh_engine_timing_read", "dh_engine_timing_stats", "dh_engine_debug_header",
+    "dh_engine_timing_enable", "dh_engine_timing_read", "dh_engine_timing_read_split", "dh_engine_timing_stats", "dh_engine_debug_header",
 ]
 
 _LIB = None

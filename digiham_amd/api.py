@@ -169,7 +169,7 @@ class Engine:
 
     def __init__(self, n_channels, max_samples, rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=False,
                  keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False, split_stages=False,
-                 taps=None, gain=None, exact_symbols=False, exact_fir=False):
+                 taps=None, gain=None, exact_symbols=False, exact_fir=False, overlap_pushes=False):
         """rrc = "custom" takes the caller's coefficient table: `taps` (nZeros + 1 floats, any shape) and `gain`, as
         Digiham::RrcFilter::RrcFilter(nZeros, gain, coeffs[]) does (include/rrc_filter.hpp:12)."""
         self.ctx = ctx if ctx is not None else Context(device=device)
@@ -177,7 +177,8 @@ class Engine:
         flags = (_capi.FLAG_FAST_FIR if fast_fir else 0) | (_capi.FLAG_KEEP_FILTERED if keep_filtered else 0) | \
                 (_capi.FLAG_FSK_INVERT if invert else 0) | (0 if events else _capi.FLAG_NO_EVENTS) | \
                 (_capi.FLAG_ORDERED_TIMING if ordered_timing else 0) | (_capi.FLAG_SPLIT_STAGES if split_stages else 0) | \
-                (_capi.FLAG_EXACT_SYMBOLS if exact_symbols else 0) | (_capi.FLAG_EXACT_FIR if exact_fir else 0)
+                (_capi.FLAG_EXACT_SYMBOLS if exact_symbols else 0) | (_capi.FLAG_EXACT_FIR if exact_fir else 0) | \
+                (_capi.FLAG_OVERLAP_PUSHES if overlap_pushes else 0)
         cfg = _capi.EngineConfig(C.sizeof(_capi.EngineConfig), getattr(mem, "index", 0), n_channels, max_samples,
                                  _capi.RRC[rrc], _capi.DEMOD[demod], sps, _capi.PROTO[proto], flags, slot_filter,
                                  mem.stream())
@@ -251,6 +252,16 @@ class Engine:
         _check(self.ctx.lib.dh_engine_timing_read(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                                   c.ctypes.data_as(C.c_void_p), C.byref(n)), "dh_engine_timing_read", self.ctx.lib)
         return a[:n.value], b[:n.value], c[:n.value]
+
+    def timing_read_split(self):
+        """(first_ms, first_channels) per push since the last timing_read: duration and channel count of the first of the
+        two launches of a push of a large engine with overlap_pushes (zeros otherwise).  Call before timing_read()."""
+        cap = getattr(self, "_timing_cap", 0)
+        a, c = np.zeros(max(cap, 1), np.float32), np.zeros(max(cap, 1), np.uint32)
+        n = C.c_uint32(cap)
+        _check(self.ctx.lib.dh_engine_timing_read_split(self._h, a.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.byref(n)),
+               "dh_engine_timing_read_split", self.ctx.lib)
+        return a[:n.value], c[:n.value]
 
     def timing_stats(self):
         """(blocks, ordered) per channel: 100-symbol timing blocks evaluated, and those decided by the in-order chain."""

@@ -174,6 +174,11 @@ int dh_engine_read_filtered(dh_engine* e, uint32_t ch, float* h, size_t* n) {
     return DH_OK;
 }
 int dh_engine_timing_enable(dh_engine* e, uint32_t max_pushes) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.be.timing_enable(max_pushes); }
+int dh_engine_timing_read_split(dh_engine* e, float* first_ms, uint32_t* first_channels, uint32_t* n) {
+    if (!e || !n) return DH_EINVAL;
+    DH_ON_DEVICE(e);
+    return e->impl.be.timing_read_split(first_ms, first_channels, n);
+}
 int dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float* decoder_ms, uint32_t* n) {
     if (!e || !n) return DH_EINVAL;
     DH_ON_DEVICE(e);

@@ -60,6 +60,7 @@ struct DhDspParams {
     uint32_t sym_cap;                                  // max symbols a push may append per channel
     uint32_t* overflow;                                // set to 1 if sym_cap was hit
     uint32_t n_channels;
+    uint32_t ch_base;                                  // first channel of this launch (a push may go out as two launches, engine.hip)
     uint32_t sps, lo, hi;                              // samples/symbol, [lo,hi) = mid-symbol evaluation window
     int32_t levels, invert;                            // 4 = GFSK, 2 = FSK
     uint32_t nz;                                       // FIR order (0 = no RRC stage)

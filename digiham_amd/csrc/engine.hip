@@ -40,6 +40,9 @@ int hip_fail(hipError_t e, const char* what) {
 #ifndef DH_LB_NARROW
 #define DH_LB_NARROW 2   // the 161-tap kernels: 256 VGPRs
 #endif
+#ifndef DH_SPLIT_MIN_CHANNELS
+#define DH_SPLIT_MIN_CHANNELS 8192   // DH_FLAG_OVERLAP_PUSHES takes effect for engines at least this large (HipBackend::go_chain)
+#endif
 #ifndef DH_LB
 #define DH_LB 4          // minimum waves per SIMD the wide-filter kernels are register-budgeted for (128 VGPRs)
 #endif
@@ -57,28 +60,32 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_r
 // its stalls are covered by the other wavefronts' FIR arithmetic instead of by nothing, as in a separate launch.
 // The two stages use the LDS block one after the other.
 // SPS = 10 is the specialised slicer of the DMR / YSF / D-Star pipes, SPS = 0 takes the run-time value (NXDN: 20).
-template <int NZ, bool FAST, int PROTO, int SPS = 10>
+// PART only names the launch: with DH_FLAG_OVERLAP_PUSHES a push of a large engine goes out as two launches (PART 0 =
+// the first channels on the engine's high-priority stream, PART 1 = the rest on its normal-priority one; see
+// HipBackend::go_chain), and profilers should list them apart.
+template <int NZ, bool FAST, int PROTO, int SPS = 10, int PART = 0>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_chain(const DhDspParams P, const DhDecParams D) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
+    const uint32_t ch = blockIdx.x + P.ch_base;
     {
         DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
-        dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, L);
+        dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, L);
     }
     __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
     __syncthreads();
 #if DH_PRIO_MODE >= 1 && DH_PRIO_MODE <= 5
     DH_SETPRIO(3);
 #elif DH_PRIO_MODE >= 6
-    if (blockIdx.x + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
+    if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
 #endif
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
 #ifdef DH_SKIP_DECODER                      // diagnostic builds (tools/phase_budget.sh): the slicer half alone
     if (P.n_channels) return;
 #endif
-    if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, blockIdx.x, S);
-    else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, blockIdx.x, S);
-    else if (PROTO == DH_PROTO_NXDN) dh_nxdn_channel(D, blockIdx.x, S);
-    else dh_ysf_channel(D, blockIdx.x, S);
+    if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, ch, S);
+    else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, ch, S);
+    else if (PROTO == DH_PROTO_NXDN) dh_nxdn_channel(D, ch, S);
+    else dh_ysf_channel(D, ch, S);
 }
 
 template <int NZ, bool FAST>
@@ -290,62 +297,131 @@ struct HipBackend {
         device = dev; stream = (hipStream_t) s;
         return DH_OK;
     }
-    void close() {                                   // engine teardown: the timing events go with it
+    void drop_timing_events() {
         for (hipEvent_t e : ev) if (e) (void) hipEventDestroy(e);
         ev.clear(); ev_cap = ev_n = 0;
     }
+    void close() {                                   // engine teardown: the timing events and the engine's own streams go with it
+        if (join_pending) { (void) hipStreamSynchronize(side); (void) hipStreamSynchronize(side_lo); }
+        drop_timing_events();
+        drop_side();
+        side_failed = false;
+    }
+
+    // ---- overlapped pushes (DH_FLAG_OVERLAP_PUSHES; engines of >= DH_SPLIT_MIN_CHANNELS DMR / YSF channels).
+    // The last wavefronts of a launch run on a draining chip (one wavefront per channel, ~2.5 ms each: about 1 ms of a
+    // 10 ms step), and on ONE stream the next push cannot start before the last wavefront of this one has gone.  In this
+    // mode a push goes out as two launches on two streams of the engine's own -- three quarters of the channels at HIGH
+    // priority, the rest at normal priority -- that depend on the caller's stream only through the moment of the push
+    // (the input is ready) and on their own predecessors (the channels' state).  The dispatcher places low-priority
+    // workgroups exactly when the high-priority launch has none left, so the second launch fills the drain of the first
+    // and the first launch of the NEXT push fills the drain of the second.  The caller's stream is joined again when
+    // anything is read, reset or synchronised through the engine: until then the INPUT BUFFER OF A PUSH MUST STAY
+    // UNTOUCHED (that is the contract of the flag).  Measured: -6..8 % step time at 8 192 .. 32 768 channels.
+    bool overlap_pushes = false;
+    hipStream_t side = nullptr, side_lo = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_lo = nullptr;
+    bool side_failed = false, join_pending = false;
+    bool side_ready() {
+        if (side) return true;
+        if (side_failed) return false;
+        int least = 0, greatest = 0;
+        bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+                  hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest) == hipSuccess &&
+                  hipStreamCreateWithPriority(&side_lo, hipStreamNonBlocking, least) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_join_lo, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void) hipGetLastError(); drop_side(); side_failed = true; }      // no stream priorities here: plain launches
+        return ok;
+    }
+    void drop_side() {
+        for (hipEvent_t* e : { &ev_fork, &ev_join, &ev_join_lo }) { if (*e) (void) hipEventDestroy(*e); *e = nullptr; }
+        for (hipStream_t* t : { &side, &side_lo }) { if (*t) (void) hipStreamDestroy(*t); *t = nullptr; }
+        join_pending = false;
+    }
+    // the caller's stream, once everything the engine has in flight on its own streams is ordered before it
+    hipStream_t ms() {
+        if (join_pending) {
+            join_pending = false;
+            (void) hipStreamWaitEvent(stream, ev_join, 0);
+            (void) hipStreamWaitEvent(stream, ev_join_lo, 0);
+        }
+        return stream;
+    }
+
     void* alloc(size_t bytes) {
         void* p = nullptr;
         if (hip_fail(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc")) return nullptr;
         return p;
     }
     void free(void* p) { (void) hipFree(p); }
-    int zero(void* p, size_t bytes) { return hip_fail(hipMemsetAsync(p, 0, bytes, stream), "hipMemsetAsync"); }
+    int zero(void* p, size_t bytes) { return hip_fail(hipMemsetAsync(p, 0, bytes, ms()), "hipMemsetAsync"); }
     int upload(void* dst, const void* src, size_t bytes) {
         // pageable source: hipMemcpyAsync stages it before returning, so the caller may free `src`
-        return hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)");
+        return hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ms()), "hipMemcpyAsync(H2D)");
     }
     int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
         if (!width || !rows) return 0;
-        if (hip_fail(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, stream), "hipMemcpy2DAsync(D2H)")) return -1;
-        return hip_fail(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        if (hip_fail(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, ms()), "hipMemcpy2DAsync(D2H)")) return -1;
+        return hip_fail(hipStreamSynchronize(ms()), "hipStreamSynchronize");
     }
     int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
         if (!width || !rows) return 0;
-        return hip_fail(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, stream), "hipMemcpy2DAsync(H2D)");
+        return hip_fail(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, ms()), "hipMemcpy2DAsync(H2D)");
     }
     int download(void* dst, const void* src, size_t bytes) {
-        if (hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)")) return -1;
-        return hip_fail(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        if (hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ms()), "hipMemcpyAsync(D2H)")) return -1;
+        return hip_fail(hipStreamSynchronize(ms()), "hipStreamSynchronize");
     }
-    int sync() { return hip_fail(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    int sync() { return hip_fail(hipStreamSynchronize(ms()), "hipStreamSynchronize"); }
     int launched(const char* what) { return hip_fail(hipGetLastError(), what); }
 
-    // per-push stage timestamps: 4 events per recorded push
+    // per-push stage timestamps: 6 events per recorded push (0..3 on the caller's stream, 4..5 around the first launch of a
+    // split push on the side stream)
     std::vector<hipEvent_t> ev;
+    std::vector<uint32_t> ev_first_part;
     uint32_t ev_cap = 0, ev_n = 0;
     int timing_enable(uint32_t max_pushes) {
-        close();
-        ev.assign((size_t) max_pushes * 4, nullptr);
+        drop_timing_events();
+        ev.assign((size_t) max_pushes * 6, nullptr);
+        ev_first_part.assign(max_pushes, 0u);
         for (auto& e : ev) if (hip_fail(hipEventCreate(&e), "hipEventCreate")) { close(); return DH_EDEVICE; }   // all or nothing
         ev_cap = max_pushes;
         return DH_OK;
     }
-    void timing_mark(int k) { if (ev_n < ev_cap) (void) hipEventRecord(ev[(size_t) ev_n * 4 + k], stream); }
+    void timing_mark(int k) {
+        if (ev_n >= ev_cap) return;
+        if (k == 0) ev_first_part[ev_n] = 0;
+        (void) hipEventRecord(ev[(size_t) ev_n * 6 + k], k < 4 ? stream : side);
+    }
     void timing_next() { if (ev_n < ev_cap) ev_n++; }
     int timing_read(float* rrc, float* slicer, float* decoder, uint32_t* n) {
         if (sync()) return DH_EDEVICE;
         const uint32_t cnt = ev_n < *n ? ev_n : *n;
         for (uint32_t i = 0; i < cnt; i++) {
             float a = 0, b = 0, c = 0;
-            HIP_TRY(hipEventElapsedTime(&a, ev[i * 4 + 0], ev[i * 4 + 1]));
-            HIP_TRY(hipEventElapsedTime(&b, ev[i * 4 + 1], ev[i * 4 + 2]));
-            HIP_TRY(hipEventElapsedTime(&c, ev[i * 4 + 2], ev[i * 4 + 3]));
+            HIP_TRY(hipEventElapsedTime(&a, ev[i * 6 + 0], ev[i * 6 + 1]));
+            HIP_TRY(hipEventElapsedTime(&b, ev[i * 6 + 1], ev[i * 6 + 2]));
+            HIP_TRY(hipEventElapsedTime(&c, ev[i * 6 + 2], ev[i * 6 + 3]));
             if (rrc) rrc[i] = a;
             if (slicer) slicer[i] = b;
             if (decoder) decoder[i] = c;
         }
         *n = cnt; ev_n = 0;
+        return DH_OK;
+    }
+    // the first launch of each recorded push that went out as two (call before timing_read, which starts a new series)
+    int timing_read_split(float* first_ms, uint32_t* first_channels, uint32_t* n) {
+        if (sync()) return DH_EDEVICE;
+        const uint32_t cnt = ev_n < *n ? ev_n : *n;
+        for (uint32_t i = 0; i < cnt; i++) {
+            float a = 0;
+            if (ev_first_part[i]) HIP_TRY(hipEventElapsedTime(&a, ev[i * 6 + 4], ev[i * 6 + 5]));
+            if (first_ms) first_ms[i] = a;
+            if (first_channels) first_channels[i] = ev_first_part[i];
+        }
+        *n = cnt;
         return DH_OK;
     }
 
@@ -355,7 +431,7 @@ struct HipBackend {
             if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
                          "hipFuncSetAttribute")) return -1;
         }
-        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST, SPS>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P);
+        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST, SPS>), dim3(P.n_channels), dim3(DH_WAVE), lds, ms(), P);
         return launched("k_rrc_demod");
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
@@ -368,13 +444,34 @@ struct HipBackend {
         if (nz == 160) return fast ? go_rrc_demod<160, true, 0>(P) : go_rrc_demod<160, false, 0>(P);
         return -1;
     }
-    template <int NZ, bool FAST, int PROTO, int SPS = 10> int go_chain(const DhDspParams& P, const DhDecParams& D) {
+    template <int NZ, bool FAST, int PROTO, int SPS = 10, bool MAY_SPLIT = false> int go_chain(const DhDspParams& P, const DhDecParams& D) {
         size_t lds = dh_dsp_shared_bytes(SPS ? (uint32_t) SPS : P.sps, NZ);
         if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
 #ifdef DH_LDS_PAD
         lds += DH_LDS_PAD;                  // occupancy experiments (tools/build_variant.sh)
 #endif
-        hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS>), dim3(P.n_channels), dim3(DH_WAVE), lds, stream, P, D);
+        if constexpr (MAY_SPLIT) {
+            if (overlap_pushes && P.n_channels >= DH_SPLIT_MIN_CHANNELS && side_ready()) {
+                const uint32_t first = (P.n_channels - P.n_channels / 4u) & ~63u;       // three quarters, whole multiples of 64
+                DhDspParams Q = P;
+                Q.ch_base = first;
+                // (the caller's stream is NOT joined first: work of earlier pushes still in flight on the engine's streams
+                // is ordered before these launches by those streams themselves)
+                if (hip_fail(hipEventRecord(ev_fork, stream), "hipEventRecord") ||
+                    hip_fail(hipStreamWaitEvent(side, ev_fork, 0), "hipStreamWaitEvent") ||
+                    hip_fail(hipStreamWaitEvent(side_lo, ev_fork, 0), "hipStreamWaitEvent")) return -1;
+                if (ev_n < ev_cap) ev_first_part[ev_n] = first;
+                timing_mark(4);
+                hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 0>), dim3(first), dim3(DH_WAVE), lds, side, P, D);
+                timing_mark(5);
+                hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 1>), dim3(P.n_channels - first), dim3(DH_WAVE), lds, side_lo, Q, D);
+                if (hip_fail(hipEventRecord(ev_join, side), "hipEventRecord") ||
+                    hip_fail(hipEventRecord(ev_join_lo, side_lo), "hipEventRecord")) return -1;
+                join_pending = true;
+                return launched("k_chain");
+            }
+        }
+        hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 0>), dim3(P.n_channels), dim3(DH_WAVE), lds, ms(), P, D);
         return launched("k_chain");
     }
     // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
@@ -387,11 +484,11 @@ struct HipBackend {
         const bool dmr = proto == DH_PROTO_DMR;
         if (nz == 0) return dmr ? go_chain<0, false, DH_PROTO_DMR>(P, D) : go_chain<0, false, DH_PROTO_YSF>(P, D);
         if (fast) return dmr ? go_chain<80, true, DH_PROTO_DMR>(P, D) : go_chain<80, true, DH_PROTO_YSF>(P, D);
-        return dmr ? go_chain<80, false, DH_PROTO_DMR>(P, D) : go_chain<80, false, DH_PROTO_YSF>(P, D);
+        return dmr ? go_chain<80, false, DH_PROTO_DMR, 10, true>(P, D) : go_chain<80, false, DH_PROTO_YSF, 10, true>(P, D);     // the headline pipes
     }
     template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
-        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3((tiles + DH_TILES_PER_WG - 1) / DH_TILES_PER_WG, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), stream, R);
+        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3((tiles + DH_TILES_PER_WG - 1) / DH_TILES_PER_WG, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), ms(), R);
         return launched("k_rrc_tile");
     }
     int launch_rrc_tiles(const DhRrcParams& R, uint32_t nz, bool fast) {
@@ -400,27 +497,27 @@ struct HipBackend {
         return -1;
     }
     int launch_rrc_generic(const DhRrcGenParams& G) {
-        hipLaunchKernelGGL(k_rrc_generic, dim3((G.n + DH_FTILE - 1) / DH_FTILE, G.n_channels), dim3(DH_WAVE), 0, stream, G);
+        hipLaunchKernelGGL(k_rrc_generic, dim3((G.n + DH_FTILE - 1) / DH_FTILE, G.n_channels), dim3(DH_WAVE), 0, ms(), G);
         return launched("k_rrc_generic");
     }
     int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {
-        hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, stream, hist, in, in_stride, n, nz);
+        hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, ms(), hist, in, in_stride, n, nz);
         return launched("k_rrc_hist");
     }
     int launch_decoder(const DhDecParams& P, int proto) {
-        if (proto == DH_PROTO_DMR) hipLaunchKernelGGL(k_dmr, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
-        else if (proto == DH_PROTO_YSF) hipLaunchKernelGGL(k_ysf, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
-        else if (proto == DH_PROTO_NXDN) hipLaunchKernelGGL(k_nxdn, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
-        else if (proto == DH_PROTO_POCSAG) hipLaunchKernelGGL(k_pocsag, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
-        else hipLaunchKernelGGL(k_dstar, dim3(P.n_channels), dim3(DH_WAVE), 0, stream, P);
+        if (proto == DH_PROTO_DMR) hipLaunchKernelGGL(k_dmr, dim3(P.n_channels), dim3(DH_WAVE), 0, ms(), P);
+        else if (proto == DH_PROTO_YSF) hipLaunchKernelGGL(k_ysf, dim3(P.n_channels), dim3(DH_WAVE), 0, ms(), P);
+        else if (proto == DH_PROTO_NXDN) hipLaunchKernelGGL(k_nxdn, dim3(P.n_channels), dim3(DH_WAVE), 0, ms(), P);
+        else if (proto == DH_PROTO_POCSAG) hipLaunchKernelGGL(k_pocsag, dim3(P.n_channels), dim3(DH_WAVE), 0, ms(), P);
+        else hipLaunchKernelGGL(k_dstar, dim3(P.n_channels), dim3(DH_WAVE), 0, ms(), P);
         return launched("k_decoder");
     }
     int launch_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
-        hipLaunchKernelGGL(k_init_state, dim3((B + 255) / 256), dim3(256), 0, stream, dsp_state, state_words, tail0, dec_state, slot_filter, B);
+        hipLaunchKernelGGL(k_init_state, dim3((B + 255) / 256), dim3(256), 0, ms(), dsp_state, state_words, tail0, dec_state, slot_filter, B);
         return launched("k_init_state");
     }
     int launch_set_slot_filter(uint32_t* dec_state, uint32_t filter, uint32_t B) {
-        hipLaunchKernelGGL(k_set_slot_filter, dim3((B + 255) / 256), dim3(256), 0, stream, dec_state, filter, B);
+        hipLaunchKernelGGL(k_set_slot_filter, dim3((B + 255) / 256), dim3(256), 0, ms(), dec_state, filter, B);
         return launched("k_set_slot_filter");
     }
 };

@@ -97,6 +97,7 @@ inline void fill_taps(int rrc, float* half, double* gain) {
 //   int launch_set_slot_filter(uint32_t* dec_state, uint32_t filter, uint32_t B);
 //   void timing_mark(int k); void timing_next();            // optional per-push stage timestamps (k = 0..3)
 //   int timing_enable(uint32_t max_pushes); int timing_read(float* rrc, float* slicer, float* decoder, uint32_t* n);
+//   int timing_read_split(float* first_ms, uint32_t* first_channels, uint32_t* n); bool overlap_pushes;
 template <class BE>
 struct Engine {
     BE be;
@@ -122,6 +123,7 @@ struct Engine {
     int init(const dh_engine_config& c) {
         int rc = make_layout(c, L);
         if (rc) return rc;
+        be.overlap_pushes = (L.flags & DH_FLAG_OVERLAP_PUSHES) != 0;
         slot_filter = c.slot_filter;
         const size_t B = L.B;
 #define DH_ALLOC(ptr, type, count) do { ptr = (type*) be.alloc(sizeof(type) * (size_t) (count)); if (!ptr) return DH_ENOMEM; } while (0)

@@ -109,6 +109,12 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3,
 #define DH_FLAG_ORDERED_TIMING  0x10  /* always run the in-order variance chain of the timing recovery (diagnostic; results are identical) */
 #define DH_FLAG_EXACT_SYMBOLS   0x40  /* error-bounded kernels: decide EVERY symbol with the reference's arithmetic (diagnostic; results are identical) */
 #define DH_FLAG_EXACT_FIR       0x80  /* error-bounded kernels: run the rounded-product FIR in every run (diagnostic / A-B; results are identical) */
+#define DH_FLAG_OVERLAP_PUSHES  0x100 /* engines of >= 8192 DMR / YSF channels: a push goes out as two launches on two streams of the engine's
+                                         own (three quarters of the channels at high priority, the rest at normal priority) which are ordered
+                                         after the caller's stream at the moment of the push and joined with it again only when results are
+                                         read, the engine is reset / synchronised or another kind of work is queued -- so the drain of one
+                                         launch is filled by the next, across pushes.  CONTRACT: the input buffer of a push must stay
+                                         untouched until dh_engine_sync() (or any read) returns.  Results are identical. */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(dh_engine_config) */
@@ -196,6 +202,10 @@ int  dh_engine_read_filtered(dh_engine* e, uint32_t channel, float* h_out, size_
  * kernel and the decoder kernel.  *n in: capacity of the arrays, out: pushes recorded. */
 int  dh_engine_timing_enable(dh_engine* e, uint32_t max_pushes);
 int  dh_engine_timing_read(dh_engine* e, float* rrc_ms, float* slicer_ms, float* decoder_ms, uint32_t* n);
+/* For pushes that went out as two launches (DH_FLAG_OVERLAP_PUSHES): duration of the FIRST launch alone (events on the
+ * engine's high-priority stream) and the number of channels it covered (0 / 0 for a push with one launch).  Call BEFORE
+ * dh_engine_timing_read, which starts a new series; the stage times of such a push on the caller's stream are ~0. */
+int  dh_engine_timing_read_split(dh_engine* e, float* first_ms, uint32_t* first_channels, uint32_t* n);
 /* Timing-recovery statistics since create/reset, per channel (host arrays of n_channels, either may be NULL):
  * blocks = 100-symbol variance blocks evaluated (gfsk_demodulator.cpp:41-80), ordered = those in which the
  * error-bounded estimate could not separate the phases and the reference's in-order sums decided. Synchronises. */

@@ -44,6 +44,8 @@ struct HostBackend {
     void timing_next() {}
     int timing_enable(uint32_t) { return 0; }
     int timing_read(float*, float*, float*, uint32_t* n) { *n = 0; return 0; }
+    int timing_read_split(float*, uint32_t*, uint32_t* n) { *n = 0; return 0; }
+    bool overlap_pushes = false;                     // (a property of the GPU dispatcher; nothing to emulate)
 
     template <int NZ, bool FAST, int SPS> static void run_rrc_demod(const DhDspParams& P) {
         std::vector<float> lds(dh_dsp_shared_bytes(P.sps, NZ) / sizeof(float));     // exactly the device allocation

@@ -108,3 +108,47 @@ def test_mixed_dmr_ysf_engines_on_two_streams(gpu_ctx, oracle):
             assert len(gf) == ref["out_count"][b] and (gf == ref["out"][b, :len(gf)]).all()
             assert ge.tobytes() == ref["events"][b, :ref["event_count"][b]].tobytes()
         assert sum(int(o[3].sum()) for o in p["outs"]) > 0
+
+
+@pytest.mark.parametrize("proto", ["dmr", "ysf"])
+def test_overlapped_pushes_equal_plain_pushes(gpu_ctx, proto):
+    """DH_FLAG_OVERLAP_PUSHES: engines of >= 8192 DMR / YSF channels send a push as two launches on two streams of
+    their own and join the caller's stream only when something is read.  Same bytes as plain pushes (ragged channel
+    count, three pushes queued back to back before the first read), and the timing interface says what happened."""
+    import torch
+    from digiham_amd import api, synth_torch
+    B, U = 8192 + 192, 64
+    base, info = synth_torch.make_batch(torch, gpu_ctx.mem.device, proto, U, 16 if proto == "dmr" else 6, U=U, seed=777)
+    T = info["samples_per_channel"]
+    third = T // 3 // 10 * 10
+    x = base.repeat(B // U, 1).contiguous()
+    chunks = [x[:, :third].contiguous(), x[:, third:2 * third].contiguous(), x[:, 2 * third:].contiguous()]   # stay alive until the read
+    got = []
+    for overlap in (True, False):
+        eng = api.Engine(B, T, proto=proto, ctx=gpu_ctx, overlap_pushes=overlap)
+        eng.timing_enable(4)
+        for c in chunks:
+            eng.push(c)                                          # nothing read in between: with the flag the three pushes overlap
+        eng.sync()
+        outs = [tuple(a.copy() for pair in (eng.symbols(), eng.frames(), eng.events()) for a in pair)]      # of the last push
+        first_ms, first_ch = eng.timing_read_split()
+        eng.timing_read()
+        assert len(first_ch) == 3
+        if overlap:
+            assert (first_ch == (B - B // 4) // 64 * 64).all() and (first_ms > 0).all()
+        else:
+            assert (first_ch == 0).all() and (first_ms == 0).all()
+        eng.reset()                                              # joins the caller's stream, then overlapped again
+        eng.push(x)
+        outs.append(tuple(a.copy() for pair in (eng.symbols(), eng.frames(), eng.events()) for a in pair))
+        eng.close()
+        got.append(outs)
+    for a, b in zip(*got):
+        s, sc, f, fc, e, ec = a
+        s2, sc2, f2, fc2, e2, ec2 = b
+        assert (sc == sc2).all() and (fc == fc2).all() and (ec == ec2).all()
+        for ch in range(B):
+            assert (s[ch, :sc[ch]] == s2[ch, :sc[ch]]).all()
+            assert (f[ch, :fc[ch]] == f2[ch, :fc[ch]]).all()
+            assert e[ch, :ec[ch]].tobytes() == e2[ch, :ec[ch]].tobytes()
+    assert int(got[0][1][3].sum()) > 0

@@ -7,7 +7,7 @@ import numpy as np, torch
 from digiham_amd import api, synth_torch
 proto = sys.argv[1] if len(sys.argv) > 1 else "dmr"
 shares = [tuple(float(v) for v in a.split(",")) for a in sys.argv[2:]] or [(1.0,), (0.75,), (0.8,), (0.85,), (0.9,), (0.6, 0.3), (0.5, 0.3), (0.55, 0.3, 0.1)]
-B = 16384
+B = int(os.environ.get("SS_B", "16384"))
 dev = torch.device("cuda", 0)
 x, info = synth_torch.make_batch(torch, dev, proto, B, 132 if proto == "dmr" else 40, seed=1000)
 T = info["samples_per_channel"]
@@ -21,8 +21,10 @@ for share in shares:
         cuts.append(B)
     parts = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
     engs = []
-    for lo, hi in parts:
-        with torch.cuda.stream(torch.cuda.Stream(dev)):
+    prio = os.environ.get('SS_PRIO')                  # "1": the first (largest) part on a high-priority stream, the rest low
+    for i, (lo, hi) in enumerate(parts):
+        st = torch.cuda.Stream(dev) if not prio else torch.cuda.Stream(dev, priority=(-1 if i == 0 else 0))
+        with torch.cuda.stream(st):
             engs.append((api.Engine(hi - lo, T, proto=proto, ctx=ctx), x[lo:hi]))
     torch.cuda.synchronize()
     for _ in range(2):
