@@ -331,6 +331,9 @@ template <int O0, int O1> __device__ __forceinline__ dh_f2 dh_lds_read2(uint32_t
 }
 // pair i of the slide sequence: (x[8 + i], x[16 + i]), consumed when tap i has been accumulated
 template <int NZ, int I> __device__ __forceinline__ void dh_fir_issue_one(uint32_t addr, dh_f2& d) {
+#ifdef DH_FIR_EXTRA_READS                   // diagnostic builds: every DH_FIR_EXTRA_READS-th window read is issued twice (how much does LDS traffic cost?)
+    if constexpr (I < NZ && I % DH_FIR_EXTRA_READS == 0) { dh_f2 extra = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr); asm volatile("" :: "v"(extra)); }
+#endif
     if constexpr (I < NZ) d = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr);
     else d = dh_f2_make(0.0f, 0.0f);
 }
