@@ -1175,6 +1175,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     sym = average > center ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
                 }
                 if (BOUNDED) doubt = (e_eff > 0.0f && (doubt || __builtin_fabsf(average - center) <= T)) || P.exact_mode == 1;
+#ifdef DH_IGNORE_DOUBT                      // diagnostic builds: undecided symbols are NOT re-evaluated (wrong in a few symbols per 100 000; what do the exact evaluations cost?)
+                doubt = false;
+#endif
                 if (!doubt) syms[nsym + q] = sym;
             }
             DH_BALLOT_ACC(vote_unsure, doubt, lane);
