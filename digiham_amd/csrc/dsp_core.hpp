@@ -1227,14 +1227,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             if (SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
-                DH_LANE_ARRAY(float, pmean, 1);
-                DH_LANE_ARRAY(uint32_t, prow, 1);               // word offset of this lane's 20 ring entries
+                // (nothing per lane is carried from pass to pass in registers: the compiler parks such values in scratch
+                // memory -- a store and a reload per block and lane, 2.4 GB of HBM writes per launch -- so the row offset is
+                // recomputed and the mean goes through LDS)
+                float* pmean = psum + 64;                       // psum uses [0, 50)
                 // pass 1: partial sums, two interleaved chains per lane (packed adds)
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
                         const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;     // lane / 10, lane % 10
                         const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
-                        DH_LA(prow, lane)[0] = ro;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
                         dh_f2 s2 = dh_f2_make(0.0f, 0.0f);
 #pragma unroll
@@ -1249,8 +1250,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // pass 2: squared deviations from the float mean, again two chains per lane (packed subtract + FMA)
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
-                        const uint32_t ro = DH_LA(prow, lane)[0];
-                        const uint32_t i = ro / DH_VARIANCE_SYMBOLS;
+                        const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;
+                        const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
                         const float total = (((psum[i] + psum[i + 10]) + psum[i + 20]) + psum[i + 30]) + psum[i + 40];
                         const float mean = total * 0.01f;
@@ -1263,7 +1264,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                             a2 = dh_f2_fma(d0, d0, a2); a2 = dh_f2_fma(d1, d1, a2);
                         }
                         pd[lane] = a2.x + a2.y;
-                        DH_LA(pmean, lane)[0] = mean;
+                        if (lane < 10) pmean[lane] = mean;
                     }
                 }
                 DH_BARRIER();
@@ -1276,7 +1277,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     if (lane < 10) {
                         const int i = lane;
                         const float v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) * 0.01f;
-                        const float mean = DH_LA(pmean, lane)[0];
+                        const float mean = pmean[lane];
                         const float e = __builtin_fmaf(mean, mean, v);
                         float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
                         // error-bounded mode: the ring holds values within e_blk of the reference's; moving every sample by
@@ -1301,7 +1302,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     DH_FOR_LANES_FRESH(lane) {
                         uint32_t any = 0;
                         if (lane < 50) {
-                            const uint32_t* row = reinterpret_cast<const uint32_t*>(S.var_rb + DH_LA(prow, lane)[0]);
+                            const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;
+                            const uint32_t* row = reinterpret_cast<const uint32_t*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20u);
 #pragma unroll
                             for (int q = 0; q < 20; q++) any |= row[q];
                         }
