@@ -286,8 +286,16 @@ inline dh_f2 dh_f2_fma(dh_f2 a, dh_f2 b, dh_f2 c) { return dh_f2_make(__builtin_
 template <bool FAST>
 DH_HD void dh_fir_finish(const float* acc, double gain, double rgain, float inv_gain, float* out16, bool* nonfinite = nullptr) {
     if (FAST) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        // one v_mul_f32 per output, from where the accumulator half lies to where the output is wanted: left to itself the
+        // compiler packs the multiplies and pays for it with ~29 register moves (halves gathered into pairs before, results
+        // copied into the outputs' registers after)
+#pragma unroll
+        for (int j = 0; j < DH_FIR_L; j++) asm("v_mul_f32 %0, %1, %2" : "=v"(out16[j]) : "s"(inv_gain), "v"(acc[j]));
+#else
 #pragma unroll
         for (int j = 0; j < DH_FIR_L; j++) out16[j] = acc[j] * inv_gain;
+#endif
         if (nonfinite) {                                  // NaN or infinity in any accumulator: 0 * acc is then NaN
             float t = 0.0f;
 #pragma unroll
@@ -1234,7 +1242,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // pass 1: partial sums, two interleaved chains per lane (packed adds)
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
-                        const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;     // lane / 10, lane % 10
+                        // lane = 5 i + g: eight consecutive lanes then read 16-byte pieces 20 or 40 words apart, which fall into
+                        // eight different groups of four banks (with lane = 10 g + i two of every eight collided: 50 LDS cycles
+                        // per block, all of this phase's bank conflicts)
+                        const uint32_t i = ((uint32_t) lane * 205u) >> 10, g = (uint32_t) lane - 5u * i;      // lane / 5, lane % 5
                         const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
                         dh_f2 s2 = dh_f2_make(0.0f, 0.0f);
@@ -1250,10 +1261,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // pass 2: squared deviations from the float mean, again two chains per lane (packed subtract + FMA)
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
-                        const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;
+                        const uint32_t i = ((uint32_t) lane * 205u) >> 10, g = (uint32_t) lane - 5u * i;
                         const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
-                        const float total = (((psum[i] + psum[i + 10]) + psum[i + 20]) + psum[i + 30]) + psum[i + 40];
+                        const float* ps = psum + 5u * i;
+                        const float total = (((ps[0] + ps[1]) + ps[2]) + ps[3]) + ps[4];
                         const float mean = total * 0.01f;
                         const dh_f2 m2 = dh_f2_make(mean, mean);
                         dh_f2 a2 = dh_f2_make(0.0f, 0.0f);
@@ -1264,7 +1276,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                             a2 = dh_f2_fma(d0, d0, a2); a2 = dh_f2_fma(d1, d1, a2);
                         }
                         pd[lane] = a2.x + a2.y;
-                        if (lane < 10) pmean[lane] = mean;
+                        if (g == 0) pmean[i] = mean;
                     }
                 }
                 DH_BARRIER();
@@ -1276,7 +1288,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     bool guard = true, vzero = false;
                     if (lane < 10) {
                         const int i = lane;
-                        const float v = ((((pd[i] + pd[i + 10]) + pd[i + 20]) + pd[i + 30]) + pd[i + 40]) * 0.01f;
+                        const float v = ((((pd[5 * i] + pd[5 * i + 1]) + pd[5 * i + 2]) + pd[5 * i + 3]) + pd[5 * i + 4]) * 0.01f;
                         const float mean = pmean[lane];
                         const float e = __builtin_fmaf(mean, mean, v);
                         float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
