@@ -804,7 +804,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const uint32_t ev_lo = SPS == 10 ? 3u : P.lo, ev_hi = SPS == 10 ? 7u : P.hi;
     const float sps_rcp = 1.0f / (float) sps;           // correctly rounded (IEEE division, once per push)
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
+#ifdef DH_SAME_ROW                          // diagnostic builds: every channel reads the rows of the first 64 (the input then lives in L2: what does HBM cost?)
+    const float* in = P.in + (size_t) (ch & 63u) * P.in_stride;
+#else
     const float* in = P.in + (size_t) ch * P.in_stride;
+#endif
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
     const float* in_end = P.in + (size_t) (P.n_channels - 1u) * P.in_stride + P.n;    // end of the readable input
 
