@@ -357,13 +357,14 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
     """The remaining single-GPU BASELINE configs on the same lease (each its own engines, inputs resident, same timing
     method as the headline)."""
     out = []
-    for workload, channels, overlap in (("rrc_gfsk", 4096, False), ("rrc_gfsk_fast", 4096, False), ("ysf_full", 16384, False),
-                                        ("mixed", (8192, 8192), False), ("dmr_full", 16384, True), ("ysf_full", 16384, True)):
+    for workload, channels, overlap, streams in (("rrc_gfsk", 4096, False, 1), ("rrc_gfsk_fast", 4096, False, 1), ("ysf_full", 16384, False, 1),
+                                                 ("mixed", (8192, 8192), False, 1), ("mixed", (8192, 8192), False, 2),
+                                                 ("dmr_full", 16384, True, 1), ("ysf_full", 16384, True, 1)):
         t_start = time.perf_counter()
-        job = Job(torch, ctx, device, workload, channels, rank=0, overlap=overlap)
+        job = Job(torch, ctx, device, workload, channels, rank=0, overlap=overlap, streams=streams)
         dt = job.timed(steps, warmup)
         roof, stage = job.roofline(step_ms=dt / steps * 1e3)
-        entry = {"workload": workload + (" --overlap" if overlap else ""),
+        entry = {"workload": workload + (" --overlap" if overlap else "") + (" --streams 2" if streams == 2 else ""),
                  "config": "%s channels x %d samples: %s%s" % (channels, job.parts[0]["T"], job.desc,
                                                               "; pushes overlapped on the engine's own streams (DH_FLAG_OVERLAP_PUSHES)" if overlap else ""),
                  "launch_group": roof.get("launch_group"),
