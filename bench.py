@@ -286,7 +286,7 @@ class Job:
         fir_flops = B * T * 2.0 * taps              # one mul + one add per tap and sample, unfused
         traffic, traffic_src = profiled_traffic(self.workload, p["B"], T, part0=group is not None) if dom_name == "k_chain" else (None, None)
         mean = lambda a: float(np.mean(a)) if len(a) else None
-        bounded = dom_name == "k_chain" and kw["rrc"] == "wide" and kw["sps"] == 10 and not kw.get("fast_fir")
+        bounded = dom_name == "k_chain" and not kw.get("fast_fir") and ((kw["rrc"] == "wide" and kw["sps"] == 10) or kw["rrc"] == "narrow")
         return {"bound": "hbm", "kernel": dom_name + ("<%s>" % kw["proto"] if dom_name == "k_chain" else "") + (" PART 0" if group else ""),
                 "launch_group": group,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -32,8 +32,10 @@
 #endif
 #define DH_MAX_NZ 160
 #define DH_MAX_SPS 40
-#define DH_HISTORY 1152              // raw samples kept BEHIND the read position by the error-bounded kernels (see DH_BOUNDED_FIR)
-#define DH_TAIL_MAX (256 + DH_HISTORY)   // raw samples carried between pushes: history + the last nz inputs + not yet consumed ones
+// raw samples kept BEHIND the read position by the error-bounded kernels (see DH_BOUNDED_FIR): the 100 symbols of the
+// rings + slack; and the most the tail carries between pushes: history + the last nz inputs + not yet consumed ones
+DH_HD uint32_t dh_history(uint32_t sps) { return DH_VARIANCE_SYMBOLS * (sps > 10u ? sps : 10u) + 152u; }
+DH_HD uint32_t dh_tail_max(uint32_t sps) { return 256u + dh_history(sps); }
 #define DH_STATE_HDR 32              // u32 words of per-channel header
 
 // per-channel state block in HBM (floats / u32 words, AoS, `state_stride` words apart):
@@ -41,13 +43,13 @@
 //                                timing blocks decided by the ordered chain, timing blocks total, ...
 //   [16 .. 16+100)               volume ring  (volume_rb)
 //   [116 .. 116+100*sps)         variance ring (variance_rb), phase-major: [sample i][symbol k]
-//   [.. + DH_TAIL_MAX)           raw-sample tail: the last nz inputs + not yet consumed samples
+//   [.. + dh_tail_max(sps))      raw-sample tail: the last nz inputs + not yet consumed samples
 enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED = 4, DH_ST_BLOCKS = 5,
        DH_ST_P0 = 6,                 // read position inside the tail at the start of the next push (= history samples in front of it)
        DH_ST_CUR_START = 7, DH_ST_CUR_OFF = 8, DH_ST_PREV_START = 9, DH_ST_PREV_OFF = 10,   // filtered positions of symbol 0 of the current / previous variance block, their offsets
        DH_ST_BLOCK_FLAGS = 11,       // bit 0: the current block's start is known, bit 1: the previous block's
        DH_ST_E_CUR = 12, DH_ST_E_PREV = 13, DH_ST_E_COUNT = 14, DH_ST_E_BLOCK = 15,          // error radii of the ring entries (floats), symbols in the current bucket
-       DH_ST_UNCERTAIN = 16, DH_ST_EXACT_RUNS = 17,                                             // statistics: symbols / runs decided by exact arithmetic
+       DH_ST_UNCERTAIN = 16, DH_ST_EXACT_RUNS = 17, DH_ST_EXACT_BLOCKS = 18,                    // statistics: symbols / runs / timing blocks decided by exact arithmetic
        DH_ST_DIAG = 20 };            // 20..31: diagnostic builds (phase clocks 20..27, wave timeline 28..31)
 #define DH_ST_VOL DH_STATE_HDR
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
@@ -72,7 +74,7 @@ struct DhDspParams {
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
 };
 
-DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + DH_TAIL_MAX; }
+DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }
 
 // LDS block of one wavefront.  `xf` holds the raw-sample window during the FIR (padded one word
 // per 16 so that the per-lane sliding windows, 16 words apart, hit 32 different banks) and is then
@@ -100,6 +102,7 @@ struct DhDspShared {
     uint32_t* clk;                                     // DH_PHASE_CLOCKS builds only
     float* tapsf;                                      // FIR taps (first half + centre)
     float* var_rb;
+    float* bound;                                      // bookkeeping of the error-bounded kernels (DhBoundState, 16 words)
 };
 
 #define DH_LDS_FIXED_WORDS 352                         // 128 + 128 + 84 + 2 + 8 (+ 2 pad): keeps var_rb 16-byte aligned
@@ -107,15 +110,18 @@ DH_HD uint32_t dh_dsp_xf_words(uint32_t nz) {
     const uint32_t padded = DH_XPAD(DH_FTILE + nz) + 1u, with_sums = DH_FTILE + 4u + DH_SCAN_N;
     return ((padded > with_sums ? padded : with_sums) + 3u) & ~3u;
 }
+// (the wide filter leaves words 48.. of the 84-word tap block free: the bookkeeping sits there; the narrow filter fills
+// the block and gets 16 words more)
 DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz) {
-    return sizeof(float) * (size_t) (DH_LDS_FIXED_WORDS + DH_VARIANCE_SYMBOLS * sps + dh_dsp_xf_words(nz));
+    return sizeof(float) * (size_t) (DH_LDS_FIXED_WORDS + (nz > 80u ? 16u : 0u) + DH_VARIANCE_SYMBOLS * sps + dh_dsp_xf_words(nz));
 }
-DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps) {          // base: 16-byte aligned
+DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {          // base: 16-byte aligned
     float* f = reinterpret_cast<float*>(base);
     DhDspShared S;
     S.vol_old = f; S.vol_new = f + 128; S.tapsf = f + 256;
     S.stats = reinterpret_cast<uint32_t*>(f + 340); S.clk = S.stats + 2;
-    S.var_rb = f + DH_LDS_FIXED_WORDS;
+    S.bound = nz > 80u ? f + DH_LDS_FIXED_WORDS : S.tapsf + 48;
+    S.var_rb = f + DH_LDS_FIXED_WORDS + (nz > 80u ? 16u : 0u);
     S.xf = S.var_rb + DH_VARIANCE_SYMBOLS * sps;
     S.mn = S.xf; S.mx = S.xf + DH_SCAN_N;
     S.variance = reinterpret_cast<double*>(S.xf + 2 * DH_SCAN_N);
@@ -608,6 +614,12 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 #ifndef DH_BOUNDED_FIR
 #define DH_BOUNDED_FIR 1
 #endif
+#ifndef DH_BOUNDED_NARROW
+#define DH_BOUNDED_NARROW 1                 // the same for the narrow filter at a run-time samples-per-symbol (the NXDN pipe)
+#endif
+template <int NZ, bool FAST, int SPS> struct DhIsBounded {
+    static constexpr bool value = DH_BOUNDED_FIR && !FAST && ((NZ == 80 && SPS == 10) || (DH_BOUNDED_NARROW && NZ == 160 && SPS == 0));
+};
 // Diagnostic builds only (tools/phase_budget.sh): -DDH_STOP_AFTER=n leaves out the phases after Pn of every run (the
 // results are then wrong; the instruction counters of such builds, subtracted from each other, give the per-phase budget)
 #ifndef DH_STOP_AFTER
@@ -617,11 +629,19 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 #define DH_BOUND_XMAX_LO 1e-25f
 #define DH_BOUND_XMAX_HI 1e15f
 
-// 240 u ||c||_1 / gain, rounded up (host side, once per engine)
+// kappa u ||c||_1 / gain, rounded up (host side, once per engine).  kappa = 240 for the 81 taps the bound above was written
+// for (gamma_82 + gamma_81 + 3.1 u = 167 u, times 1.44 of head room for the slicer's own roundings); for n taps the two
+// accumulation chains give (2 n + 5) u, and the same proportion is kept: kappa = 1.44 (2 n + 5).  The slicer's roundings
+// grow with the samples per symbol (sums of sps terms): both sides together <= 2 (avg + umid) u A / gain with
+//   vol = (sps (sps + 1) / 2 - 1) / sps + 1,  centre = vol + 1,  umid = (vol + centre + 1) 0.625 + centre + 1,
+//   avg = (w (w + 1) / 2 - 1) / w + 1 for a mid-symbol window of w samples
+// = 68 at sps 20 (w 6), 119 at sps 40 (w 14): (3.25 (2 n + 5) + that) / kappa stays below 2.8 for every filter and sps the
+// engine accepts, under the decision threshold T = 3.5 e.
 inline float dh_fir_error_coefficient(const float* taps_half, uint32_t nz, double gain) {
     double l1 = 0.0;
     for (uint32_t i = 0; i <= nz; i++) { const double c = taps_half[i <= nz / 2 ? i : nz - i]; l1 += c < 0 ? -c : c; }
-    const double coef = 240.0 * 5.9604644775390625e-08 * l1 / (gain < 0 ? -gain : gain) * 1.0001;
+    const double kappa = nz == 80 ? 240.0 : 1.44 * (2.0 * (nz + 1) + 5.0);
+    const double coef = kappa * 5.9604644775390625e-08 * l1 / (gain < 0 ? -gain : gain) * 1.0001;
     float f = (float) coef;
     if ((double) f < coef) { union { float f; uint32_t u; } b; b.f = f; b.u++; f = b.f; }
     return f;
@@ -671,10 +691,10 @@ __device__ __forceinline__ float dh_max3_abs(float a, float b, float c) {
 struct DhBoundState {
     int32_t cur_start, cur_off, prev_start, prev_off;   // filtered positions of symbol 0 of the current / previous variance block, their offsets
     uint32_t blk_flags;                                 // bit 0: the current block's start is known, bit 1: the previous block's
-    uint32_t e_count, n_uncertain, n_exact_runs;
+    uint32_t e_count, n_uncertain, n_exact_runs, n_exact_blocks;
     float e_cur, e_prev, e_blk;                         // error radii: current / previous >= 100-symbol bucket, current variance block
 };
-#define DH_BOUND_STATE(S) (reinterpret_cast<DhBoundState*>((S).tapsf + 48))
+#define DH_BOUND_STATE(S) (reinterpret_cast<DhBoundState*>((S).bound))
 DH_HD float dh_uniform_f(float x) { union { float f; uint32_t u; } b; b.f = x; b.u = dh_uniform(b.u); return b.f; }
 
 // What the exact evaluation of one symbol needs to know about the stream (error-bounded kernels)
@@ -755,6 +775,120 @@ DH_COLD uint8_t dh_exact_symbol(const DhExactCtx& C, DhDspShared& S, uint32_t k,
     return average > center ? (uint8_t) !C.invert : (uint8_t) (C.invert != 0);
 }
 
+// ---- the same two exact evaluations with the raw samples staged through LDS (generic sps; used by the narrow filter, whose
+// 161-tap chains would otherwise fetch every sample with a dependent load of its own from HBM / L2)
+// raw[0 ..] = V[base ..]: the reference's filtered sample at filtered position f (rrc_filter.cpp:22-34), 0 where the stream
+// does not hold all of V[f .. f + NZ]
+template <int NZ>
+DH_HD float dh_exact_filtered_lds(const float* raw, int32_t base, uint32_t nv, const float* tapsf, double gain, double rgain, int32_t f) {
+    if (f < 0 || (uint32_t) f + (uint32_t) NZ >= nv) return 0.0f;
+    const float* x = raw + (f - base);
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i <= NZ; i++) {
+        const float c = tapsf[i <= NZ / 2 ? i : NZ - i];
+        const float prod = c * x[i];
+        acc = acc + prod;
+    }
+    return dh_div_gain(acc, gain, rgain);
+}
+// V[base .. base + count) into raw[] (zeros outside the stream); barriers on both sides
+DH_HD void dh_stage_raw(float* raw, const float* tail, uint32_t tc, const float* in, uint32_t nv, int32_t base, uint32_t count) {
+    DH_BARRIER();
+    DH_FOR_LANES_FRESH(lane) {
+        for (uint32_t e = (uint32_t) lane; e < count; e += DH_WAVE) {
+            const int32_t idx = base + (int32_t) e;
+            raw[e] = (idx >= 0 && (uint32_t) idx < nv) ? dh_virtual_sample(tail, tc, in, (uint32_t) idx) : 0.0f;
+        }
+    }
+    DH_BARRIER();
+}
+// `stage`: LDS floats free at the caller's phase, at least sps + NZ + 2 + 64 of them (the last 64 are the result scratch)
+template <int NZ>
+DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint32_t k, float* stage, uint32_t sps, uint32_t LO, uint32_t HI) {
+    const uint32_t W = HI - LO;
+    float* scratch = stage + sps + NZ + 2;
+    const float mn_a = S.mn[k], mx_a = S.mx[k];
+    const float lo_thr = mn_a + 2.5f * C.e_eff, hi_thr = mx_a - 2.5f * C.e_eff;
+    uint64_t cand_lo[2] = { 0, 0 }, cand_hi[2] = { 0, 0 };
+    for (int h = 0; h < 2; h++) {
+        uint64_t vlo = 0, vhi = 0;
+        DH_FOR_LANES_FRESH(lane) {
+            const uint32_t j = (uint32_t) lane + 64u * (uint32_t) h;
+            bool lo = false, hi = false;
+            if (j < DH_VOLUME_RB_SIZE) {
+                const float v = (j >= C.k0 && j <= k) ? S.vol_new[j] : S.vol_old[j];
+                lo = v <= lo_thr; hi = v >= hi_thr;
+            }
+            DH_BALLOT_ACC(vlo, lo, lane); DH_BALLOT_ACC(vhi, hi, lane);
+        }
+        cand_lo[h] = vlo; cand_hi[h] = vhi;
+    }
+    // the mid-symbol window of symbol k
+    float avg_sum = 0.0f;
+    {
+        const int32_t s0 = dh_slot_position(C, k, k, sps);
+        const int32_t base = s0 + (int32_t) LO;
+        dh_stage_raw(stage, C.tail, C.tc, C.in, C.nv, base, W + NZ + 1u);
+        DH_FOR_LANES_FRESH(lane) {
+            if ((uint32_t) lane < W) scratch[lane] = dh_exact_filtered_lds<NZ>(stage, base, C.nv, C.tapsf, C.gain, C.rgain, base + lane);
+        }
+        DH_BARRIER();
+        for (uint32_t i = 0; i < W; i++) avg_sum += scratch[i];
+    }
+    float exact_min = DH_FLT_MAX, exact_max = DH_FLT_MIN;            // the reference's seeds (gfsk_demodulator.cpp:110-111)
+    uint64_t todo[2] = { cand_lo[0] | cand_hi[0], cand_lo[1] | cand_hi[1] };
+    for (int h = 0; h < 2; h++) {
+        while (todo[h]) {
+            const uint32_t j = (uint32_t) dh_ffs64(todo[h]) + 64u * (uint32_t) h;
+            todo[h] &= todo[h] - 1;
+            const int32_t s0 = dh_slot_position(C, j, k, sps);
+            float vol = 0.0f;                                        // a slot never written holds an exact zero
+            if (s0 != INT32_MIN) {
+                dh_stage_raw(stage, C.tail, C.tc, C.in, C.nv, s0, sps + NZ + 1u);
+                DH_FOR_LANES_FRESH(lane) {
+                    if ((uint32_t) lane < sps) scratch[lane] = dh_exact_filtered_lds<NZ>(stage, s0, C.nv, C.tapsf, C.gain, C.rgain, s0 + lane);
+                }
+                DH_BARRIER();
+                for (uint32_t i = 0; i < sps; i++) vol += scratch[i];
+                vol = dh_div_const(vol, (float) sps, C.sps_rcp);
+            }
+            if ((cand_lo[j >> 6] >> (j & 63u)) & 1u) exact_min = dh_fmin_(exact_min, vol);
+            if ((cand_hi[j >> 6] >> (j & 63u)) & 1u) exact_max = dh_fmax_(exact_max, vol);
+        }
+    }
+    const float center = (exact_max + exact_min) / 2.0f;
+    const float average = avg_sum / (float) W;
+    if (C.levels == 4) {
+        const float umid = __builtin_fmaf(exact_max - center, 0.625f, center);
+        const float lmid = __builtin_fmaf(exact_min - center, 0.625f, center);
+        if (average > center) return average > umid ? 1 : 0;
+        return average < lmid ? 3 : 2;
+    }
+    return average > center ? (uint8_t) !C.invert : (uint8_t) (C.invert != 0);
+}
+// the variance ring of the block that just ended, recomputed exactly, a chunk of symbols at a time through `stage` (cap floats)
+template <int NZ>
+DH_COLD void dh_exact_var_ring_staged(const DhExactCtx& C, DhDspShared& S, uint32_t sps, float* stage, uint32_t cap) {
+    const uint32_t spc = (cap - (uint32_t) NZ - 3u) / sps;            // symbols per chunk
+    for (uint32_t j0 = 0; j0 < DH_VARIANCE_SYMBOLS; j0 += spc) {
+        const uint32_t nj = dh_min<uint32_t>(spc, DH_VARIANCE_SYMBOLS - j0);
+        const int32_t base = C.cur_start + (int32_t) (j0 * sps) - 1;      // one sample of slack for the block's +-1 step
+        dh_stage_raw(stage, C.tail, C.tc, C.in, C.nv, base, nj * sps + (uint32_t) NZ + 3u);
+        for (uint32_t r = 0; r * DH_WAVE < nj * sps; r++) {
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t e = r * DH_WAVE + (uint32_t) lane;
+                if (e < nj * sps) {
+                    const uint32_t jj = e / sps, i = e - jj * sps, j = j0 + jj;
+                    const int32_t f = C.cur_start + (int32_t) (j * sps) + (j ? C.cur_off : 0) + (int32_t) i;
+                    S.var_rb[i * DH_VARIANCE_SYMBOLS + j] = dh_exact_filtered_lds<NZ>(stage, base, C.nv, C.tapsf, C.gain, C.rgain, f);
+                }
+            }
+        }
+    }
+    DH_BARRIER();
+}
+
 // the rounded-product FIR over the staged window (runs the bound does not cover): outputs into fo[16] per lane
 template <int NZ>
 DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t need, float (*fo_all)[DH_FIR_L], float* fo_dev) {
@@ -796,7 +930,7 @@ DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps
 template <int NZ, bool FAST, int SPS>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
     static_assert(SPS == 0 || SPS == 10, "only sps 10 is specialised");
-    constexpr bool BOUNDED = DH_BOUNDED_FIR && NZ == 80 && !FAST && SPS == 10;      // see "Error-bounded FIR" above
+    constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -839,7 +973,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     if (BOUNDED) {
         BS->cur_start = (int32_t) sth[DH_ST_CUR_START]; BS->cur_off = (int32_t) sth[DH_ST_CUR_OFF];
         BS->prev_start = (int32_t) sth[DH_ST_PREV_START]; BS->prev_off = (int32_t) sth[DH_ST_PREV_OFF];
-        BS->blk_flags = sth[DH_ST_BLOCK_FLAGS]; BS->e_count = sth[DH_ST_E_COUNT]; BS->n_uncertain = 0; BS->n_exact_runs = 0;
+        BS->blk_flags = sth[DH_ST_BLOCK_FLAGS]; BS->e_count = sth[DH_ST_E_COUNT]; BS->n_uncertain = 0; BS->n_exact_runs = 0; BS->n_exact_blocks = 0;
         BS->e_cur = st[DH_ST_E_CUR]; BS->e_prev = st[DH_ST_E_PREV]; BS->e_blk = st[DH_ST_E_BLOCK];
     }
     DH_FOR_LANES(lane) {
@@ -1208,7 +1342,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 while (todo) {
                     const uint32_t q = (uint32_t) dh_ffs64(todo) + 64u * (uint32_t) h;
                     todo &= todo - 1;
-                    const uint8_t sym = dh_exact_symbol<NZ, SPS ? SPS : 10>(C, S, k0 + q, S.xf + 640);
+                    const uint8_t sym = SPS == 0 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, sps, ev_lo, ev_hi)
+                                                 : dh_exact_symbol<NZ, SPS ? SPS : 10>(C, S, k0 + q, S.xf + 640);
                     DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
                     BS->n_uncertain++;
                 }
@@ -1350,45 +1485,102 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
             if (ordered) {
                 // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
-                // ring and fetched 16 bytes at a time
-                DH_BARRIER();
-                if (BOUNDED && e_blk > 0.0f) {          // the chain needs the reference's samples: all thousand of this block, exactly
-                    DhExactCtx C;
-                    C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
-                    C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
-                    C.prev_start = 0; C.prev_off = 0; C.blk_flags = dh_uniform(BS->blk_flags);
-                    C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
-                    dh_exact_var_ring<NZ>(C, S, sps);
+                // ring and fetched 16 bytes at a time.
+                // Error-bounded kernels: the ring holds values within e_blk of the reference's.  At sps 10 the estimate above
+                // has already failed, so the chain runs on the reference's samples -- all thousand of this block, recomputed
+                // exactly.  At a run-time sps there is no estimate: the chain first runs on the ring as it is (attempt 0) and
+                // its result stands if the intervals [V - tol, V + tol] separate the smallest phase from all others, from 0 and
+                // from 5e6; otherwise attempt 1 recomputes the ring exactly.  tol: samples moved by <= e move the variance
+                // by |2 cov(x, d) + var(d)| <= 2 e sigma + e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken
+                // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
+                // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
+                const bool approx_ring = BOUNDED && e_blk > 0.0f;
+                for (int attempt = (approx_ring && SPS == 0 && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {
                     DH_BARRIER();
-                }
-                DH_FOR_LANES_FRESH(lane) {
-                    if ((uint32_t) lane < sps) {
-                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
-                        float total = 0.0f;
-#pragma unroll 5
-                        for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
-                            const dh_f4a v = row[q];
-                            total += v.x; total += v.y; total += v.z; total += v.w;
-                        }
-                        const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
-                        double dsum = 0.0;
-#pragma unroll 5
-                        for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
-                            const dh_f4a v = row[q];
-                            const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
-                            const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
-                            dsum += s0; dsum += s1; dsum += s2; dsum += s3;
-                        }
-                        S.variance[lane] = dsum / (double) DH_VARIANCE_SYMBOLS;
+                    if (approx_ring && attempt == 1) {
+                        DhExactCtx C;
+                        C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
+                        C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
+                        C.prev_start = 0; C.prev_off = 0; C.blk_flags = dh_uniform(BS->blk_flags);
+                        C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
+                        // (the window block is dead here except words 512..575, where the L2 touch of the next window may
+                        // still be dropping its dwords: the staged variant uses the words behind them)
+                        if (SPS == 0) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u);
+                        else dh_exact_var_ring<NZ>(C, S, sps);
+                        BS->n_exact_blocks++;
+                        DH_BARRIER();
                     }
+                    DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1); DH_LANE_ARRAY(uint32_t, iv_ok, 1);
+                    DH_FOR_LANES_FRESH(lane) {
+                        if ((uint32_t) lane < sps) {
+                            const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
+                            float total = 0.0f;
+#pragma unroll 5
+                            for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                                const dh_f4a v = row[q];
+                                total += v.x; total += v.y; total += v.z; total += v.w;
+                            }
+                            const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
+                            double dsum = 0.0;
+#pragma unroll 5
+                            for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                                const dh_f4a v = row[q];
+                                const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
+                                const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+                                dsum += s0; dsum += s1; dsum += s2; dsum += s3;
+                            }
+                            const double var = dsum / (double) DH_VARIANCE_SYMBOLS;
+                            S.variance[lane] = var;
+                            if (BOUNDED && SPS == 0 && attempt == 0) {
+                                // this phase's interval, as floats rounded outwards (2e-7 V covers the two conversions)
+                                const double eb = (double) e_blk;
+                                const double tol = 2.5 * eb * __builtin_sqrt(var) + 4.0 * eb * eb + 2e-10 * (var + mean * mean) + 2e-7 * var + 1e-40;
+                                DH_LA(iv_lo, lane)[0] = (float) (var - tol); DH_LA(iv_hi, lane)[0] = (float) (var + tol);
+                                DH_LA(iv_ok, lane)[0] = (var + mean * mean < 1e30) ? 1u : 0u;      // false for NaN / overflow, as in the estimate
+                            }
+                        } else if (BOUNDED && SPS == 0 && attempt == 0) {
+                            DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u;
+                        }
+                    }
+                    DH_BARRIER();
+                    if (BOUNDED && SPS == 0 && attempt == 0) {
+                        // is the reference's (arg-min, vmin <= 0, vmin > 5e6) beyond doubt?  One vote per question.
+                        float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                        hmin = -dh_wave_max(-iv_hi[0]);
+#else
+                        hmin = DH_FLT_MAX;
+                        for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
+#endif
+                        uint64_t v_above = 0, v_ok = 0, v_pos = 0, v_small = 0, v_big = 0;
+                        DH_FOR_LANES_FRESH(lane) {
+                            const float l = DH_LA(iv_lo, lane)[0], h = DH_LA(iv_hi, lane)[0];
+                            DH_BALLOT_ACC(v_above, l > hmin, lane);
+                            DH_BALLOT_ACC(v_ok, DH_LA(iv_ok, lane)[0] != 0u, lane);
+                            DH_BALLOT_ACC(v_pos, l > 0.0f, lane);
+                            DH_BALLOT_ACC(v_small, h < 4999999.0f, lane);
+                            DH_BALLOT_ACC(v_big, l > 5000001.0f, lane);
+                        }
+                        const uint64_t phases = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
+                        const uint64_t cand = ~v_above & phases;                  // phases whose interval reaches below the smallest upper end
+                        const bool one = cand != 0 && (cand & (cand - 1)) == 0;
+                        const bool sure = one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand));
+                        if (!sure) continue;                                      // attempt 1: the exact ring
+                        DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+                        const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
+                        if (v_big & cand) {
+                        } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                        else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+                        break;
+                    }
+                    double vmin = S.variance[0]; uint32_t vmin_pos = 0;
+                    for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
+                    DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+                    if (vmin <= 0 || vmin > 5000000) {
+                    } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                    else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+                    break;
                 }
-                DH_BARRIER();
-                DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
-                double vmin = S.variance[0]; uint32_t vmin_pos = 0;
-                for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
-                if (vmin <= 0 || vmin > 5000000) {
-                } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
-                else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
             }
             DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[0]++; }
         }
@@ -1448,8 +1640,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // a last L2-touch load may still be writing into the window block
 #endif
     // ---- write back state: rings, header, and the raw tail V[base .. nv): the unread samples (from p) and, in the
-    // error-bounded kernels, up to DH_HISTORY samples behind them
-    const uint32_t keep = BOUNDED ? dh_min<uint32_t>(DH_HISTORY, p) : 0u;
+    // error-bounded kernels, up to dh_history(sps) samples behind them
+    const uint32_t tail_max = dh_tail_max(sps);
+    const uint32_t keep = BOUNDED ? dh_min<uint32_t>(dh_history(sps), p) : 0u;
     const uint32_t base = p - keep;
     const uint32_t new_tc = nv - base;                 // = history + unread filtered samples + NZ
     DH_FOR_LANES(lane) {
@@ -1458,21 +1651,21 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     }
     // the tail may overlap its own source when base < tc: in chunks through LDS (a chunk is read completely before any of
     // it is written, and later chunks only read further ahead)
-    for (uint32_t c0 = 0; c0 < new_tc && c0 < DH_TAIL_MAX; c0 += DH_FTILE) {
+    for (uint32_t c0 = 0; c0 < new_tc && c0 < tail_max; c0 += DH_FTILE) {
         DH_BARRIER();
         DH_FOR_LANES(lane) {
-            for (uint32_t j = c0 + lane; j < new_tc && j < DH_TAIL_MAX && j < c0 + DH_FTILE; j += DH_WAVE) S.xf[j - c0] = dh_virtual_sample(tail, tc, in, base + j);
+            for (uint32_t j = c0 + lane; j < new_tc && j < tail_max && j < c0 + DH_FTILE; j += DH_WAVE) S.xf[j - c0] = dh_virtual_sample(tail, tc, in, base + j);
         }
         DH_BARRIER();
         DH_FOR_LANES(lane) {
-            for (uint32_t j = c0 + lane; j < new_tc && j < DH_TAIL_MAX && j < c0 + DH_FTILE; j += DH_WAVE) tail[j] = S.xf[j - c0];
+            for (uint32_t j = c0 + lane; j < new_tc && j < tail_max && j < c0 + DH_FTILE; j += DH_WAVE) tail[j] = S.xf[j - c0];
         }
     }
     DH_FOR_LANES(lane) {
         if (DH_IS_LANE0(lane)) {
             sth[DH_ST_K] = k0;
             sth[DH_ST_OFF] = (uint32_t) off;
-            sth[DH_ST_TAIL] = new_tc < DH_TAIL_MAX ? new_tc : DH_TAIL_MAX;
+            sth[DH_ST_TAIL] = new_tc < tail_max ? new_tc : tail_max;
             sth[DH_ST_NSYM] += nsym;
             if (BOUNDED) {
                 sth[DH_ST_P0] = keep;
@@ -1480,7 +1673,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 sth[DH_ST_PREV_START] = (uint32_t) (BS->prev_start - (int32_t) base); sth[DH_ST_PREV_OFF] = (uint32_t) BS->prev_off;
                 sth[DH_ST_BLOCK_FLAGS] = BS->blk_flags; sth[DH_ST_E_COUNT] = BS->e_count;
                 st[DH_ST_E_CUR] = BS->e_cur; st[DH_ST_E_PREV] = BS->e_prev; st[DH_ST_E_BLOCK] = BS->e_blk;
-                sth[DH_ST_UNCERTAIN] += BS->n_uncertain; sth[DH_ST_EXACT_RUNS] += BS->n_exact_runs;
+                sth[DH_ST_UNCERTAIN] += BS->n_uncertain; sth[DH_ST_EXACT_RUNS] += BS->n_exact_runs; sth[DH_ST_EXACT_BLOCKS] += BS->n_exact_blocks;
             }
 #ifdef DH_PHASE_CLOCKS
             for (int i = 0; i < 8; i++) sth[DH_ST_DIAG + i] += S.clk[i] >> 6;
@@ -1493,7 +1686,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             sth[DH_ST_BLOCKS] += S.stats[0];
             sth[DH_ST_ORDERED] += S.stats[1];
             P.sym_count[ch] = nsym;
-            if ((overflow || new_tc > DH_TAIL_MAX) && P.overflow) *P.overflow = 1u;
+            if ((overflow || new_tc > tail_max) && P.overflow) *P.overflow = 1u;
         }
     }
 }

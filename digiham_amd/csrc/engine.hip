@@ -38,7 +38,7 @@ int hip_fail(hipError_t e, const char* what) {
 #define DH_TILES_PER_WG 4
 #endif
 #ifndef DH_LB_NARROW
-#define DH_LB_NARROW 2   // the 161-tap kernels: 256 VGPRs
+#define DH_LB_NARROW 3   // the 161-tap kernels: 168 VGPRs (their fused FIR fits; the rounded one, now the rare path, spills a little)
 #endif
 #ifndef DH_SPLIT_MIN_CHANNELS
 #define DH_SPLIT_MIN_CHANNELS 8192   // DH_FLAG_OVERLAP_PUSHES takes effect for engines at least this large (HipBackend::go_chain)
@@ -51,7 +51,7 @@ int hip_fail(hipError_t e, const char* what) {
 template <int NZ, bool FAST, int SPS>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
+    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
     dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
 }
 
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     const uint32_t ch = blockIdx.x + P.ch_base;
     {
-        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps);
+        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
         dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, L);
     }
     __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
 template <int NZ, bool FAST>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_TILE_LB)) void k_rrc_tile(const DhRrcParams R) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    DhDspShared S = dh_dsp_carve(dh_smem, 0u);
+    DhDspShared S = dh_dsp_carve(dh_smem, 0u, NZ);
     // DH_TILES_PER_WG consecutive tiles of one channel per wavefront: fewer, longer-lived workgroups
     const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
     for (uint32_t t = blockIdx.x * DH_TILES_PER_WG; t < tiles && t < (blockIdx.x + 1u) * DH_TILES_PER_WG; t++)

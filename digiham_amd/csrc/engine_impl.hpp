@@ -57,7 +57,7 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     L.hi = (uint32_t) (int) __builtin_roundf((float) L.sps * 2 / 3);
     L.fused = L.rrc != DH_RRC_NONE && L.rrc != DH_RRC_CUSTOM && L.demod != DH_DEMOD_NONE && !(L.flags & DH_FLAG_KEEP_FILTERED);
     // a symbol consumes at least sps-1 samples
-    L.sym_cap = L.demod ? (L.max_samples + DH_TAIL_MAX) / (L.sps - 1) + 4 : L.max_samples;
+    L.sym_cap = L.demod ? (L.max_samples + dh_tail_max(L.sps)) / (L.sps - 1) + 4 : L.max_samples;
     L.sym_stride = round_up(L.sym_cap, 64);
     L.state_words = round_up(dh_state_words(L.sps), 16);
     const uint32_t max_syms = dh_carry_max(L.proto) + L.sym_cap;

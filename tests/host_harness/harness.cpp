@@ -49,7 +49,7 @@ struct HostBackend {
 
     template <int NZ, bool FAST, int SPS> static void run_rrc_demod(const DhDspParams& P) {
         std::vector<float> lds(dh_dsp_shared_bytes(P.sps, NZ) / sizeof(float));     // exactly the device allocation
-        DhDspShared S = dh_dsp_carve(lds.data(), P.sps);
+        DhDspShared S = dh_dsp_carve(lds.data(), P.sps, NZ);
         for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, S);
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
@@ -63,7 +63,7 @@ struct HostBackend {
     }
     template <int NZ, bool FAST> static void run_rrc_tiles(const DhRrcParams& R) {
         std::vector<float> lds(dh_dsp_shared_bytes(0, NZ) / sizeof(float));
-        DhDspShared S = dh_dsp_carve(lds.data(), 0);
+        DhDspShared S = dh_dsp_carve(lds.data(), 0, NZ);
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
         for (uint32_t ch = 0; ch < R.n_channels; ch++)
             for (uint32_t t = 0; t < tiles; t++) dh_rrc_tile<NZ, FAST>(R, ch, t, S);

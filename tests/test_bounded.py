@@ -28,9 +28,13 @@ def _run(ctx, x, proto, chunks, **kw):
     while pos < n:
         c = min(chunks[i % len(chunks)], n - pos); i += 1
         eng.push(np.ascontiguousarray(x[:, pos:pos + c])); pos += c
-        s, sc = eng.symbols(); f, fc = eng.frames(); e, ec = eng.events()
+        s, sc = eng.symbols()
         for b in range(B):
-            syms[b].append(s[b, :sc[b]].copy()); frames[b].append(f[b, :fc[b]].copy()); evs[b].append(e[b, :ec[b]].copy())
+            syms[b].append(s[b, :sc[b]].copy())
+        if eng.has_proto:
+            f, fc = eng.frames(); e, ec = eng.events()
+            for b in range(B):
+                frames[b].append(f[b, :fc[b]].copy()); evs[b].append(e[b, :ec[b]].copy())
     st = _stats(eng)
     eng.close()
     cat = lambda parts, dt: [np.concatenate(p) if p else np.zeros(0, dt) for p in parts]
@@ -132,3 +136,35 @@ def test_signals_on_the_thresholds(ctx, oracle):
     assert unc.sum() >= 8, "too few symbols needed the exact evaluation (%s): the bisection did not land on the thresholds" % unc
     res, _ = _run(ctx, x, "dmr", [1700, 301])
     assert_matches_oracle(res, ref, x.shape[0], "thresholds, ragged")
+
+
+@pytest.mark.parametrize("sps", [20, 10, 40, 7])
+def test_narrow_filter_generic_sps_all_three_modes(ctx, oracle, sps):
+    """The narrow (161-tap) filter at a run-time sps is error-bounded too (the NXDN pipe at sps 20): the generic exact
+    symbol evaluation and exact ring recomputation (raw samples staged through LDS), the ordered chain on the approximate
+    ring with its interval test, tap-count dependent radius.  Normal, every-symbol-exact and every-run-exact must all
+    be the oracle's dibits; ragged and tiny pushes exercise the longer history (100 symbols x sps samples)."""
+    from digiham_amd import _taps
+    rng = np.random.default_rng(100 + sps)
+    chans = []
+    for i in range(4):
+        dibits = rng.integers(0, 4, 1200 if sps <= 20 else 500)
+        x = synth.shape(dibits, sps=sps, taps=_taps.narrow())
+        chans.append(synth.impair(x, 50 + i, snr_db=[None, 24, 15, 9][i], dc=[0, 0.1, -0.2, 0][i], delay=3 * i, gain=[1, 0.4, 1.9, 1][i]))
+    n = min(len(c) for c in chans)
+    x = np.stack([c[:n] for c in chans]).astype(np.float32)
+    ref = oracle.chain(x, rrc=2, sps=sps, proto=0)
+    total = int(ref["sym_count"].sum())
+    kw = dict(rrc="narrow", sps=sps)
+    for chunks in ([n], [3 * sps + 1, 5000, 17, 2600]):
+        res, (unc, ex) = _run(ctx, x, "none", chunks, **kw)
+        assert_matches_oracle(res, ref, x.shape[0], "normal sps %d %s" % (sps, chunks[:1]))
+        assert unc.sum() < total // 10
+        res, (unc, ex) = _run(ctx, x, "none", chunks, exact_fir=True, **kw)
+        assert_matches_oracle(res, ref, x.shape[0], "exact fir sps %d %s" % (sps, chunks[:1]))
+    res, (unc, ex) = _run(ctx, x[:, : n // 3], "none", [n // 3], exact_symbols=True, **kw)
+    ref3 = oracle.chain(x[:, : n // 3], rrc=2, sps=sps, proto=0)
+    assert_matches_oracle(res, ref3, x.shape[0], "exact symbols sps %d" % sps)
+    assert int(unc.sum()) == int(ref3["sym_count"].sum())
+    res, _ = _run(ctx, x, "none", [n], ordered_timing=True, **kw)
+    assert_matches_oracle(res, ref, x.shape[0], "ordered timing sps %d" % sps)
