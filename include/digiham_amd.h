@@ -114,7 +114,9 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3,
                                          after the caller's stream at the moment of the push and joined with it again only when results are
                                          read, the engine is reset / synchronised or another kind of work is queued -- so the drain of one
                                          launch is filled by the next, across pushes.  CONTRACT: the input buffer of a push must stay
-                                         untouched until dh_engine_sync() (or any read) returns.  Results are identical. */
+                                         untouched until dh_engine_sync() (or any read) returns, and the raw device
+                                         views of the outputs (dh_engine_symbols / _frames / _events) are only valid after dh_engine_sync().
+                                         Results are identical. */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(dh_engine_config) */
