@@ -1483,6 +1483,93 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
                 }
             }
+            if (ordered && SPS == 0 && 2u * sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
+                // Run-time sps with at least two lanes per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
+                // per phase, lane g sps + i takes a contiguous piece of row i -- `seg` = 4 ceil(25 / G) ring entries, read 16
+                // bytes at a time -- and the partial sums meet in LDS.  The bound of the sps-10 estimate holds with 8e-6 V'
+                // for 4e-6 V' (chains of up to 52 fused terms + G partials); in the error-bounded kernels the ring holds
+                // values within e_blk of the reference's, which moves a variance by |2 cov(x, d) + var(d)| <= 2 e sigma +
+                // e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken as 2.5 e sqrt(V) + 4 e^2).  An estimate
+                // of exactly 0, a NaN or an overflow is left to the chain below.
+                DH_BARRIER();                                   // mn / mx are dead from here: scratch
+                float* psum = S.mn; float* pd = S.mx; float* pmean = S.mn + 64;
+                const uint32_t G = DH_WAVE / sps, active = G * sps, quads = (25u + G - 1u) / G;
+                for (int pass = 0; pass < 2; pass++) {
+                    DH_FOR_LANES_FRESH(lane) {
+                        if ((uint32_t) lane < active) {
+                            const uint32_t g = (uint32_t) lane / sps, i = (uint32_t) lane - g * sps;
+                            const uint32_t q0 = g * quads;                                 // first 16-byte piece of this lane
+                            const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS);
+                            float mean = 0.0f;
+                            if (pass == 1) {
+                                float total = 0.0f;
+                                for (uint32_t gg = 0; gg < G; gg++) total += psum[gg * sps + i];
+                                mean = total * 0.01f;
+                                if (g == 0) pmean[i] = mean;
+                            }
+                            float acc = 0.0f;
+                            for (uint32_t q = 0; q < quads; q += 3u) {                     // three pieces in flight
+                                dh_f4a v[3];
+#pragma unroll
+                                for (uint32_t j = 0; j < 3u; j++) v[j] = row[dh_min<uint32_t>(q0 + q + j, 24u)];
+#pragma unroll
+                                for (uint32_t j = 0; j < 3u; j++) {
+                                    if (q + j < quads && q0 + q + j < 25u) {
+                                        if (pass == 0) { acc += v[j].x; acc += v[j].y; acc += v[j].z; acc += v[j].w; }
+                                        else {
+                                            const float d0 = mean - v[j].x, d1 = mean - v[j].y, d2 = mean - v[j].z, d3 = mean - v[j].w;
+                                            acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
+                                            acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
+                                        }
+                                    }
+                                }
+                            }
+                            if (pass == 0) psum[lane] = acc; else pd[lane] = acc;
+                        }
+                    }
+                    DH_BARRIER();
+                }
+                DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1);
+                uint64_t v_ok = 0, v_pos = 0, v_small = 0, v_big = 0, v_above = 0;
+                DH_FOR_LANES_FRESH(lane) {
+                    float l = DH_FLT_MAX, h = DH_FLT_MAX;
+                    bool ok = true;
+                    if ((uint32_t) lane < sps) {
+                        float v = 0.0f;
+                        for (uint32_t gg = 0; gg < G; gg++) v += pd[gg * sps + (uint32_t) lane];
+                        v *= 0.01f;
+                        const float mean = pmean[lane];
+                        const float e = __builtin_fmaf(mean, mean, v);
+                        float tol = __builtin_fmaf(v, 8e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
+                        if (BOUNDED && e_blk > 0.0f) tol += 2.5f * e_blk * __builtin_sqrtf(v) + 4.0f * e_blk * e_blk;
+                        ok = e < 1e30f && v != 0.0f;
+                        l = v - tol; h = v + tol;
+                    }
+                    DH_LA(iv_lo, lane)[0] = l; DH_LA(iv_hi, lane)[0] = h;
+                    DH_BALLOT_ACC(v_ok, ok, lane);
+                    DH_BALLOT_ACC(v_pos, l > 0.0f, lane);
+                    DH_BALLOT_ACC(v_small, h < 4999999.0f, lane);
+                    DH_BALLOT_ACC(v_big, l > 5000001.0f, lane);
+                }
+                float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                hmin = -dh_wave_max(-iv_hi[0]);
+#else
+                hmin = DH_FLT_MAX;
+                for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
+#endif
+                DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(v_above, DH_LA(iv_lo, lane)[0] > hmin, lane); }
+                const uint64_t phases = (1ull << sps) - 1ull;                    // sps <= 32 here
+                const uint64_t cand = ~v_above & phases;                          // phases whose interval reaches below the smallest upper end
+                const bool one = cand != 0 && (cand & (cand - 1)) == 0;
+                if (one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand))) {
+                    ordered = false;
+                    const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
+                    if (v_big & cand) {
+                    } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                    else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+                }
+            }
             if (ordered) {
                 // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
                 // ring and fetched 16 bytes at a time.
@@ -1495,7 +1582,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
                 // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
                 const bool approx_ring = BOUNDED && e_blk > 0.0f;
-                for (int attempt = (approx_ring && SPS == 0 && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {
+                for (int attempt = (approx_ring && SPS == 0 && 2u * sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
                     DH_BARRIER();
                     if (approx_ring && attempt == 1) {
                         DhExactCtx C;
