@@ -476,10 +476,10 @@ struct HipBackend {
     }
     // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
-        if (proto == DH_PROTO_NXDN && nz == 160 && !fast) return go_chain<160, false, DH_PROTO_NXDN, 0>(P, D);   // rrc_filter -n | gfsk_demodulator -s 20 | nxdn_decoder
+        if (proto == DH_PROTO_NXDN && nz == 160 && !fast) return go_chain<160, false, DH_PROTO_NXDN, 0, true>(P, D);   // rrc_filter -n | gfsk_demodulator -s 20 | nxdn_decoder
         // (POCSAG stays on two launches: measured 9.5 ms chained against 8.9 ms split at 16 384 channels)
         if (P.sps != 10) return 1;
-        if (proto == DH_PROTO_DSTAR && nz == 0) return go_chain<0, false, DH_PROTO_DSTAR>(P, D);    // fsk_demodulator -s 10 | dstar_decoder
+        if (proto == DH_PROTO_DSTAR && nz == 0) return go_chain<0, false, DH_PROTO_DSTAR, 10, true>(P, D);    // fsk_demodulator -s 10 | dstar_decoder
         if ((nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;
         const bool dmr = proto == DH_PROTO_DMR;
         if (nz == 0) return dmr ? go_chain<0, false, DH_PROTO_DMR>(P, D) : go_chain<0, false, DH_PROTO_YSF>(P, D);

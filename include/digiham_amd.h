@@ -109,7 +109,7 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3,
 #define DH_FLAG_ORDERED_TIMING  0x10  /* always run the in-order variance chain of the timing recovery (diagnostic; results are identical) */
 #define DH_FLAG_EXACT_SYMBOLS   0x40  /* error-bounded kernels: decide EVERY symbol with the reference's arithmetic (diagnostic; results are identical) */
 #define DH_FLAG_EXACT_FIR       0x80  /* error-bounded kernels: run the rounded-product FIR in every run (diagnostic / A-B; results are identical) */
-#define DH_FLAG_OVERLAP_PUSHES  0x100 /* engines of >= 8192 DMR / YSF channels: a push goes out as two launches on two streams of the engine's
+#define DH_FLAG_OVERLAP_PUSHES  0x100 /* engines of >= 8192 channels on the one-launch chains (DMR, YSF, NXDN, D-Star): a push goes out as two launches on two streams of the engine's
                                          own (three quarters of the channels at high priority, the rest at normal priority) which are ordered
                                          after the caller's stream at the moment of the push and joined with it again only when results are
                                          read, the engine is reset / synchronised or another kind of work is queued -- so the drain of one

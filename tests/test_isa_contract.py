@@ -133,7 +133,7 @@ def test_exact_kernels_keep_their_two_firs_apart_and_the_hot_one_in_registers(ke
     * the error-bounded one -- packed FMAs -- which runs in (nearly) every pass: no scratch access in that block.
     A handful of spills elsewhere (rare paths, the YSF decoder half) is what a fourth wavefront per SIMD costs."""
     exact = [n for n in kernels if "k_chain" in n and ("ILi80ELb0E" in n or "ILi160ELb0E" in n)]
-    assert len(exact) == 5                    # DMR and YSF, each as launch PART 0 and PART 1 (DH_FLAG_OVERLAP_PUSHES), and the NXDN chain (161 taps)
+    assert len(exact) == 6                    # DMR, YSF and NXDN (161 taps), each as launch PART 0 and PART 1 (DH_FLAG_OVERLAP_PUSHES)
     for name in exact:
         lines, meta = kernels[name]
         narrow = "ILi160ELb0E" in name
