@@ -149,6 +149,28 @@ class Context:
                "dh_debug_div_const", self.lib)
         return out if dev else self.mem.to_numpy(out)
 
+    def debug_mfma_f16(self, a, b, c):
+        """d[t] = c[t] + a[t] @ b[t] on the matrix cores: a [T][16][32], b [T][32][16] as float16 (or uint16 bit patterns), c [T][16][16] float32."""
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+        a = a.view(np.uint16) if a.dtype == np.float16 else a.astype(np.uint16)
+        b = b.view(np.uint16) if b.dtype == np.float16 else b.astype(np.uint16)
+        T = a.shape[0]
+        da, db = self.mem.from_numpy(a.reshape(T, 512)), self.mem.from_numpy(b.reshape(T, 512))
+        dc = self.mem.from_numpy(np.ascontiguousarray(c, np.float32).reshape(T, 256))
+        out = self.mem.zeros((T, 256), np.float32)
+        _check(self.lib.dh_debug_mfma_f16(self.mem.ptr(da), self.mem.ptr(db), self.mem.ptr(dc), self.mem.ptr(out), T, self.mem.stream()),
+               "dh_debug_mfma_f16", self.lib)
+        return self.mem.to_numpy(out).reshape(T, 16, 16)
+
+    def debug_f16_split(self, x, scale=1.0):
+        """(h1, h2) as float16 arrays: the two halves the error-bounded FIR makes of x * scale."""
+        d = self.mem.from_numpy(np.ascontiguousarray(x, np.float32).ravel())
+        n = d.shape[0]
+        h1, h2 = self.mem.zeros((n,), np.uint16), self.mem.zeros((n,), np.uint16)
+        _check(self.lib.dh_debug_f16_split(self.mem.ptr(d), self.mem.ptr(h1), self.mem.ptr(h2), n, float(scale), self.mem.stream()),
+               "dh_debug_f16_split", self.lib)
+        return self.mem.to_numpy(h1).view(np.float16), self.mem.to_numpy(h2).view(np.float16)
+
     def dvfilter(self, x, state=None):
         """x: int16 [B][n] numpy; returns (y, state) with state a device array [B][22] to carry on."""
         a = np.ascontiguousarray(x, np.int16)

@@ -81,6 +81,15 @@ int dh_debug_div_const(const float* in, float* out, size_t n, unsigned divisor, 
     return dh_be_div_const(in, out, n, divisor, s);
 }
 
+int dh_debug_mfma_f16(const uint16_t* a, const uint16_t* b, const float* c, float* d, size_t tiles, void* s) {
+    if ((!a || !b || !c || !d) && tiles) return DH_EINVAL;
+    return dh_be_mfma_f16(a, b, c, d, tiles, s);
+}
+int dh_debug_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, float scale, void* s) {
+    if ((!in || !h1 || !h2) && n) return DH_EINVAL;
+    return dh_be_f16_split(in, h1, h2, n, scale, s);
+}
+
 int dh_engine_create(const dh_engine_config* cfg, dh_engine** out) {
     if (!cfg || !out) return DH_EINVAL;
     *out = nullptr;

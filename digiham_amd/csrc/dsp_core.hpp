@@ -72,6 +72,8 @@ struct DhDspParams {
     float err_coef;                                    // error radius of a filtered sample per unit of max |x| (dh_fir_error_coefficient)
     double gain, rgain; float inv_gain;                // rgain = 1/gain rounded to double
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
+    const uint32_t* tapfrag;                           // split-f16 FIR: the per-lane tap fragments (DhF16Taps::frag), or null
+    float err_coef_f16;                                // its error radius per unit of max |x| (dh_f16_error_coefficient)
 };
 
 DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }
@@ -82,15 +84,20 @@ DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYM
 #define DH_XPAD(i) ((i) + ((i) >> 4))
 #define DH_SCAN_N 128
 // The LDS block of one wavefront, carved by dh_dsp_carve():
-//   vol_old[128] vol_new[128] tapsf[84] stats[2] (clk[8])   fixed part
+//   vol_old[128] vol_new[128]                                fixed part, then
+//   wide filter / no filter:  tap table[112] bound[12] stats[2] pad[2] (clk[8] in DH_PHASE_CLOCKS builds)
+//   narrow filter:            tapsf[84] stats[2] clk[8] pad[2] bound[16]
 //   var_rb[100 * sps]     variance ring, phase-major: row i holds sample i of the last 100 symbols
 //   xf[...]               raw-sample window during the FIR (padded one word per 16 so that the per-lane sliding
 //                         windows, 16 words apart, hit 32 different banks), then overwritten by the filtered samples
+// The wide filter's tap table is the WHOLE response between two runs of 15 zeros (tap k at word 15 + k): the matrix-pipe
+// FIR (dh_fir_mfma) reads its Toeplitz operand c[p - n], p = 0..95, n = 0..15, straight out of it; `tapsf` points at tap 0,
+// so everything that indexes the first half + centre still works.
 // Everything that only lives between the window phase (P3) and the next staging (P7) sits INSIDE the window block,
 // which is idle then: the AGC extremes mn / mx (also the scratch of the timing estimate) in its first 256 words
 // (the filtered samples there are dead once P3 has copied them into the ring), the ordered-chain variances behind
-// them, and the mid-symbol sums behind the last filtered sample.  10.1 KB per wavefront for the wide filter at
-// sps 10: 16 wavefronts per CU.
+// them, and the mid-symbol sums behind the last filtered sample.  10 240 bytes per wavefront for the wide filter at
+// sps 10: exactly 16 wavefronts per CU.
 struct DhDspShared {
     float* xf;
     float* vol_old;                                    // ring content before the current run (+ identity padding)
@@ -100,28 +107,40 @@ struct DhDspShared {
     double* variance;                                  // [DH_MAX_SPS] per-phase variances of the ordered chain
     uint32_t* stats;                                   // timing blocks of this push: all / decided by the ordered chain
     uint32_t* clk;                                     // DH_PHASE_CLOCKS builds only
-    float* tapsf;                                      // FIR taps (first half + centre)
+    float* tapsf;                                      // FIR taps (first half + centre; the wide filter: all of them, see above)
     float* var_rb;
     float* bound;                                      // bookkeeping of the error-bounded kernels (DhBoundState, 16 words)
 };
 
-#define DH_LDS_FIXED_WORDS 352                         // 128 + 128 + 84 + 2 + 8 (+ 2 pad): keeps var_rb 16-byte aligned
+#define DH_TAP_LEAD 15                                 // zeros in front of (and behind) the wide filter's tap table
+#ifdef DH_PHASE_CLOCKS
+#define DH_LDS_CLK_WORDS 8u
+#else
+#define DH_LDS_CLK_WORDS 0u
+#endif
+// words in front of the variance ring (a multiple of 4: keeps var_rb 16-byte aligned)
+DH_HD uint32_t dh_lds_fixed_words(uint32_t nz) { return nz > 80u ? 352u + 16u : 384u + DH_LDS_CLK_WORDS; }
 DH_HD uint32_t dh_dsp_xf_words(uint32_t nz) {
     const uint32_t padded = DH_XPAD(DH_FTILE + nz) + 1u, with_sums = DH_FTILE + 4u + DH_SCAN_N;
     return ((padded > with_sums ? padded : with_sums) + 3u) & ~3u;
 }
-// (the wide filter leaves words 48.. of the 84-word tap block free: the bookkeeping sits there; the narrow filter fills
-// the block and gets 16 words more)
 DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz) {
-    return sizeof(float) * (size_t) (DH_LDS_FIXED_WORDS + (nz > 80u ? 16u : 0u) + DH_VARIANCE_SYMBOLS * sps + dh_dsp_xf_words(nz));
+    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + DH_VARIANCE_SYMBOLS * sps + dh_dsp_xf_words(nz));
 }
 DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {          // base: 16-byte aligned
     float* f = reinterpret_cast<float*>(base);
     DhDspShared S;
-    S.vol_old = f; S.vol_new = f + 128; S.tapsf = f + 256;
-    S.stats = reinterpret_cast<uint32_t*>(f + 340); S.clk = S.stats + 2;
-    S.bound = nz > 80u ? f + DH_LDS_FIXED_WORDS : S.tapsf + 48;
-    S.var_rb = f + DH_LDS_FIXED_WORDS + (nz > 80u ? 16u : 0u);
+    S.vol_old = f; S.vol_new = f + 128;
+    if (nz > 80u) {
+        S.tapsf = f + 256;
+        S.stats = reinterpret_cast<uint32_t*>(f + 340); S.clk = S.stats + 2;
+        S.bound = f + 352;
+    } else {
+        S.tapsf = f + 256 + DH_TAP_LEAD;
+        S.bound = f + 256 + 112;
+        S.stats = reinterpret_cast<uint32_t*>(f + 256 + 124); S.clk = reinterpret_cast<uint32_t*>(f + 384);
+    }
+    S.var_rb = f + dh_lds_fixed_words(nz);
     S.xf = S.var_rb + DH_VARIANCE_SYMBOLS * sps;
     S.mn = S.xf; S.mx = S.xf + DH_SCAN_N;
     S.variance = reinterpret_cast<double*>(S.xf + 2 * DH_SCAN_N);
@@ -463,6 +482,264 @@ struct alignas(16) dh_f4a { float x, y, z, w; };     // 16-byte aligned: one ds_
 DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
 DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
 DH_HD void dh_store4_unaligned(float* q, const dh_f4& v) { __builtin_memcpy(q, &v, sizeof(v)); }   // global_store_dwordx4
+
+// ---------------------------------------------------------------------------------------------
+// The fused FIR on the matrix pipe (error-bounded and FAST wide-filter kernels): v_mfma_f32_16x16x4_f32 is bit for bit a
+// k-ordered chain of f32 FMAs, at the same FLOP rate as v_pk_fma_f32 -- but it issues beside the VALU, which the rest
+// of the slicer keeps busy, and takes one register per operand instead of a ds_read2 per packed FMA.
+//
+// Toeplitz form.  The 1024 outputs of a pass are 64 blocks of 16: y[16 b + n] = sum_p x[16 b + p] c[p - n], p = 0..NZ+15,
+// with c = 0 outside 0..NZ.  One MFMA tile takes 16 blocks as its rows (A operand: the raw samples) and the 16 samples of
+// a block as its columns (B operand: the taps, the same for every block and tile); K runs over p in (NZ + 16) / 4 slices
+// of 4.  Multiplying by an exact zero changes nothing, so each output is the (NZ + 1)-term fused chain in tap order --
+// the value the VALU form (dh_fir_lane<NZ, true>) produces, and the one the bound of "Error-bounded FIR" is proven for
+// (a non-finite sample under a zero tap turns into a NaN, which is exactly what sends the run to the reference's
+// arithmetic anyway).
+//   A: lane (m = l & 15, q = l >> 4) holds x[16 b(m) + 4 s + q];   B: lane (n = l & 15, q = l >> 4) holds c[4 s + q - n]
+//   D: lane (n = l & 15, g = l >> 4), register r holds y[16 b(4 g + r) + n]
+// Blocks of tile T: b(m) = 2 m + (T & 1) + 32 (T >> 1).  In the padded window (one word per 16) block b starts at word
+// 17 b, so the sixteen rows of a tile are 34 words apart: with the q = 0 / 1 (2 / 3) lanes of a ds_read_b32's lane group
+// one word apart that is 32 different banks.  Tiles T and T + 1 interleave their blocks, so slice s of the odd tile IS
+// slice s + 4 of the even one: 28 window reads serve the 48 MFMAs of a tile pair.  Results go back unpadded (sample o at
+// word o): sixteen ds_write_b32 at compile-time offsets from one per-lane base (2-way bank conflicts, which a 4-byte
+// store hides behind its own issue time).
+#ifndef DH_MFMA_FIR
+#define DH_MFMA_FIR 1
+#endif
+#define DH_MF_OUT(T, r, g, n) (128u * (uint32_t) (g) + (uint32_t) (n) + 32u * (uint32_t) (r) + 16u * ((uint32_t) (T) & 1u) + 512u * ((uint32_t) (T) >> 1))
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+typedef float dh_f32x4 __attribute__((ext_vector_type(4)));
+// acc[4 T + r] of lane (n, g) = sum over the chain for output DH_MF_OUT(T, r, g, n); `tapsf` points at tap 0 of the
+// zero-framed table, `xs` at the padded window
+template <int NZ>
+__device__ __forceinline__ void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* acc16) {
+    static_assert((NZ + 16) % 4 == 0 && NZ <= 80, "K = NZ + 16 in slices of four; the zero-framed tap table exists for the wide filter");
+    constexpr int NS = (NZ + 16) / 4;
+    const int m = lane & 15, q = lane >> 4;
+    const float* xb = xs + 34 * m + q;
+    const float* tb = tapsf + (q - m);
+    float tap[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) tap[s] = tb[4 * s];
+    dh_f32x4 a0 = { 0.0f, 0.0f, 0.0f, 0.0f }, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+    for (int s = 0; s < NS + 4; s++) {
+        const int off = 4 * s + (s >> 2);
+        const float x01 = xb[off], x23 = xb[544 + off];
+        if (s < NS) { a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x01, tap[s], a0, 0, 0, 0); a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x23, tap[s], a2, 0, 0, 0); }
+        if (s >= 4) { a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x01, tap[s - 4], a1, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x23, tap[s - 4], a3, 0, 0, 0); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { acc16[r] = a0[r]; acc16[4 + r] = a1[r]; acc16[8 + r] = a2[r]; acc16[12 + r] = a3[r]; }
+}
+#else
+template <int NZ>
+inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* acc16) {
+    const int n = lane & 15, g = lane >> 4;
+    for (int T = 0; T < 4; T++) for (int r = 0; r < 4; r++) {
+        const uint32_t o = DH_MF_OUT(T, r, g, n), b16 = o - (uint32_t) n;
+        float acc = 0.0f;
+        for (int p = 0; p < NZ + 16; p++) acc = __builtin_fmaf(xs[DH_XPAD(b16 + (uint32_t) p)], tapsf[p - n], acc);
+        acc16[4 * T + r] = acc;
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// The fused FIR as a SPLIT-f16 product on the matrix cores (DH_FIR_F16; the error-bounded wide-filter kernels).
+//
+// f32 arithmetic -- v_pk_fma_f32 and v_mfma_f32_16x16x4_f32 alike -- runs at 64 flop / clock / SIMD, and an f32 MFMA keeps
+// the vector ALU as busy as the packed FMAs it replaces (tools/microbench/mfma_valu_overlap.hip: MFMA wave + VALU wave on one
+// SIMD take the SUM of their times): 81 taps x 1024 outputs are 2 600 SIMD cycles per run whichever instruction does them.
+// v_mfma_f32_16x16x32_f16 does 16 times the work per cycle.  The error-bounded scheme does not need the reference's floats,
+// only values with a KNOWN distance from them, so the filter runs there:
+//   samples   x_s = x 2^-k  (k from the run's max |x|, which staging computes anyway: max |x_s| in [0.5, 1))
+//             h1 = f16(x_s), h2 = f16((x_s - h1) 2^11):   x_s = h1 + 2^-11 h2 + eps,  |eps| <= 2^-24   (both conversions round to
+//             nearest; x_s - h1 is exact in f32; f16 subnormals are honoured by the MFMA -- tools/microbench/mfma_f16_numerics.hip)
+//   taps      c = g1 + 2^-11 g2 + delta, g1 = f16(c), g2 = f16((c - g1) 2^11)   (host, once per engine; delta known exactly)
+//   products  M = sum g1 h1  (3 MFMAs of K = 32 per tile of 256 outputs),  R = sum (g2 h1 + g1 h2)  (6 MFMAs),
+//             y = (M + 2^-11 R) / (gain 2^-k)  as  fma(R, k2, M k1);   the g2 h2 products (2^-22) are dropped
+// f16 x f16 products are exact in f32; what the hardware does to their sum is not documented, so the bound rests on a
+// stated assumption, checked on the device by tests/test_numerics.py (known-answer probes + 10^6 random dot products):
+//   (H1) inside one MFMA every addend (32 products and C) enters the sum with an alignment error below 2^-24 mu, and each
+//        of its four passes rounds with a relative error <= 2^-23, where mu bounds every addend and partial sum:
+//        |D - (C + sum a b)| <= 41 u mu,  u = 2^-24.  (Observed on gfx950: products are truncated to 2^-24 of the largest
+//        product of their group of eight, groups are added in order with a final round to nearest; worst case over 10^6
+//        random sums 3.5 u (|C| + sum |a b|) -- a tenth of what (H1) allows.)
+// dh_f16_error_coefficient() adds it all up (reference chain gamma_82 + its division; 123 u for the three chained MFMAs of
+// M; the split residuals; the dropped products; the two roundings of the combine) and keeps the 1.44 of head room for the
+// slicer's own roundings that the f32 bound has.  Toeplitz layout as in dh_fir_mfma, natural block order:
+//   A: lane (m = l & 15, q = l >> 4) holds h[16 (16 T + m) + 32 s + 8 q + j], j = 0..7 -- ONE ds_read_b128 from the plain f16
+//      window (32 bytes per row, 16 per q: conflict-free in every lane group of a b128 read)
+//   B: lane (n = l & 15, q = l >> 4) holds g[32 s + 8 q + j - n]: per-lane fragments precomputed on the host (6 x 1 KiB,
+//      dh_f16_tap_fragments), fetched with the samples
+//   D: lane (n, g), register r holds y[256 T + 64 g + 16 r + n]
+#ifndef DH_FIR_F16
+#define DH_FIR_F16 1
+#endif
+#define DH_F16_KSTEPS 3                      // (80 + 16) / 32
+#define DH_F16_FRAGS (2 * DH_F16_KSTEPS)     // g1 fragments, then g2 fragments
+#define DH_F16_H2_OFFSET 552                 // word offset of the h2 array inside the window block (1104 halves = 552 words of h1 first)
+#define DH_F16_OUT(T, r, g, n) (256u * (uint32_t) (T) + 64u * (uint32_t) (g) + 16u * (uint32_t) (r) + (uint32_t) (n))
+
+// IEEE binary16 <-> binary32 in integer arithmetic (host and harness; the device converts in hardware): round to nearest even
+DH_HD uint16_t dh_f16_bits(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    const uint32_t sign = (v.u >> 16) & 0x8000u, a = v.u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t) (sign | (a > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (a >= 0x477FF000u) return (uint16_t) (sign | 0x7C00u);                         // >= 65520 rounds to infinity
+    if (a < 0x33000001u) return (uint16_t) sign;                                      // <= 2^-25: zero (the tie goes to even = 0)
+    const int e = (int) (a >> 23) - 127;
+    uint32_t man = (a & 0x7FFFFFu) | 0x800000u, shift = e < -14 ? (uint32_t) (13 + (-14 - e)) : 13u;
+    uint32_t q = man >> shift; const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    const uint32_t bits = e < -14 ? q : ((uint32_t) (e + 15 - 1) << 10) + q;           // (the implicit bit of q carries into the exponent)
+    return (uint16_t) (sign | bits);
+}
+DH_HD float dh_f16_value(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+    union { float f; uint32_t u; } v;
+    if (e == 31u) v.u = sign | 0x7F800000u | (m << 13);
+    else if (e == 0u) { v.f = (float) m * 5.9604644775390625e-08f; v.u |= sign; }     // m 2^-24
+    else v.u = sign | ((e + 112u) << 23) | (m << 13);
+    return v.f;
+}
+
+// the split of a tap and the per-lane B operands (host, once per engine): frag[f][lane][d], f = 0..2 the g1 slices, 3..5 the g2 slices
+struct DhF16Taps {
+    uint32_t frag[DH_F16_FRAGS][DH_WAVE][4];
+    double l1, l1_g1, l1_g2, sum_delta;
+};
+inline void dh_f16_tap_fragments(const float* taps_half, uint32_t nz, DhF16Taps& F) {
+    uint16_t g1[DH_MAX_NZ + 1], g2[DH_MAX_NZ + 1];
+    F.l1 = F.l1_g1 = F.l1_g2 = F.sum_delta = 0.0;
+    for (uint32_t i = 0; i <= nz; i++) {
+        const float c = taps_half[i <= nz / 2 ? i : nz - i];
+        g1[i] = dh_f16_bits(c);
+        const double r = (double) c - (double) dh_f16_value(g1[i]);
+        g2[i] = dh_f16_bits((float) (r * 2048.0));                                     // (r has at most 13 significant bits: exact)
+        const double v2 = (double) dh_f16_value(g2[i]);
+        const double delta = r - v2 / 2048.0;
+        F.l1 += c < 0 ? -(double) c : (double) c; F.l1_g1 += __builtin_fabs((double) dh_f16_value(g1[i]));
+        F.l1_g2 += __builtin_fabs(v2); F.sum_delta += __builtin_fabs(delta);
+    }
+    for (int f = 0; f < DH_F16_FRAGS; f++) for (int lane = 0; lane < DH_WAVE; lane++) for (int d = 0; d < 4; d++) {
+        const int n = lane & 15, q = lane >> 4, s = f % DH_F16_KSTEPS;
+        uint32_t w = 0;
+        for (int hh = 0; hh < 2; hh++) {
+            const int t = 32 * s + 8 * q + 2 * d + hh - n;
+            const uint16_t v = (t >= 0 && t <= (int) nz) ? (f < DH_F16_KSTEPS ? g1[t] : g2[t]) : 0;
+            w |= (uint32_t) v << (16 * hh);
+        }
+        F.frag[f][lane][d] = w;
+    }
+}
+// error radius of a filtered sample per unit of max |x| for this path (see above; everything in units of u / gain):
+//   reference: 82 (gamma_82, + second order) L1 + 1.0001 L1 (its division and rounding)
+//   main sum:  123 L1(g1) (1 + 2^-11) ((H1), three MFMAs; |h1| <= max |x_s| (1 + 2^-11))
+//   second sum: 2^-11 246 (L1(g2) + L1(g1) / 2)
+//   residuals (absolute in the scaled domain, where max |x_s| >= 1/2: twice as much per unit of max |x|):
+//              2 (2^-22 L1(g2) / 2 + sum |delta| (1 + 2^-12) + u L1) / u
+//   combine:   3.1 L1 (fl32(1 / gain), the multiply, the fma)
+// times 1.44 for the slicer's own roundings, as in dh_fir_error_coefficient.
+inline float dh_f16_error_coefficient(const DhF16Taps& F, double gain) {
+    const double u = 5.9604644775390625e-08;
+    const double kl1 = 82.01 * F.l1 + 1.0001 * F.l1 + 123.0 * F.l1_g1 * (1.0 + 1.0 / 2048.0) + 246.0 / 2048.0 * (F.l1_g2 + 0.5 * F.l1_g1)
+                     + 2.0 * (0.5 * F.l1_g2 / 4194304.0 + F.sum_delta * (1.0 + 1.0 / 4096.0) + u * F.l1) / u + 3.1 * F.l1;
+    const double coef = 1.44 * kl1 * u / (gain < 0 ? -gain : gain) * 1.0001;
+    float f = (float) coef;
+    if ((double) f < coef) { union { float f; uint32_t u; } b; b.f = f; b.u++; f = b.f; }
+    return f;
+}
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 dh_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dh_h4 __attribute__((ext_vector_type(4)));
+typedef uint32_t dh_u4 __attribute__((ext_vector_type(4)));
+// four samples -> four halves of h1 and of h2 (scale = 2^-k as a float)
+__device__ __forceinline__ void dh_f16_split4(const dh_f4& v, float scale, dh_h4& h1, dh_h4& h2) {
+    const float x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float xs = x[i] * scale;                            // exact (power of two)
+        const _Float16 a = (_Float16) xs;                         // v_cvt_f16_f32: round to nearest even
+        const float r = xs - (float) a;                           // exact
+        h1[i] = a; h2[i] = (_Float16) (r * 2048.0f);
+    }
+}
+// acc16[4 T + r] of lane (n, g) = y-before-gain of output DH_F16_OUT(T, r, g, n) in the scaled domain: main + 2^-11 second sum
+// is formed by the caller's fma (k1, k2).  `hw` = the window block (h1 at byte 0, h2 at DH_F16_H2_OFFSET words), G = the six
+// tap fragments of this lane.
+__device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[DH_F16_FRAGS], int lane, float k1, float k2, float* out16) {
+    const int m = lane & 15, q = lane >> 4;
+    const char* base = reinterpret_cast<const char*>(hw) + 32 * m + 16 * q;
+    dh_h8 g[DH_F16_FRAGS];
+#pragma unroll
+    for (int f = 0; f < DH_F16_FRAGS; f++) g[f] = __builtin_bit_cast(dh_h8, G[f]);
+    // two tiles at a time: their twelve window reads go out together, and their four accumulation chains (main and second
+    // sum of each) alternate, so no MFMA waits for the one before it
+#pragma unroll
+    for (int TT = 0; TT < 4; TT += 2) {
+        dh_h8 a1[2][DH_F16_KSTEPS], a2[2][DH_F16_KSTEPS];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int s = 0; s < DH_F16_KSTEPS; s++) {
+                a1[t][s] = *reinterpret_cast<const dh_h8*>(base + 512 * (TT + t) + 64 * s);
+                a2[t][s] = *reinterpret_cast<const dh_h8*>(base + 512 * (TT + t) + 64 * s + 4 * DH_F16_H2_OFFSET);
+            }
+        dh_f32x4 mn[2] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } }, sc[2] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
+#pragma unroll
+        for (int s = 0; s < DH_F16_KSTEPS; s++) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[t][s], g[DH_F16_KSTEPS + s], sc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) mn[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[t][s], g[s], mn[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < DH_F16_KSTEPS; s++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[t][s], g[s], sc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out16[4 * (TT + t) + r] = __builtin_fmaf(sc[t][r], k2, mn[t][r] * k1);
+        // scheduling groups: the pair's twelve 16-byte window reads first, then its eighteen MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+    }
+}
+#else
+// harness: the same split and the same sums as plain f32 chains (products of halves are exact in f32; a sequential chain of
+// 96 rounded additions stays inside what (H1) allows the hardware, so the decisions downstream are the same)
+inline void dh_f16_split4(const dh_f4& v, float scale, uint16_t* h1, uint16_t* h2) {
+    const float x[4] = { v.x, v.y, v.z, v.w };
+    for (int i = 0; i < 4; i++) {
+        const float xs = x[i] * scale;
+        h1[i] = dh_f16_bits(xs);
+        const float r = xs - dh_f16_value(h1[i]);
+        h2[i] = dh_f16_bits(r * 2048.0f);
+    }
+}
+inline void dh_fir_f16(const float* hw, const uint32_t (*G)[DH_WAVE][4], int lane, float k1, float k2, float* out16) {
+    const uint16_t* h1 = reinterpret_cast<const uint16_t*>(hw);
+    const uint16_t* h2 = reinterpret_cast<const uint16_t*>(hw + DH_F16_H2_OFFSET);
+    const int n = lane & 15, g = lane >> 4;
+    for (int T = 0; T < 4; T++) for (int r = 0; r < 4; r++) {
+        const uint32_t o = DH_F16_OUT(T, r, g, n), b16 = o - (uint32_t) n;
+        float mn = 0.0f, sc = 0.0f;
+        for (int pass = 0; pass < 3; pass++)                       // main; taps' second halves; samples' second halves (the device's order)
+            for (int s = 0; s < DH_F16_KSTEPS; s++) for (int qq = 0; qq < 4; qq++) for (int j = 0; j < 8; j++) {
+                const int kk = 8 * qq + j;                         // B fragment of lane (n, qq): element j
+                const uint32_t w = G[(pass == 1 ? DH_F16_KSTEPS : 0) + s][16 * qq + n][j >> 1];
+                const float tap = dh_f16_value((uint16_t) (w >> (16 * (j & 1))));
+                const uint16_t hv = (pass == 2 ? h2 : h1)[b16 + 32u * (uint32_t) s + (uint32_t) kk];
+                if (pass == 0) mn = __builtin_fmaf(dh_f16_value(hv), tap, mn); else sc = __builtin_fmaf(dh_f16_value(hv), tap, sc);
+            }
+        out16[4 * T + r] = __builtin_fmaf(sc, k2, mn * k1);
+    }
+}
+#endif
 
 // Four consecutive floats to LDS at `base` + a compile-time offset (the padded window is only dword aligned, so the
 // widest store the hardware takes is a dword pair; the compiler adds the offset to the base with one VALU instruction
@@ -931,6 +1208,7 @@ template <int NZ, bool FAST, int SPS>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
     static_assert(SPS == 0 || SPS == 10, "only sps 10 is specialised");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
+    constexpr bool MF16 = DH_FIR_F16 && BOUNDED && NZ == 80;                         // its fused FIR as a split-f16 product on the matrix cores
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -977,7 +1255,13 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         BS->e_cur = st[DH_ST_E_CUR]; BS->e_prev = st[DH_ST_E_PREV]; BS->e_blk = st[DH_ST_E_BLOCK];
     }
     DH_FOR_LANES(lane) {
-        for (int i = lane; i <= NZ / 2; i += DH_WAVE) S.tapsf[i] = P.taps[i];
+        if (NZ > 80) { for (int i = lane; i <= NZ / 2; i += DH_WAVE) S.tapsf[i] = P.taps[i]; }
+        else if (NZ > 0) {                              // the whole response between two runs of zeros (see DhDspShared)
+            for (int j = lane; j < NZ + 1 + 2 * DH_TAP_LEAD; j += DH_WAVE) {
+                const int k = j - DH_TAP_LEAD;
+                S.tapsf[k] = (k >= 0 && k <= NZ) ? P.taps[k <= NZ / 2 ? k : NZ - k] : 0.0f;
+            }
+        }
         if (lane < 2) S.stats[lane] = 0;
 #ifdef DH_PHASE_CLOCKS
         if (lane < 8) S.clk[lane] = 0;
@@ -1018,12 +1302,16 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags |= 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
         bool use_exact = BOUNDED && P.exact_mode == 2;  // this run through the exact FIR (odd samples, odd staging path)
         DH_LANE_ARRAY(float, xmax_lane, 1);
+        float e_run = 0.0f;                             // error radius of this run's filtered samples (0: exact)
+        bool f16_staged = false, xmax_done = false;     // split-f16 FIR: the window block holds the two arrays of halves
+        float k1 = 0.0f, k2 = 0.0f;                     // ... and its outputs are fma(second sum, k2, main sum * k1)
 
         // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window (zeros beyond)
         // After the first run of a push the whole window comes straight from `in`: 16 B per lane per load,
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
         // From the second run on, the window was already put there by the previous iteration's prefetch.
         if (staged && staged_p == p) {
+            static_assert(DH_PF_L2 || !BOUNDED, "the register-prefetch build does not compute max |x| of a prefetched window: error-bounded kernels need DH_PF_L2");
         } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
             // whole window inside the input buffer: unconditional loads (all in flight together, see the prefetch
             // below for why that matters), samples past the end of the stream zeroed afterwards
@@ -1036,46 +1324,93 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             constexpr uint32_t GSTEP = NZ > 0 ? DH_XPAD(4u * DH_WAVE) : 4u * DH_WAVE;
             constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;     // lanes of the last group inside the window
             static_assert((DH_FTILE + NZ) % 4u == 0 && (DH_FTILE + NZ) >= 4u * DH_WAVE * (DH_PF_N - 1) && LAST_LANES <= DH_WAVE, "four full groups + a partial one cover the window");
+            DH_LANE_ARRAY(dh_f4, v, DH_PF_N);
             DH_FOR_LANES_FRESH(lane) {
-                dh_f4 v[DH_PF_N];
                 const uint32_t l4 = 4u * (uint32_t) lane;
                 const bool in_last = (uint32_t) lane < LAST_LANES;
                 const float* lsrc = src + l4;          // one 64-bit address per lane; the groups are immediate offsets of it
 #pragma unroll
-                for (int r = 0; r < DH_PF_N - 1; r++) v[r] = dh_load4_unaligned(lsrc + 4 * DH_WAVE * r);
-                if constexpr (LAST_LANES > 0) v[DH_PF_N - 1] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
-                else v[DH_PF_N - 1] = v[0];
-                float* ldst = &S.xf[DH_XP(l4)];
+                for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(v, lane)[r] = dh_load4_unaligned(lsrc + 4 * DH_WAVE * r);
+                if constexpr (LAST_LANES > 0) DH_LA(v, lane)[DH_PF_N - 1] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+                else DH_LA(v, lane)[DH_PF_N - 1] = DH_LA(v, lane)[0];
+                if (have < DH_FTILE + NZ) {            // the last window of the push: zeros beyond the input
+#pragma unroll
+                    for (int r = 0; r < DH_PF_N; r++) {
+                        const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
+                        dh_f4 w = DH_LA(v, lane)[r];
+                        w.x = e + 0u < have ? w.x : 0.0f; w.y = e + 1u < have ? w.y : 0.0f;
+                        w.z = e + 2u < have ? w.z : 0.0f; w.w = e + 3u < have ? w.w : 0.0f;
+                        DH_LA(v, lane)[r] = w;
+                    }
+                }
                 if (BOUNDED) {                         // max |x| of the window (a NaN is skipped here and caught behind the FIR)
                     float mx = 0.0f;
 #pragma unroll
                     for (int r = 0; r < DH_PF_N; r++) {
+                        const dh_f4 w = DH_LA(v, lane)[r];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                        mx = dh_max3_abs(v[r].x, v[r].y, mx); mx = dh_max3_abs(v[r].z, v[r].w, mx);
+                        mx = dh_max3_abs(w.x, w.y, mx); mx = dh_max3_abs(w.z, w.w, mx);
 #else
-                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)));
-                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w)));
+                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y)));
+                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.z), __builtin_fabsf(w.w)));
 #endif
                     }
                     DH_LA(xmax_lane, lane)[0] = mx;
                 }
-                if (have >= DH_FTILE + NZ) {
-                    dh_lds_store4_at<0>(ldst, v[0]); dh_lds_store4_at<GSTEP>(ldst, v[1]);
-                    dh_lds_store4_at<2 * GSTEP>(ldst, v[2]); dh_lds_store4_at<3 * GSTEP>(ldst, v[3]);
-                    static_assert(DH_PF_N == 5, "four full groups + a partial one");
-                    if constexpr (LAST_LANES > 0) { if (in_last) dh_lds_store4_at<4 * GSTEP>(ldst, v[4]); }
-                    dh_lds_stores_done();
-                } else {
+            }
+            if (MF16 && !use_exact) {
+                // split-f16 FIR: the window goes to LDS as two arrays of halves, scaled by the power of two that puts the
+                // run's max |x| into [0.5, 1)
+                float xmax;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                xmax = dh_wave_max(xmax_lane[0]);
+#else
+                xmax = 0.0f;
+                for (int l = 0; l < DH_WAVE; l++) xmax = __builtin_fmaxf(xmax, xmax_lane[l][0]);
+#endif
+                xmax_done = true;
+                float scale = 1.0f;
+                if (xmax == 0.0f) { e_run = 0.0f; k1 = P.inv_gain; }                    // all zeros in, all zeros out
+                else if (xmax >= DH_BOUND_XMAX_LO && xmax <= DH_BOUND_XMAX_HI) {
+                    union { float f; uint32_t u; } b; b.f = xmax;
+                    const uint32_t ex = b.u >> 23;                                      // xmax in [2^(ex - 127), 2^(ex - 126))
+                    b.u = (253u - ex) << 23; scale = b.f;                               // 2^(126 - ex)
+                    b.u = (ex + 1u) << 23; k1 = P.inv_gain * b.f;                       // fl32(1 / gain) 2^(ex - 126): exact scaling
+                    e_run = P.err_coef_f16 * xmax;
+                } else use_exact = true;                                                // tiny, huge or infinite samples: outside the bound's assumptions
+                if (!use_exact) {
+                    k2 = k1 * 0.00048828125f;                                           // 2^-11
+                    DH_FOR_LANES_FRESH(lane) {
+                        const bool in_last = (uint32_t) lane < LAST_LANES;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                        dh_h4* d1 = reinterpret_cast<dh_h4*>(S.xf) + lane;              // halves 4 lane .. 4 lane + 3 of group 0; group r is 256 halves on
+                        dh_h4* d2 = reinterpret_cast<dh_h4*>(S.xf + DH_F16_H2_OFFSET) + lane;
 #pragma unroll
-                    for (int r = 0; r < DH_PF_N; r++) {
-                        const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
-                        if (e < DH_FTILE + NZ) {
-                            dh_f4 w = v[r];
-                            w.x = e + 0u < have ? w.x : 0.0f; w.y = e + 1u < have ? w.y : 0.0f;
-                            w.z = e + 2u < have ? w.z : 0.0f; w.w = e + 3u < have ? w.w : 0.0f;
-                            dh_store4(&S.xf[DH_XP(e)], w);
+                        for (int r = 0; r < DH_PF_N; r++) {
+                            dh_h4 a, b;
+                            dh_f16_split4(v[r], scale, a, b);
+                            if (r < DH_PF_N - 1 || in_last) { d1[DH_WAVE * r] = a; d2[DH_WAVE * r] = b; }
                         }
+#else
+                        uint16_t* d1 = reinterpret_cast<uint16_t*>(S.xf) + 4 * lane;
+                        uint16_t* d2 = reinterpret_cast<uint16_t*>(S.xf + DH_F16_H2_OFFSET) + 4 * lane;
+                        for (int r = 0; r < DH_PF_N; r++)
+                            if (r < DH_PF_N - 1 || in_last) dh_f16_split4(v[lane][r], scale, d1 + 4 * DH_WAVE * r, d2 + 4 * DH_WAVE * r);
+#endif
                     }
+                    f16_staged = true;
+                }
+            }
+            if (!f16_staged) {
+                DH_FOR_LANES_FRESH(lane) {
+                    const uint32_t l4 = 4u * (uint32_t) lane;
+                    const bool in_last = (uint32_t) lane < LAST_LANES;
+                    float* ldst = &S.xf[DH_XP(l4)];
+                    dh_lds_store4_at<0>(ldst, DH_LA(v, lane)[0]); dh_lds_store4_at<GSTEP>(ldst, DH_LA(v, lane)[1]);
+                    dh_lds_store4_at<2 * GSTEP>(ldst, DH_LA(v, lane)[2]); dh_lds_store4_at<3 * GSTEP>(ldst, DH_LA(v, lane)[3]);
+                    static_assert(DH_PF_N == 5, "four full groups + a partial one");
+                    if constexpr (LAST_LANES > 0) { if (in_last) dh_lds_store4_at<4 * GSTEP>(ldst, DH_LA(v, lane)[4]); }
+                    dh_lds_stores_done();
                 }
             }
         } else if (p >= tc) {
@@ -1101,8 +1436,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         DH_BARRIER();
-        float e_run = 0.0f;                             // error radius of this run's filtered samples (0: exact)
-        if (BOUNDED && !use_exact) {
+        if (BOUNDED && !use_exact && !xmax_done) {
             float xmax;
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
             xmax = dh_wave_max(xmax_lane[0]);
@@ -1125,6 +1459,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
 #if DH_PRIO_MODE == 1
             DH_SETPRIO(0);
+#elif DH_PRIO_MODE == 8 || DH_PRIO_MODE == 9
+            DH_SETPRIO(DH_PRIO_MODE == 8 ? 3 : 1);     // the matrix-pipe FIR first: its MFMAs must not wait behind other wavefronts' vector work
 #elif DH_PRIO_MODE >= 2
             {
 #if DH_PRIO_MODE >= 6
@@ -1140,50 +1476,123 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
 #endif
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
-            float tv[NZ / 2 + 1];
-#pragma unroll
-            // (from the LDS copy into vector registers: taps as scalar operands free 40 VGPRs but cost this kernel 5 %,
+            // (taps from the LDS copy into vector registers: as scalar operands they free 40 VGPRs but cost this kernel 5 %,
             // see DhFirBatch)
-            for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
+            constexpr bool MFMA = DH_MFMA_FIR && NZ > 0 && NZ <= 80 && (BOUNDED || FAST) && !MF16;      // the fused FIR as f32 MFMAs (dh_fir_mfma)
+            int mf_layout = 0;                          // fo[] holds a matrix-core output layout: 1 = DH_MF_OUT, 2 = DH_F16_OUT
             if (BOUNDED) {
                 uint64_t vote_bad = 0;
                 if (!use_exact) {
-                    DH_FOR_LANES_FRESH(lane) {
-                        bool bad = false;
-                        if ((uint32_t) (lane * DH_FIR_L) < need)
-                            dh_fir_lane<NZ, true>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane), &bad);
-                        DH_BALLOT_ACC(vote_bad, bad, lane);
+                    if constexpr (MF16) {
+                        // (f16_staged holds: every staging path that does not fill the two arrays of halves sets use_exact)
+                        DH_FOR_LANES_FRESH(lane) {
+                            float t = 0.0f;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                            // the tap fragments: six 16-byte loads per lane, 1 KiB per instruction, the same 6 KiB for every
+                            // wavefront of the chip (L1 / L2 hits); requested here, where the staging registers are free again,
+                            // they arrive behind the window reads
+                            dh_u4 tapfrag_regs[DH_F16_FRAGS];
+                            const dh_u4* tf = reinterpret_cast<const dh_u4*>(P.tapfrag) + lane;
+#pragma unroll
+                            for (int f = 0; f < DH_F16_FRAGS; f++) tapfrag_regs[f] = tf[DH_WAVE * f];
+                            dh_fir_f16(S.xf, tapfrag_regs, lane, k1, k2, fo);
+#else
+                            dh_fir_f16(S.xf, reinterpret_cast<const uint32_t (*)[DH_WAVE][4]>(P.tapfrag), lane, k1, k2, fo[lane]);
+#endif
+#pragma unroll
+                            for (int j = 0; j < DH_FIR_L; j++) t = __builtin_fmaf(DH_LA(fo, lane)[j], 0.0f, t);       // NaN or infinity anywhere: 0 * y is NaN
+                            DH_BALLOT_ACC(vote_bad, !(t == 0.0f), lane);
+                        }
+                        mf_layout = 2;
+                    } else if constexpr (MFMA) {
+                        DH_FOR_LANES_FRESH(lane) {
+                            bool bad = false;
+                            float acc[DH_FIR_L];
+                            dh_fir_mfma<MFMA ? NZ : 80>(S.tapsf, S.xf, lane, acc);
+                            dh_fir_finish<true>(acc, P.gain, P.rgain, P.inv_gain, DH_LA(fo, lane), &bad);
+                            DH_BALLOT_ACC(vote_bad, bad, lane);
+                        }
+                        mf_layout = 1;
+                    } else {
+                        float tv[NZ / 2 + 1];
+#pragma unroll
+                        for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
+                        DH_FOR_LANES_FRESH(lane) {
+                            bool bad = false;
+                            if ((uint32_t) (lane * DH_FIR_L) < need)
+                                dh_fir_lane<NZ, true>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane), &bad);
+                            DH_BALLOT_ACC(vote_bad, bad, lane);
+                        }
                     }
                 }
                 if (use_exact || vote_bad) {            // a NaN / infinity among the samples: the reference's arithmetic decides
-                    use_exact = true; e_run = 0.0f; BS->n_exact_runs++;
+                    use_exact = true; e_run = 0.0f; BS->n_exact_runs++; mf_layout = 0;
+                    if (MF16 && f16_staged) {           // the window block holds halves: the reference's FIR wants the raw samples back
+                        DH_BARRIER();
+                        DH_FOR_LANES_FRESH(lane) {
+                            for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
+                                S.xf[DH_XP(e)] = p + e < nv ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
+                        }
+                        DH_BARRIER();
+                    }
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
                     dh_exact_fir_pass<NZ>(P, S, need, nullptr, fo);
 #else
                     dh_exact_fir_pass<NZ>(P, S, need, fo, nullptr);
 #endif
                 }
+            } else if constexpr (MFMA) {
+                DH_FOR_LANES_FRESH(lane) {
+                    float acc[DH_FIR_L];
+                    dh_fir_mfma<MFMA ? NZ : 80>(S.tapsf, S.xf, lane, acc);
+                    dh_fir_finish<true>(acc, P.gain, P.rgain, P.inv_gain, DH_LA(fo, lane), nullptr);
+                }
+                mf_layout = 1;
             } else {
+                float tv[NZ / 2 + 1];
+#pragma unroll
+                for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
                 DH_FOR_LANES_FRESH(lane) {
                     if ((uint32_t) (lane * DH_FIR_L) < need)
                         dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
                 }
             }
             DH_BARRIER();
-            DH_FOR_LANES_FRESH(lane) {
-                if ((uint32_t) (lane * DH_FIR_L) < need) {
-                    dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
+            if (MF16 && mf_layout == 2) {
+                DH_FOR_LANES_FRESH(lane) {
+                    float* dst = S.xf + DH_F16_OUT(0, 0, lane >> 4, lane & 15);
 #pragma unroll
-                    for (int j = 0; j < DH_FIR_L / 4; j++) {
-                        dh_f4a v; v.x = DH_LA(fo, lane)[4 * j]; v.y = DH_LA(fo, lane)[4 * j + 1];
-                        v.z = DH_LA(fo, lane)[4 * j + 2]; v.w = DH_LA(fo, lane)[4 * j + 3];
-                        dst[j] = v;
+                    for (int T = 0; T < 4; T++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) dst[DH_F16_OUT(T, r, 0, 0)] = DH_LA(fo, lane)[4 * T + r];
+                }
+            } else if (MFMA && mf_layout == 1) {
+                // sample DH_MF_OUT(T, r, g, n) of the run from register 4 T + r of lane 16 g + n: compile-time offsets
+                DH_FOR_LANES_FRESH(lane) {
+                    float* dst = S.xf + DH_MF_OUT(0, 0, lane >> 4, lane & 15);
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) dst[DH_MF_OUT(T, r, 0, 0)] = DH_LA(fo, lane)[4 * T + r];
+                }
+            } else {
+                DH_FOR_LANES_FRESH(lane) {
+                    if ((uint32_t) (lane * DH_FIR_L) < need) {
+                        dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
+#pragma unroll
+                        for (int j = 0; j < DH_FIR_L / 4; j++) {
+                            dh_f4a v; v.x = DH_LA(fo, lane)[4 * j]; v.y = DH_LA(fo, lane)[4 * j + 1];
+                            v.z = DH_LA(fo, lane)[4 * j + 2]; v.w = DH_LA(fo, lane)[4 * j + 3];
+                            dst[j] = v;
+                        }
                     }
                 }
             }
             DH_BARRIER();
 #if DH_PRIO_MODE == 1 || DH_PRIO_MODE == 3
             DH_SETPRIO(3);
+#elif DH_PRIO_MODE == 8 || DH_PRIO_MODE == 9
+            DH_SETPRIO(0);
 #elif DH_PRIO_MODE >= 6
             if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
 #endif

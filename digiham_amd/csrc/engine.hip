@@ -75,7 +75,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     __syncthreads();
 #if DH_PRIO_MODE >= 1 && DH_PRIO_MODE <= 5
     DH_SETPRIO(3);
-#elif DH_PRIO_MODE >= 6
+#elif DH_PRIO_MODE >= 6 && DH_PRIO_MODE <= 7
     if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
 #endif
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
@@ -241,6 +241,33 @@ __global__ void k_div_gain(const float* in, float* out, size_t n, double gain, d
 __global__ void k_div_const(const float* in, float* out, size_t n, float d, float r) {
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
         out[i] = dh_div_const(in[i], d, r);
+}
+
+// one tile per wavefront: D = C + A x B with v_mfma_f32_16x16x32_f16 (dh_debug_mfma_f16)
+__global__ __launch_bounds__(DH_WAVE) void k_mfma_f16(const uint16_t* A, const uint16_t* B, const float* C, float* D) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const size_t t = blockIdx.x;
+    const int l = threadIdx.x, m = l & 15, q = l >> 4;
+    typedef unsigned short dh_us8 __attribute__((ext_vector_type(8)));
+    dh_us8 a, b;
+    for (int j = 0; j < 8; j++) { a[j] = A[t * 512 + m * 32 + 8 * q + j]; b[j] = B[t * 512 + (8 * q + j) * 16 + m]; }
+    dh_f32x4 c;
+    for (int r = 0; r < 4; r++) c[r] = C[t * 256 + (4 * q + r) * 16 + m];
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dh_h8, a), __builtin_bit_cast(dh_h8, b), c, 0, 0, 0);
+    for (int r = 0; r < 4; r++) D[t * 256 + (4 * q + r) * 16 + m] = c[r];
+#endif
+}
+__global__ void k_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, float scale) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (size_t i = (blockIdx.x * (size_t) blockDim.x + threadIdx.x) * 4; i < n; i += (size_t) gridDim.x * blockDim.x * 4) {
+        dh_f4 v; v.x = in[i]; v.y = i + 1 < n ? in[i + 1] : 0.0f; v.z = i + 2 < n ? in[i + 2] : 0.0f; v.w = i + 3 < n ? in[i + 3] : 0.0f;
+        dh_h4 a, b;
+        dh_f16_split4(v, scale, a, b);
+        uint16_t t1[4], t2[4];
+        __builtin_memcpy(t1, &a, sizeof(t1)); __builtin_memcpy(t2, &b, sizeof(t2));      // the four halves as the kernels store them (one 8-byte vector)
+        for (int j = 0; j < 4 && i + j < n; j++) { h1[i + j] = t1[j]; h2[i + j] = t2[j]; }
+    }
+#endif
 }
 
 inline unsigned grid_for(size_t n, unsigned block) {
@@ -611,6 +638,19 @@ static int dh_be_div_gain(const float* in, float* out, size_t n, int narrow, voi
     if (!n) return DH_OK;
     const double gain = narrow ? DH_RRC_NARROW_GAIN : DH_RRC_WIDE_GAIN;
     hipLaunchKernelGGL(k_div_gain, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t) stream, in, out, n, gain, 1.0 / gain);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+
+static int dh_be_mfma_f16(const uint16_t* a, const uint16_t* b, const float* c, float* d, size_t tiles, void* stream) {
+    if (!tiles) return DH_OK;
+    hipLaunchKernelGGL(k_mfma_f16, dim3((unsigned) tiles), dim3(DH_WAVE), 0, (hipStream_t) stream, a, b, c, d);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+static int dh_be_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, float scale, void* stream) {
+    if (!n) return DH_OK;
+    hipLaunchKernelGGL(k_f16_split, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t) stream, in, h1, h2, n, scale);
     HIP_TRY(hipGetLastError());
     return DH_OK;
 }

@@ -119,6 +119,7 @@ struct Engine {
     uint32_t last_n = 0;
     DhDspParams dsp{}; DhRrcParams rrcp{}; DhDecParams dec{};
     float* custom_taps = nullptr; double custom_gain = 0.0;      // DH_RRC_CUSTOM: device copy of the caller's table
+    uint32_t* tapfrag = nullptr; float err_coef_f16 = 0.0f;      // split-f16 FIR of the wide filter: per-lane tap fragments (dh_f16_tap_fragments)
 
     int init(const dh_engine_config& c) {
         int rc = make_layout(c, L);
@@ -156,13 +157,26 @@ struct Engine {
             custom_gain = c.rrc_gain;
             if (be.upload(custom_taps, c.rrc_taps, sizeof(float) * (L.nz + 1)) || be.sync()) return DH_EDEVICE;   // the caller's table may go away
         }
+        if (L.fused && L.nz == 80) {
+            DhF16Taps* F = new (std::nothrow) DhF16Taps;
+            if (!F) return DH_ENOMEM;
+            float half[DH_MAX_NZ / 2 + 1]; double gain;
+            fill_taps(L.rrc, half, &gain);
+            dh_f16_tap_fragments(half, L.nz, *F);
+            err_coef_f16 = dh_f16_error_coefficient(*F, gain);
+            tapfrag = (uint32_t*) be.alloc(sizeof(F->frag));
+            rc = tapfrag ? be.upload(tapfrag, F->frag, sizeof(F->frag)) : DH_ENOMEM;
+            if (!rc) rc = be.sync();
+            delete F;
+            if (rc) return rc == DH_ENOMEM ? rc : DH_EDEVICE;
+        }
 #undef DH_ALLOC
         return reset();
     }
 
     void destroy() {
         void* ptrs[] = { dsp_state, syms, sym_count, sym_carry, dec_state, frames, frame_count, events, ev_count,
-                         overflow, filtered, rrc_hist, staging, tables, custom_taps };
+                         overflow, filtered, rrc_hist, staging, tables, custom_taps, tapfrag };
         for (void* p : ptrs) if (p) be.free(p);
     }
 
@@ -238,6 +252,7 @@ struct Engine {
             if (L.fused) {
                 fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain;
                 dsp.err_coef = dh_fir_error_coefficient(dsp.taps, L.nz, dsp.gain);
+                dsp.tapfrag = tapfrag; dsp.err_coef_f16 = err_coef_f16;
             }
             // slicer and decoder of a channel in one wavefront where the backend has that kernel (sps 10, wide or
             // no RRC); DH_FLAG_SPLIT_STAGES keeps the two launches (per-stage timing, A/B measurements)

@@ -256,6 +256,14 @@ int dh_debug_div_gain(const float* d_in, float* d_out, size_t n, int narrow, voi
  * evaluate it (reciprocal multiply + exact FMA residual + correction; IEEE division for 0, tiny, huge and non-finite
  * operands).  d_out[i] must equal d_in[i] / (float) divisor for every float. */
 int dh_debug_div_const(const float* d_in, float* d_out, size_t n, unsigned divisor, void* stream);
+/* The matrix-core instruction behind the error-bounded wide-filter FIR (v_mfma_f32_16x16x32_f16), one tile per item:
+ * d_d[t][16][16] = d_c[t][16][16] + d_a[t][16][32] x d_b[t][32][16], A and B as IEEE binary16 bit patterns.  The bound of
+ * that FIR rests on a stated assumption about how the hardware adds the products (dsp_core.hpp, "(H1)"): the parity tests
+ * check it through this entry. */
+int dh_debug_mfma_f16(const uint16_t* d_a, const uint16_t* d_b, const float* d_c, float* d_d, size_t tiles, void* stream);
+/* The split of a scaled sample into two halves as the same kernels do it: d_h1[i] = f16(x scale), d_h2[i] =
+ * f16((x scale - h1) 2^11), both rounded to nearest even, subnormal halves kept. */
+int dh_debug_f16_split(const float* d_in, uint16_t* d_h1, uint16_t* d_h2, size_t n, float scale, void* stream);
 
 #ifdef __cplusplus
 }

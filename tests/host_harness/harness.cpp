@@ -155,6 +155,24 @@ static int dh_be_frontend(const int16_t* in, size_t in_stride, float* out, size_
     return 0;
 }
 
+// (harness: products of halves are exact in f32; a k-ordered chain of rounded additions is one of the behaviours (H1) allows)
+static int dh_be_mfma_f16(const uint16_t* a, const uint16_t* b, const float* c, float* d, size_t tiles, void*) {
+    for (size_t t = 0; t < tiles; t++) for (int m = 0; m < 16; m++) for (int n = 0; n < 16; n++) {
+        float acc = c[t * 256 + m * 16 + n];
+        for (int k = 0; k < 32; k++) acc = __builtin_fmaf(dh_f16_value(a[t * 512 + m * 32 + k]), dh_f16_value(b[t * 512 + k * 16 + n]), acc);
+        d[t * 256 + m * 16 + n] = acc;
+    }
+    return 0;
+}
+static int dh_be_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, float scale, void*) {
+    for (size_t i = 0; i < n; i += 4) {
+        dh_f4 v; v.x = in[i]; v.y = i + 1 < n ? in[i + 1] : 0.0f; v.z = i + 2 < n ? in[i + 2] : 0.0f; v.w = i + 3 < n ? in[i + 3] : 0.0f;
+        uint16_t a[4], b[4];
+        dh_f16_split4(v, scale, a, b);
+        for (int j = 0; j < 4 && i + j < n; j++) { h1[i + j] = a[j]; h2[i + j] = b[j]; }
+    }
+    return 0;
+}
 static int dh_be_div_const(const float* in, float* out, size_t n, unsigned divisor, void*) {
     const float d = (float) divisor, r = 1.0f / d;
     for (size_t i = 0; i < n; i++) out[i] = dh_div_const(in[i], d, r);
