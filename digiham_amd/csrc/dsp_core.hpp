@@ -167,7 +167,7 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {     
 // young wavefront catches up with its elders and the last ones of a launch finish closer together (DMR chain -1.8 %,
 // slicer alone -2.7 %; 1 = only FIR low, 2 = only progress, 6 / 7 = progress for the last 4 096 / 8 192 channels: worse).
 #ifndef DH_PRIO_MODE
-#define DH_PRIO_MODE 3
+#define DH_PRIO_MODE 0
 #endif
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_PRIO_MODE
 #define DH_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
@@ -577,6 +577,9 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #ifndef DH_FIR_F16
 #define DH_FIR_F16 1
 #endif
+#ifndef DH_PF_REG
+#define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
+#endif
 #define DH_F16_KSTEPS 3                      // (80 + 16) / 32
 #define DH_F16_FRAGS (2 * DH_F16_KSTEPS)     // g1 fragments, then g2 fragments
 #define DH_F16_H2_OFFSET 552                 // word offset of the h2 array inside the window block (1104 halves = 552 words of h1 first)
@@ -676,18 +679,16 @@ __device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[DH_
     dh_h8 g[DH_F16_FRAGS];
 #pragma unroll
     for (int f = 0; f < DH_F16_FRAGS; f++) g[f] = __builtin_bit_cast(dh_h8, G[f]);
-    // two tiles at a time: their twelve window reads go out together, and their four accumulation chains (main and second
-    // sum of each) alternate, so no MFMA waits for the one before it
+    // Two tiles at a time, so that four accumulation chains (main and second sum of each) alternate and no MFMA waits for
+    // the one before it.  Only six 16-byte fragments of the window are live at once: the h2 fragment of a K step is read
+    // into the registers of the h1 fragment the step has just finished with, two steps before it is needed.
 #pragma unroll
     for (int TT = 0; TT < 4; TT += 2) {
         dh_h8 a1[2][DH_F16_KSTEPS], a2[2][DH_F16_KSTEPS];
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int s = 0; s < DH_F16_KSTEPS; s++) {
-                a1[t][s] = *reinterpret_cast<const dh_h8*>(base + 512 * (TT + t) + 64 * s);
-                a2[t][s] = *reinterpret_cast<const dh_h8*>(base + 512 * (TT + t) + 64 * s + 4 * DH_F16_H2_OFFSET);
-            }
+            for (int s = 0; s < DH_F16_KSTEPS; s++) a1[t][s] = *reinterpret_cast<const dh_h8*>(base + 512 * (TT + t) + 64 * s);
         dh_f32x4 mn[2] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } }, sc[2] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
 #pragma unroll
         for (int s = 0; s < DH_F16_KSTEPS; s++) {
@@ -695,6 +696,8 @@ __device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[DH_
             for (int t = 0; t < 2; t++) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[t][s], g[DH_F16_KSTEPS + s], sc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 2; t++) mn[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[t][s], g[s], mn[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) a2[t][s] = *reinterpret_cast<const dh_h8*>(base + 512 * (TT + t) + 64 * s + 4 * DH_F16_H2_OFFSET);
         }
 #pragma unroll
         for (int s = 0; s < DH_F16_KSTEPS; s++)
@@ -704,9 +707,12 @@ __device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[DH_
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) out16[4 * (TT + t) + r] = __builtin_fmaf(sc[t][r], k2, mn[t][r] * k1);
-        // scheduling groups: the pair's twelve 16-byte window reads first, then its eighteen MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+        // scheduling groups (DS read = 0x100, MFMA = 0x008): the order written above
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
     }
 }
 #else
@@ -1272,6 +1278,76 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // raw samples behind every entry of the 100-symbol rings are still at hand when a comparison has to be settled exactly
     uint32_t p = BOUNDED ? sth[DH_ST_P0] : 0u;          // read position in the filtered stream
     bool staged = false; uint32_t staged_p = 0;         // the LDS window already holds V[staged_p ...) (prefetch)
+    constexpr bool PF_REG = MF16 && DH_PF_REG;          // ... as two arrays of halves, with these constants of its run:
+    float st_e_run = 0.0f, st_k1 = 0.0f, st_k2 = 0.0f;
+    // split-f16 FIR: the window held in `varr` (five 16-byte groups per lane, as loaded) -> zeros beyond `have`, max |x| of the
+    // wavefront, the power-of-two scale that puts it into [0.5, 1), the two arrays of halves in the window block.  Returns
+    // false (nothing stored) when max |x| is outside the range the bound covers.
+    auto stage_f16 = [&](auto& varr, uint32_t have, float& e_out, float& k1_out, float& k2_out) __attribute__((always_inline)) -> bool {
+        constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;
+        DH_LANE_ARRAY(float, xm, 1);
+        DH_FOR_LANES_FRESH(lane) {
+            const uint32_t l4 = 4u * (uint32_t) lane;
+            if (have < DH_FTILE + NZ) {                // the last window of the push: zeros beyond the input
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
+                    dh_f4 w = DH_LA(varr, lane)[r];
+                    w.x = e + 0u < have ? w.x : 0.0f; w.y = e + 1u < have ? w.y : 0.0f;
+                    w.z = e + 2u < have ? w.z : 0.0f; w.w = e + 3u < have ? w.w : 0.0f;
+                    DH_LA(varr, lane)[r] = w;
+                }
+            }
+            float mx = 0.0f;                            // (a NaN is skipped here and caught behind the FIR)
+#pragma unroll
+            for (int r = 0; r < DH_PF_N; r++) {
+                const dh_f4 w = DH_LA(varr, lane)[r];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                mx = dh_max3_abs(w.x, w.y, mx); mx = dh_max3_abs(w.z, w.w, mx);
+#else
+                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y)));
+                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.z), __builtin_fabsf(w.w)));
+#endif
+            }
+            DH_LA(xm, lane)[0] = mx;
+        }
+        float xmax;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        xmax = dh_wave_max(xm[0]);
+#else
+        xmax = 0.0f;
+        for (int l = 0; l < DH_WAVE; l++) xmax = __builtin_fmaxf(xmax, xm[l][0]);
+#endif
+        float scale = 1.0f;
+        if (xmax == 0.0f) { e_out = 0.0f; k1_out = P.inv_gain; }                       // all zeros in, all zeros out
+        else if (xmax >= DH_BOUND_XMAX_LO && xmax <= DH_BOUND_XMAX_HI) {
+            union { float f; uint32_t u; } b; b.f = xmax;
+            const uint32_t ex = b.u >> 23;                                              // xmax in [2^(ex - 127), 2^(ex - 126))
+            b.u = (253u - ex) << 23; scale = b.f;                                       // 2^(126 - ex)
+            b.u = (ex + 1u) << 23; k1_out = P.inv_gain * b.f;                           // fl32(1 / gain) 2^(ex - 126): exact scaling
+            e_out = P.err_coef_f16 * xmax;
+        } else return false;                                                            // tiny, huge or infinite samples: outside the bound's assumptions
+        k2_out = k1_out * 0.00048828125f;                                               // 2^-11
+        DH_FOR_LANES_FRESH(lane) {
+            const bool in_last = (uint32_t) lane < LAST_LANES;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            dh_h4* d1 = reinterpret_cast<dh_h4*>(S.xf) + lane;                          // halves 4 lane .. 4 lane + 3 of group 0; group r is 256 halves on
+            dh_h4* d2 = reinterpret_cast<dh_h4*>(S.xf + DH_F16_H2_OFFSET) + lane;
+#pragma unroll
+            for (int r = 0; r < DH_PF_N; r++) {
+                dh_h4 a, b;
+                dh_f16_split4(varr[r], scale, a, b);
+                if (r < DH_PF_N - 1 || in_last) { d1[DH_WAVE * r] = a; d2[DH_WAVE * r] = b; }
+            }
+#else
+            uint16_t* d1 = reinterpret_cast<uint16_t*>(S.xf) + 4 * lane;
+            uint16_t* d2 = reinterpret_cast<uint16_t*>(S.xf + DH_F16_H2_OFFSET) + 4 * lane;
+            for (int r = 0; r < DH_PF_N; r++)
+                if (r < DH_PF_N - 1 || in_last) dh_f16_split4(varr[lane][r], scale, d1 + 4 * DH_WAVE * r, d2 + 4 * DH_WAVE * r);
+#endif
+        }
+        return true;
+    };
     uint32_t nsym = 0;
     bool overflow = false;
     const uint32_t max_run = (DH_FTILE - 2) / sps;      // symbols whose windows fit one FIR pass
@@ -1312,6 +1388,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // From the second run on, the window was already put there by the previous iteration's prefetch.
         if (staged && staged_p == p) {
             static_assert(DH_PF_L2 || !BOUNDED, "the register-prefetch build does not compute max |x| of a prefetched window: error-bounded kernels need DH_PF_L2");
+            if (PF_REG) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; }      // (put there by P7 of the previous run)
         } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
             // whole window inside the input buffer: unconditional loads (all in flight together, see the prefetch
             // below for why that matters), samples past the end of the stream zeroed afterwards
@@ -1333,73 +1410,37 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(v, lane)[r] = dh_load4_unaligned(lsrc + 4 * DH_WAVE * r);
                 if constexpr (LAST_LANES > 0) DH_LA(v, lane)[DH_PF_N - 1] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
                 else DH_LA(v, lane)[DH_PF_N - 1] = DH_LA(v, lane)[0];
-                if (have < DH_FTILE + NZ) {            // the last window of the push: zeros beyond the input
+                if (!MF16 || use_exact) {
+                    if (have < DH_FTILE + NZ) {        // the last window of the push: zeros beyond the input
 #pragma unroll
-                    for (int r = 0; r < DH_PF_N; r++) {
-                        const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
-                        dh_f4 w = DH_LA(v, lane)[r];
-                        w.x = e + 0u < have ? w.x : 0.0f; w.y = e + 1u < have ? w.y : 0.0f;
-                        w.z = e + 2u < have ? w.z : 0.0f; w.w = e + 3u < have ? w.w : 0.0f;
-                        DH_LA(v, lane)[r] = w;
+                        for (int r = 0; r < DH_PF_N; r++) {
+                            const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
+                            dh_f4 w = DH_LA(v, lane)[r];
+                            w.x = e + 0u < have ? w.x : 0.0f; w.y = e + 1u < have ? w.y : 0.0f;
+                            w.z = e + 2u < have ? w.z : 0.0f; w.w = e + 3u < have ? w.w : 0.0f;
+                            DH_LA(v, lane)[r] = w;
+                        }
                     }
-                }
-                if (BOUNDED) {                         // max |x| of the window (a NaN is skipped here and caught behind the FIR)
-                    float mx = 0.0f;
+                    if (BOUNDED) {                     // max |x| of the window (a NaN is skipped here and caught behind the FIR)
+                        float mx = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < DH_PF_N; r++) {
-                        const dh_f4 w = DH_LA(v, lane)[r];
+                        for (int r = 0; r < DH_PF_N; r++) {
+                            const dh_f4 w = DH_LA(v, lane)[r];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                        mx = dh_max3_abs(w.x, w.y, mx); mx = dh_max3_abs(w.z, w.w, mx);
+                            mx = dh_max3_abs(w.x, w.y, mx); mx = dh_max3_abs(w.z, w.w, mx);
 #else
-                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y)));
-                        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.z), __builtin_fabsf(w.w)));
+                            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y)));
+                            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.z), __builtin_fabsf(w.w)));
 #endif
+                        }
+                        DH_LA(xmax_lane, lane)[0] = mx;
                     }
-                    DH_LA(xmax_lane, lane)[0] = mx;
                 }
             }
             if (MF16 && !use_exact) {
-                // split-f16 FIR: the window goes to LDS as two arrays of halves, scaled by the power of two that puts the
-                // run's max |x| into [0.5, 1)
-                float xmax;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                xmax = dh_wave_max(xmax_lane[0]);
-#else
-                xmax = 0.0f;
-                for (int l = 0; l < DH_WAVE; l++) xmax = __builtin_fmaxf(xmax, xmax_lane[l][0]);
-#endif
+                // split-f16 FIR: the window goes to LDS as two arrays of halves (stage_f16)
                 xmax_done = true;
-                float scale = 1.0f;
-                if (xmax == 0.0f) { e_run = 0.0f; k1 = P.inv_gain; }                    // all zeros in, all zeros out
-                else if (xmax >= DH_BOUND_XMAX_LO && xmax <= DH_BOUND_XMAX_HI) {
-                    union { float f; uint32_t u; } b; b.f = xmax;
-                    const uint32_t ex = b.u >> 23;                                      // xmax in [2^(ex - 127), 2^(ex - 126))
-                    b.u = (253u - ex) << 23; scale = b.f;                               // 2^(126 - ex)
-                    b.u = (ex + 1u) << 23; k1 = P.inv_gain * b.f;                       // fl32(1 / gain) 2^(ex - 126): exact scaling
-                    e_run = P.err_coef_f16 * xmax;
-                } else use_exact = true;                                                // tiny, huge or infinite samples: outside the bound's assumptions
-                if (!use_exact) {
-                    k2 = k1 * 0.00048828125f;                                           // 2^-11
-                    DH_FOR_LANES_FRESH(lane) {
-                        const bool in_last = (uint32_t) lane < LAST_LANES;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                        dh_h4* d1 = reinterpret_cast<dh_h4*>(S.xf) + lane;              // halves 4 lane .. 4 lane + 3 of group 0; group r is 256 halves on
-                        dh_h4* d2 = reinterpret_cast<dh_h4*>(S.xf + DH_F16_H2_OFFSET) + lane;
-#pragma unroll
-                        for (int r = 0; r < DH_PF_N; r++) {
-                            dh_h4 a, b;
-                            dh_f16_split4(v[r], scale, a, b);
-                            if (r < DH_PF_N - 1 || in_last) { d1[DH_WAVE * r] = a; d2[DH_WAVE * r] = b; }
-                        }
-#else
-                        uint16_t* d1 = reinterpret_cast<uint16_t*>(S.xf) + 4 * lane;
-                        uint16_t* d2 = reinterpret_cast<uint16_t*>(S.xf + DH_F16_H2_OFFSET) + 4 * lane;
-                        for (int r = 0; r < DH_PF_N; r++)
-                            if (r < DH_PF_N - 1 || in_last) dh_f16_split4(v[lane][r], scale, d1 + 4 * DH_WAVE * r, d2 + 4 * DH_WAVE * r);
-#endif
-                    }
-                    f16_staged = true;
-                }
+                if (stage_f16(v, have, e_run, k1, k2)) f16_staged = true; else use_exact = true;
             }
             if (!f16_staged) {
                 DH_FOR_LANES_FRESH(lane) {
@@ -1657,10 +1698,26 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #if !DH_PF_L2
         DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
 #endif
+        DH_LANE_ARRAY(dh_f4, pfr, PF_REG ? DH_PF_N : 1);  // split-f16 kernels: the next window, parked in registers through P4 - P6
         // Only when the whole window lies inside the input buffer (every run but the last ones of the last
         // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
         // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
         const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
+        const bool pf_reg = PF_REG && pf_plain && P.exact_mode != 2;
+        if (pf_reg) {
+            // The split-f16 FIR leaves registers free where the packed-FMA FIR had none: the next window's five 16-byte loads
+            // per lane are issued here, straight from HBM, land while P4 - P6 run, and P7 turns them into the two arrays of
+            // halves -- the next iteration starts at the matrix cores.
+            constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;
+            const float* src = in + (p_next - tc);
+            DH_FOR_LANES_FRESH(lane) {
+                const float* lsrc = src + 4u * (uint32_t) lane;
+                const bool in_last = (uint32_t) lane < LAST_LANES;
+#pragma unroll
+                for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(pfr, lane)[PF_REG ? r : 0] = dh_load4_unaligned(lsrc + 4 * DH_WAVE * r);
+                DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+            }
+        } else {
 #if DH_PF_L2
         // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
         // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The dwords themselves are not
@@ -1691,6 +1748,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
 #endif
+        }
 
         // ---- P4: sliding AGC min/max as two wave scans
         if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
@@ -1706,38 +1764,52 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
         const float T = DH_BOUND_T_FACTOR * e_eff;
         uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
-        for (uint32_t h = 0; h * DH_WAVE < m && DH_STOP_AFTER >= 5; h++) {
+        // Straight-line per half of the run (m <= 100 symbols: lanes 0..63, then 0..35): every lane computes, a predicate
+        // guards the store -- written as a loop over the lane's symbols this compiled to a real loop with exec-mask
+        // bookkeeping (half of this phase's instructions were scalar).  The wave-uniform choices (4 / 2 levels, invert,
+        // exact_mode) are selects, not branches.
+        const bool four_levels = P.levels == 4;
+        const bool force_doubt = BOUNDED && P.exact_mode == 1;
+        const float inv_width = 1.0f / (float) (ev_hi - ev_lo);                       // (a power of two for sps 10: the product below is the division)
+        const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+        if (h * DH_WAVE < m && DH_STOP_AFTER >= 5) {
         uint64_t vote_unsure = 0;
         DH_FOR_LANES_FRESH(lane) {
+            const uint32_t q = h * DH_WAVE + (uint32_t) lane;
+            const bool valid = q < m;
+            const uint32_t qq = valid ? q : 0u, k = k0 + qq;                         // (lanes beyond the run recompute symbol 0: in-range reads, no store)
+            const float mn = S.mn[k], mx = S.mx[k];
+            const float center = (mx + mn) / 2.0f;
+            const float sumq = S.sum[qq];
+            const float average = width_pow2 ? sumq * inv_width : sumq / (float) (ev_hi - ev_lo);
+            // (float)((double)(max - center) * 0.625 + center), gfsk_demodulator.cpp:117-118: the product is exact
+            // in double (24 x 3 bits) and the sum is either exact there too or so lopsided that the small term
+            // cannot reach a float rounding boundary (|center| >= 2^-25 |max - center| unless it is 0), so the
+            // double-rounded result equals the single rounding of the exact value: one float FMA.
+            const float umid = __builtin_fmaf(mx - center, 0.625f, center);
+            const float lmid = __builtin_fmaf(mn - center, 0.625f, center);
+            const bool above = average > center;
+            const uint8_t sym4 = above ? (average > umid ? 1 : 0) : (average < lmid ? 3 : 2);
+            const uint8_t sym2 = above ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+            const uint8_t sym = four_levels ? sym4 : sym2;
             bool doubt = false;
-            for (uint32_t q = h * DH_WAVE + (uint32_t) lane; q < dh_min<uint32_t>(m, (h + 1u) * DH_WAVE); q += DH_WAVE) {
-                const uint32_t k = k0 + q;
-                const float mn = S.mn[k], mx = S.mx[k];
-                const float center = (mx + mn) / 2.0f;
-                const float average = S.sum[q] / (float) (ev_hi - ev_lo);
-                uint8_t sym;
-                if (P.levels == 4) {
-                    // (float)((double)(max - center) * 0.625 + center), gfsk_demodulator.cpp:117-118: the product is exact
-                    // in double (24 x 3 bits) and the sum is either exact there too or so lopsided that the small term
-                    // cannot reach a float rounding boundary (|center| >= 2^-25 |max - center| unless it is 0), so the
-                    // double-rounded result equals the single rounding of the exact value: one float FMA.
-                    const float umid = __builtin_fmaf(mx - center, 0.625f, center);
-                    const float lmid = __builtin_fmaf(mn - center, 0.625f, center);
-                    if (average > center) sym = average > umid ? 1 : 0;
-                    else sym = average < lmid ? 3 : 2;
-                    if (BOUNDED) doubt = __builtin_fabsf(average - umid) <= T || __builtin_fabsf(average - lmid) <= T;
-                } else {
-                    sym = average > center ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
-                }
-                if (BOUNDED) doubt = (e_eff > 0.0f && (doubt || __builtin_fabsf(average - center) <= T)) || P.exact_mode == 1;
-#ifdef DH_IGNORE_DOUBT                      // diagnostic builds: undecided symbols are NOT re-evaluated (wrong in a few symbols per 100 000; what do the exact evaluations cost?)
-                doubt = false;
-#endif
-                if (!doubt) syms[nsym + q] = sym;
+            if (BOUNDED) {
+                // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
+                // reference's; those symbols are not stored here but decided exactly below
+                const float d_mid = __builtin_fminf(__builtin_fabsf(average - umid), __builtin_fabsf(average - lmid));
+                const float d_all = __builtin_fminf(four_levels ? d_mid : DH_FLT_MAX, __builtin_fabsf(average - center));
+                doubt = valid && ((e_eff > 0.0f && !(d_all > T)) || force_doubt);       // (!(d > T): a NaN distance is a doubt)
             }
+#ifdef DH_IGNORE_DOUBT                      // diagnostic builds: undecided symbols are NOT re-evaluated (wrong in a few symbols per 100 000; what do the exact evaluations cost?)
+            doubt = false;
+#endif
+            if (valid && !doubt) syms[nsym + q] = sym;
             DH_BALLOT_ACC(vote_unsure, doubt, lane);
         }
-        if (h < 2) unsure[h] = vote_unsure;
+        unsure[h] = vote_unsure;
+        }
         }
         if (BOUNDED && (unsure[0] | unsure[1])) {
             DhExactCtx C;
@@ -2115,6 +2187,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #else
         staged = pf_plain; staged_p = p_next;
 #endif
+        if (pf_reg) {
+            if constexpr (PF_REG) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = p_next; }
+        }
         DH_BARRIER();
         p = p_next;
         nsym += m;
