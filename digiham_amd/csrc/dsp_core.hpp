@@ -577,6 +577,9 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #ifndef DH_FIR_F16
 #define DH_FIR_F16 1
 #endif
+#ifndef DH_EXACT_STAGED
+#define DH_EXACT_STAGED 1                    // the exact re-evaluations of the sps-10 kernels stage their raw samples through LDS, like the generic-sps ones
+#endif
 #ifndef DH_PF_REG
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
 #endif
@@ -1353,6 +1356,17 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const uint32_t max_run = (DH_FTILE - 2) / sps;      // symbols whose windows fit one FIR pass
 
     DH_CLK(7);
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    // split-f16 FIR: this lane's six tap fragments -- 16-byte loads, 1 KiB per instruction, the same 6 KiB for every wavefront
+    // of the chip (L1 / L2 hits).  Requested one iteration ahead (here, and again at the end of every iteration, when the
+    // staging registers are free), so they have landed when P2 wants them.
+    dh_u4 tapfrag_regs[DH_F16_FRAGS];
+#define DH_TAPFRAG_LOAD() do { if constexpr (MF16) { const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(P.tapfrag) + dh_fresh_lane_id_(); \
+        _Pragma("unroll") for (int f_ = 0; f_ < DH_F16_FRAGS; f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
+    DH_TAPFRAG_LOAD();
+#else
+#define DH_TAPFRAG_LOAD() ((void) 0)
+#endif
     for (;;) {
         // ---- run planning (wave-uniform): symbols k0 .. k0+m-1 of the current variance block.
         // A symbol at filtered position s is produced iff nf - s > sps + 1 (gfsk_demodulator.cpp:18-22);
@@ -1529,13 +1543,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         DH_FOR_LANES_FRESH(lane) {
                             float t = 0.0f;
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                            // the tap fragments: six 16-byte loads per lane, 1 KiB per instruction, the same 6 KiB for every
-                            // wavefront of the chip (L1 / L2 hits); requested here, where the staging registers are free again,
-                            // they arrive behind the window reads
-                            dh_u4 tapfrag_regs[DH_F16_FRAGS];
-                            const dh_u4* tf = reinterpret_cast<const dh_u4*>(P.tapfrag) + lane;
-#pragma unroll
-                            for (int f = 0; f < DH_F16_FRAGS; f++) tapfrag_regs[f] = tf[DH_WAVE * f];
                             dh_fir_f16(S.xf, tapfrag_regs, lane, k1, k2, fo);
 #else
                             dh_fir_f16(S.xf, reinterpret_cast<const uint32_t (*)[DH_WAVE][4]>(P.tapfrag), lane, k1, k2, fo[lane]);
@@ -1805,7 +1812,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #ifdef DH_IGNORE_DOUBT                      // diagnostic builds: undecided symbols are NOT re-evaluated (wrong in a few symbols per 100 000; what do the exact evaluations cost?)
             doubt = false;
 #endif
+#ifdef DH_P5_NOSTORE                        // diagnostic builds: the dibits are computed but (practically) never stored -- what do the byte stores cost?
+            if (valid && !doubt && sym == 77) syms[nsym + q] = sym;
+#else
             if (valid && !doubt) syms[nsym + q] = sym;
+#endif
             DH_BALLOT_ACC(vote_unsure, doubt, lane);
         }
         unsure[h] = vote_unsure;
@@ -1823,7 +1834,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 while (todo) {
                     const uint32_t q = (uint32_t) dh_ffs64(todo) + 64u * (uint32_t) h;
                     todo &= todo - 1;
-                    const uint8_t sym = SPS == 0 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, sps, ev_lo, ev_hi)
+                    // (the raw samples behind each evaluation staged through the dead part of the window block: fetched one by
+                    // one from HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
+                    const uint8_t sym = DH_EXACT_STAGED || SPS == 0 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, sps, ev_lo, ev_hi)
                                                  : dh_exact_symbol<NZ, SPS ? SPS : 10>(C, S, k0 + q, S.xf + 640);
                     DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
                     BS->n_uncertain++;
@@ -1855,11 +1868,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             if (SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
-                // (nothing per lane is carried from pass to pass in registers: the compiler parks such values in scratch
-                // memory -- a store and a reload per block and lane, 2.4 GB of HBM writes per launch -- so the row offset is
-                // recomputed and the mean goes through LDS)
-                float* pmean = psum + 64;                       // psum uses [0, 50)
-                // pass 1: partial sums, two interleaved chains per lane (packed adds)
+                // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
+                // V' = Q' / 100 - mean'^2 loses more to cancellation than the reference's two passes, and its tolerance says
+                // so: with S', Q' the float sums (chains of 10 + 1 + 4 roundings: 15 u), 0.01f for 1 / 100 (0.4 u) and m2 =
+                // mean x^2 = sigma^2 + mu^2 >= A^2:
+                //   |Q' 0.01f - m2| <= 16.4 u m2,  |mean' - mu| <= 16.4 u A  =>  |mean'^2 - mu^2| <= 32.8 u m2,  the final fma 1 u m2
+                //   |V' - sigma^2| <= 50.2 u m2 = 3.0e-6 m2;  V_ref within (100.1 u A)^2 + 1.2e-14 V of sigma^2: 3.6e-11 m2
+                // so tol = 4e-6 m2' + 1e-42 (m2' = Q' 0.01f, within 1e-6 of m2; 1e-42 for up to ~120 subnormal roundings).
+                // A strong DC component (mu^2 >> sigma^2) widens the intervals; what they cannot separate goes to the ordered
+                // chain as before.
                 DH_FOR_LANES_FRESH(lane) {
                     if (lane < 50) {
                         // lane = 5 i + g: eight consecutive lanes then read 16-byte pieces 20 or 40 words apart, which fall into
@@ -1868,35 +1885,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         const uint32_t i = ((uint32_t) lane * 205u) >> 10, g = (uint32_t) lane - 5u * i;      // lane / 5, lane % 5
                         const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
                         const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
-                        dh_f2 s2 = dh_f2_make(0.0f, 0.0f);
+                        dh_f2 s2 = dh_f2_make(0.0f, 0.0f), q2 = dh_f2_make(0.0f, 0.0f);
 #pragma unroll
                         for (int q = 0; q < 5; q++) {
                             const dh_f4a v = row[q];
-                            s2 = dh_f2_add(s2, dh_f2_make(v.x, v.y)); s2 = dh_f2_add(s2, dh_f2_make(v.z, v.w));
+                            const dh_f2 a = dh_f2_make(v.x, v.y), b = dh_f2_make(v.z, v.w);
+                            s2 = dh_f2_add(s2, a); s2 = dh_f2_add(s2, b);
+                            q2 = dh_f2_fma(a, a, q2); q2 = dh_f2_fma(b, b, q2);
                         }
-                        psum[lane] = s2.x + s2.y;
-                    }
-                }
-                DH_BARRIER();
-                // pass 2: squared deviations from the float mean, again two chains per lane (packed subtract + FMA)
-                DH_FOR_LANES_FRESH(lane) {
-                    if (lane < 50) {
-                        const uint32_t i = ((uint32_t) lane * 205u) >> 10, g = (uint32_t) lane - 5u * i;
-                        const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
-                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
-                        const float* ps = psum + 5u * i;
-                        const float total = (((ps[0] + ps[1]) + ps[2]) + ps[3]) + ps[4];
-                        const float mean = total * 0.01f;
-                        const dh_f2 m2 = dh_f2_make(mean, mean);
-                        dh_f2 a2 = dh_f2_make(0.0f, 0.0f);
-#pragma unroll
-                        for (int q = 0; q < 5; q++) {
-                            const dh_f4a v = row[q];
-                            const dh_f2 d0 = dh_f2_sub(m2, dh_f2_make(v.x, v.y)), d1 = dh_f2_sub(m2, dh_f2_make(v.z, v.w));
-                            a2 = dh_f2_fma(d0, d0, a2); a2 = dh_f2_fma(d1, d1, a2);
-                        }
-                        pd[lane] = a2.x + a2.y;
-                        if (g == 0) pmean[i] = mean;
+                        psum[lane] = s2.x + s2.y; pd[lane] = q2.x + q2.y;
                     }
                 }
                 DH_BARRIER();
@@ -1908,14 +1905,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     bool guard = true, vzero = false;
                     if (lane < 10) {
                         const int i = lane;
-                        const float v = ((((pd[5 * i] + pd[5 * i + 1]) + pd[5 * i + 2]) + pd[5 * i + 3]) + pd[5 * i + 4]) * 0.01f;
-                        const float mean = pmean[lane];
-                        const float e = __builtin_fmaf(mean, mean, v);
-                        float tol = __builtin_fmaf(v, 4e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
+                        const float total = (((psum[5 * i] + psum[5 * i + 1]) + psum[5 * i + 2]) + psum[5 * i + 3]) + psum[5 * i + 4];
+                        const float e = ((((pd[5 * i] + pd[5 * i + 1]) + pd[5 * i + 2]) + pd[5 * i + 3]) + pd[5 * i + 4]) * 0.01f;      // mean x^2
+                        const float mean = total * 0.01f;
+                        const float v = __builtin_fmaf(-mean, mean, e);
+                        float tol = __builtin_fmaf(e, 4e-6f, 1e-42f);
                         // error-bounded mode: the ring holds values within e_blk of the reference's; moving every sample by
                         // up to e_blk moves the mean by <= e_blk, every deviation by <= 2 e_blk and the variance by
                         // <= 4 e_blk sqrt(V) + 4 e_blk^2 (Cauchy-Schwarz); taken twice over for the float mean's own rounding
-                        if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * __builtin_sqrtf(v + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
+                        if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * __builtin_sqrtf(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
                         guard = e < 1e30f;                           // false for NaN, and for samples beyond ~1e15 (e overflows first)
                         vzero = v == 0.0f;
                         l = v - tol; h = v + tol;
@@ -2073,7 +2071,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
                         // (the window block is dead here except words 512..575, where the L2 touch of the next window may
                         // still be dropping its dwords: the staged variant uses the words behind them)
-                        if (SPS == 0) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u);
+                        if (DH_EXACT_STAGED || SPS == 0) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u);
                         else dh_exact_var_ring<NZ>(C, S, sps);
                         BS->n_exact_blocks++;
                         DH_BARRIER();
@@ -2204,6 +2202,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else { BS->e_cur = ec; BS->e_count = cnt; }
             if (block_done) { BS->prev_start = BS->cur_start; BS->prev_off = BS->cur_off; BS->blk_flags = (BS->blk_flags & 1u) ? 2u : 0u; }
         }
+        DH_TAPFRAG_LOAD();                              // for the next run
         DH_CLK(6);
     }
 
