@@ -70,26 +70,64 @@ WORKLOADS = {
 UNITS = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}     # bursts / frames per step: ~3.96-4 s
 
 
-def profiled_traffic(workload, channels, T, part0=False):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
-    KiB, per-dispatch average; MI355X_MICROARCH.md) -- bench.py cannot collect counters itself.  Only for the
-    configuration those passes were run on (tools/profile_gpu.sh: the default workload); newest round first.
+def profiled_counters(workload, channels, T, part0=False):
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot collect counters itself):
+    HBM bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE (KiB, per-dispatch average; MI355X_MICROARCH.md), and the share of
+    the SIMDs' cycles on which a vector instruction issued.  Only for the configuration those passes were run on
+    (tools/profile_gpu.sh: 16 384 channels, 4 096 for the RRC-only configs); newest round first.
     part0: the push goes out as two launches; take the lines of the first one (kernel template argument PART = 0)."""
-    if workload != "dmr_full" or channels != 16384 or T != 190080:
-        return None, None
+    want_B = 4096 if workload.startswith("rrc_gfsk") else 16384
+    if channels != want_B:
+        return {}
     pdir = os.path.join(ROOT, "profiles")
-    want = lambda line: "k_chain" in line and (not part0 or ", 10, 0>" in line)
-    for name in sorted((f for f in os.listdir(pdir) if f.endswith("_chain_pmc.txt")), reverse=True):
-        fetch = write = None
+    kern = "k_rrc_tile" if workload.startswith("rrc_gfsk") else "k_chain"
+    want = lambda line: kern in line and (not part0 or ", 10, 0>" in line)
+    names = sorted((f for f in os.listdir(pdir) if f.endswith("_%s_pmc.txt" % workload) or (workload == "dmr_full" and f.endswith("_chain_pmc.txt"))), reverse=True)
+    for name in names:
+        c = {}
         for line in open(os.path.join(pdir, name)):
-            if want(line) and " FETCH_SIZE " in line:
-                fetch = float(line.split("avg=")[1].split()[0])
-            if want(line) and " WRITE_SIZE " in line:
-                write = float(line.split("avg=")[1].split()[0])
-        if fetch is not None and write is not None:
-            return fetch * 2.0 * 1024.0 + write * 1024.0, \
-                "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)" % name
-    return None, None
+            if want(line) and "avg=" in line:
+                for key in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
+                    if " %s " % key in line and key not in c:
+                        c[key] = float(line.split("avg=")[1].split()[0])
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out = {"traffic": c["FETCH_SIZE"] * 2.0 * 1024.0 + c["WRITE_SIZE"] * 1024.0,
+                   "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)" % name}
+            if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+                out["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+            for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA"):
+                if k in c:
+                    out[k.lower() + "_per_launch"] = c[k]
+            return out
+    return {}
+
+
+_COPY_GBS = {}
+
+
+def copy_ceiling(torch, device):
+    """What a plain streaming kernel reaches on this lease: a 2 GiB device-to-device copy (16 bytes per lane), read + write
+    bytes over its duration -- the achievable HBM ceiling SURVEY.md section 8(d) asks for beside the 8 TB/s of the data sheet."""
+    key = str(device)
+    if key not in _COPY_GBS:
+        n = 1 << 29                                  # floats: 2 GiB in, 2 GiB out
+        a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        _COPY_GBS[key] = 5 * 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
+    return _COPY_GBS[key]
 
 
 def oracle_kw(proto):
@@ -123,6 +161,19 @@ def effective_cores():
     return visible, max(1, eff)
 
 
+def outputs_sha(syms, sym_count, frames, frame_count):
+    """SHA-256 over every channel's dibits and decoder bytes of one push (counts included)."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(sym_count, dtype=np.uint32).tobytes())
+    h.update(np.ascontiguousarray(frame_count, dtype=np.uint32).tobytes())
+    for b in range(len(sym_count)):
+        h.update(np.ascontiguousarray(syms[b, :sym_count[b]]).tobytes())
+        h.update(np.ascontiguousarray(frames[b, :frame_count[b]]).tobytes())
+    return h.hexdigest()
+
+
 def cpu_baseline(x_host_fn, proto, budget_s=12.0):
     """Time the oracle (unpinned scalar CPU restatement of the reference pipe) on the host cores this process may use."""
     from oracle import oracle as O
@@ -137,14 +188,15 @@ def cpu_baseline(x_host_fn, proto, budget_s=12.0):
     chans = min(chans, 16384)
     x = x_host_fn(chans)
     t0 = time.perf_counter()
-    O.chain(x, threads=cores, **oracle_kw(proto))
+    ref = O.chain(x, threads=cores, **oracle_kw(proto))
     dt = time.perf_counter() - t0
+    ref_sha = outputs_sha(ref["syms"], ref["sym_count"], ref["out"], ref["out_count"])
     rate = x.size / dt
     per_core, single = rate / 1e6 / cores, 1e-6 / per_sample
     return {"value": rate / SAMPLE_RATE, "unit": "channels", "msamples_per_s": rate / 1e6,
             "msamples_per_s_per_core": per_core, "single_thread_msamples_per_s": single,
             "cores": cores, "cores_visible": visible, "cores_effective": cores, "oversubscribed": bool(per_core < 0.5 * single),
-            "kind": "port",
+            "kind": "port", "outputs_sha256": ref_sha, "channels_hashed": int(chans),
             "what": "CPU restatement (unpinned port): oracle/ C code, not the reference binaries -- rrc_filter / gfsk_demodulator / "
                     "*_decoder need csdr, which this image lacks, so examples/dmr-decoder.sh itself cannot be timed here",
             "sample": "%d channels x %d samples of the same synthetic workload through oracle/ (scalar C restatement of "
@@ -284,18 +336,31 @@ class Job:
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         taps = {"wide": 81, "narrow": 161, "none": 0}[kw["rrc"]]
         fir_flops = B * T * 2.0 * taps              # one mul + one add per tap and sample, unfused
-        traffic, traffic_src = profiled_traffic(self.workload, p["B"], T, part0=group is not None) if dom_name == "k_chain" else (None, None)
+        pc = profiled_counters(self.workload, p["B"], T, part0=group is not None)
         mean = lambda a: float(np.mean(a)) if len(a) else None
-        bounded = dom_name == "k_chain" and not kw.get("fast_fir") and ((kw["rrc"] == "wide" and kw["sps"] == 10) or kw["rrc"] == "narrow")
+        f16 = dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "wide" and kw["sps"] == 10
+        bounded = f16 or (dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "narrow")
+        ceiling = copy_ceiling(self.torch, p["x"].device)
+        if f16:
+            what = ("vector instruction issue: the 81-tap FIR runs as a split-f16 product on the matrix cores (36 v_mfma_f32_16x16x32_f16 per 1024 "
+                    "outputs, error radius carried, undecided comparisons re-evaluated with the reference's rounded arithmetic: bit-exact output); "
+                    "what remains is the slicer's and decoder's vector / scalar work")
+        else:
+            what = "fp32 VALU (%d-tap FIR, %s)" % (taps, "FMA" if kw.get("fast_fir") else
+                                                   "FMA with a proven error radius, undecided comparisons re-evaluated with the reference's rounded arithmetic: bit-exact output"
+                                                   if bounded else "unfused mul+add for bit-exactness")
+        co = {"what": what, "fir_useful_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops_f32_vector": 157.3}
+        for k in ("valu_issue_frac", "mfma_busy_frac", "sq_insts_valu_per_launch", "sq_insts_salu_per_launch", "sq_insts_mfma_per_launch"):
+            if k in pc:
+                co[k] = pc[k]
         return {"bound": "hbm", "kernel": dom_name + ("<%s>" % kw["proto"] if dom_name == "k_chain" else "") + (" PART 0" if group else ""),
                 "launch_group": group,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBS, "peak_achievable": ceiling, "frac_of_achievable": achieved / ceiling,
+                "peak_achievable_source": "2 GiB device-to-device copy timed on this lease (read + write bytes)",
+                "traffic": pc.get("traffic"), "traffic_source": pc.get("traffic_source"),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                "co_limit": {"what": "fp32 VALU (%d-tap FIR, %s)" % (taps, "FMA" if kw.get("fast_fir") else
-                                                                       "FMA with a proven error radius, undecided comparisons re-evaluated with the reference's rounded arithmetic: bit-exact output"
-                                                                       if bounded else "unfused mul+add for bit-exactness"),
-                             "achieved_tflops": fir_flops / (dom_ms * 1e-3) / 1e12, "peak_tflops": 157.3}}, \
+                "co_limit": co}, \
                {"rrc": mean(rrc_ms), "slicer": mean(slicer_ms), "decoder": mean(dec_ms)}
 
     def verify(self, ctx, nv, reps=2):
@@ -309,7 +374,8 @@ class Job:
             kw, T = p["kw"], p["T"]
             n = min(nv, p["B"])
             small = api.Engine(n, T, ctx=ctx, **kw)
-            xs = p["x"][:n].contiguous()
+            pick = self.torch.linspace(0, p["B"] - 1, n, device=p["x"].device).round().long()      # spread over the whole batch
+            xs = p["x"][pick].contiguous()
             got_s, got_f, got_y = [[] for _ in range(n)], [[] for _ in range(n)], []
             for _ in range(reps):
                 small.push(xs)
@@ -347,7 +413,7 @@ class Job:
                     ok &= err <= 1e-6
                 else:
                     ok &= bool((y.view(np.uint32) == r.view(np.uint32)).all())
-        out = {"channels": nv, "pushes": reps, "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir"), "frame_bytes": frame_bytes}
+        out = {"channels": nv, "sampling": "evenly spread over the batch", "pushes": reps, "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir"), "frame_bytes": frame_bytes}
         if self.kw.get("fast_fir"):
             out.update({"within_1e-6_vs_oracle": bool(ok), "max_rel_err": worst})
         return ok, out
@@ -369,7 +435,9 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
                                                               "; pushes overlapped on the engine's own streams (DH_FLAG_OVERLAP_PUSHES)" if overlap else ""),
                  "launch_group": roof.get("launch_group"),
                  "steps": steps, "ms_per_step": dt / steps * 1e3, "value": job.samples_per_step * steps / dt / SAMPLE_RATE, "unit": "channels",
-                 "kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "frac": roof["frac"], "stage_ms": stage}
+                 "kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "frac": roof["frac"], "frac_of_achievable": roof["frac_of_achievable"],
+                 "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "traffic": roof["traffic"], "traffic_source": roof["traffic_source"],
+                 "stage_ms": stage}
         if verify:
             ok, entry["verified"] = job.verify(ctx, min(verify, 4))
             assert ok, "GPU output differs from the oracle (%s)" % workload
@@ -396,7 +464,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--split-stages", action="store_true", help="slicer and decoder as two kernels (per-stage timing)")
     ap.add_argument("--overlap", action="store_true", help="DH_FLAG_OVERLAP_PUSHES: pushes as two launches on the engine's own streams, joined at the end")
-    ap.add_argument("--verify", type=int, default=8, help="channels checked bit-exact against the oracle after the run")
+    ap.add_argument("--verify", type=int, default=64, help="channels checked bit-exact against the oracle after the run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -467,9 +535,20 @@ def main():
             def host_rows(k):
                 return np.ascontiguousarray(x0[:k].cpu().numpy())
             try:
-                line["cpu_baseline"] = cpu_baseline(host_rows, proto)
+                line["cpu_baseline"] = cb = cpu_baseline(host_rows, proto)
             except Exception as e:          # the baseline is a report, never a reason to lose the GPU number
-                line["cpu_baseline"] = {"error": repr(e)}
+                line["cpu_baseline"] = cb = {"error": repr(e)}
+            if "outputs_sha256" in cb and job.kw["proto"] != "none":
+                # the same channels through a fresh engine of the product: every byte the oracle run of the baseline produced
+                k = cb["channels_hashed"]
+                eng = api.Engine(k, T, ctx=ctx, **job.kw)
+                eng.push(x0[:k].contiguous())
+                gs, gsc = eng.symbols()
+                gf, gfc = eng.frames()
+                eng.close()
+                cb["gpu_outputs_sha256"] = outputs_sha(gs, gsc, gf, gfc)
+                cb["gpu_matches_baseline_outputs"] = cb["gpu_outputs_sha256"] == cb["outputs_sha256"]
+                assert cb["gpu_matches_baseline_outputs"], "GPU output differs from the oracle run of the CPU baseline"
     job.close()
     del job
     if rank == 0:
