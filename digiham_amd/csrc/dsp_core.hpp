@@ -583,9 +583,12 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #ifndef DH_PF_REG
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
 #endif
-#define DH_F16_KSTEPS 3                      // (80 + 16) / 32
-#define DH_F16_FRAGS (2 * DH_F16_KSTEPS)     // g1 fragments, then g2 fragments
-#define DH_F16_H2_OFFSET 552                 // word offset of the h2 array inside the window block (1104 halves = 552 words of h1 first)
+// K = taps + 15 rounded up to whole MFMAs of 32: three for the wide filter (96), six for the narrow one (192; taps beyond the
+// response are zeros in the fragments, and the halves beyond the window are stored as zeros)
+#define DH_F16_KSTEPS_OF(nz) (((nz) + 16 + 31) / 32)
+#define DH_F16_MAX_KSTEPS DH_F16_KSTEPS_OF(DH_MAX_NZ)
+#define DH_F16_HALVES_OF(nz) (1008 + 32 * DH_F16_KSTEPS_OF(nz))     // halves per array: the last block (63) reads up to here
+#define DH_F16_H2_OFFSET_OF(nz) (DH_F16_HALVES_OF(nz) / 2)           // word offset of the h2 array inside the window block
 #define DH_F16_OUT(T, r, g, n) (256u * (uint32_t) (T) + 64u * (uint32_t) (g) + 16u * (uint32_t) (r) + (uint32_t) (n))
 
 // IEEE binary16 <-> binary32 in integer arithmetic (host and harness; the device converts in hardware): round to nearest even
@@ -613,7 +616,8 @@ DH_HD float dh_f16_value(uint16_t h) {
 
 // the split of a tap and the per-lane B operands (host, once per engine): frag[f][lane][d], f = 0..2 the g1 slices, 3..5 the g2 slices
 struct DhF16Taps {
-    uint32_t frag[DH_F16_FRAGS][DH_WAVE][4];
+    uint32_t frag[2 * DH_F16_MAX_KSTEPS][DH_WAVE][4];        // the first 2 * DH_F16_KSTEPS_OF(nz) are used
+    uint32_t ksteps;
     double l1, l1_g1, l1_g2, sum_delta;
 };
 inline void dh_f16_tap_fragments(const float* taps_half, uint32_t nz, DhF16Taps& F) {
@@ -629,28 +633,31 @@ inline void dh_f16_tap_fragments(const float* taps_half, uint32_t nz, DhF16Taps&
         F.l1 += c < 0 ? -(double) c : (double) c; F.l1_g1 += __builtin_fabs((double) dh_f16_value(g1[i]));
         F.l1_g2 += __builtin_fabs(v2); F.sum_delta += __builtin_fabs(delta);
     }
-    for (int f = 0; f < DH_F16_FRAGS; f++) for (int lane = 0; lane < DH_WAVE; lane++) for (int d = 0; d < 4; d++) {
-        const int n = lane & 15, q = lane >> 4, s = f % DH_F16_KSTEPS;
+    const int KS = (int) DH_F16_KSTEPS_OF(nz);
+    F.ksteps = (uint32_t) KS;
+    for (int f = 0; f < 2 * KS; f++) for (int lane = 0; lane < DH_WAVE; lane++) for (int d = 0; d < 4; d++) {
+        const int n = lane & 15, q = lane >> 4, s = f % KS;
         uint32_t w = 0;
         for (int hh = 0; hh < 2; hh++) {
             const int t = 32 * s + 8 * q + 2 * d + hh - n;
-            const uint16_t v = (t >= 0 && t <= (int) nz) ? (f < DH_F16_KSTEPS ? g1[t] : g2[t]) : 0;
+            const uint16_t v = (t >= 0 && t <= (int) nz) ? (f < KS ? g1[t] : g2[t]) : 0;
             w |= (uint32_t) v << (16 * hh);
         }
         F.frag[f][lane][d] = w;
     }
 }
 // error radius of a filtered sample per unit of max |x| for this path (see above; everything in units of u / gain):
-//   reference: 82 (gamma_82, + second order) L1 + 1.0001 L1 (its division and rounding)
-//   main sum:  123 L1(g1) (1 + 2^-11) ((H1), three MFMAs; |h1| <= max |x_s| (1 + 2^-11))
-//   second sum: 2^-11 246 (L1(g2) + L1(g1) / 2)
+//   reference: (taps + 1) (gamma, + second order) L1 + 1.0001 L1 (its division and rounding): 82 for the wide filter
+//   main sum:  41 KS L1(g1) (1 + 2^-11) ((H1), KS chained MFMAs -- 123 for the wide filter; |h1| <= max |x_s| (1 + 2^-11))
+//   second sum: 2^-11 82 KS (L1(g2) + L1(g1) / 2)
 //   residuals (absolute in the scaled domain, where max |x_s| >= 1/2: twice as much per unit of max |x|):
 //              2 (2^-22 L1(g2) / 2 + sum |delta| (1 + 2^-12) + u L1) / u
 //   combine:   3.1 L1 (fl32(1 / gain), the multiply, the fma)
 // times 1.44 for the slicer's own roundings, as in dh_fir_error_coefficient.
-inline float dh_f16_error_coefficient(const DhF16Taps& F, double gain) {
+inline float dh_f16_error_coefficient(const DhF16Taps& F, uint32_t nz, double gain) {
     const double u = 5.9604644775390625e-08;
-    const double kl1 = 82.01 * F.l1 + 1.0001 * F.l1 + 123.0 * F.l1_g1 * (1.0 + 1.0 / 2048.0) + 246.0 / 2048.0 * (F.l1_g2 + 0.5 * F.l1_g1)
+    const double ks = (double) F.ksteps, nref = 2.0 + (double) nz;                     // gamma_(taps + 1) for the reference's chain
+    const double kl1 = (nref + 0.01) * F.l1 + 1.0001 * F.l1 + 41.0 * ks * F.l1_g1 * (1.0 + 1.0 / 2048.0) + 82.0 * ks / 2048.0 * (F.l1_g2 + 0.5 * F.l1_g1)
                      + 2.0 * (0.5 * F.l1_g2 / 4194304.0 + F.sum_delta * (1.0 + 1.0 / 4096.0) + u * F.l1) / u + 3.1 * F.l1;
     const double coef = 1.44 * kl1 * u / (gain < 0 ? -gain : gain) * 1.0001;
     float f = (float) coef;
@@ -676,7 +683,9 @@ __device__ __forceinline__ void dh_f16_split4(const dh_f4& v, float scale, dh_h4
 // acc16[4 T + r] of lane (n, g) = y-before-gain of output DH_F16_OUT(T, r, g, n) in the scaled domain: main + 2^-11 second sum
 // is formed by the caller's fma (k1, k2).  `hw` = the window block (h1 at byte 0, h2 at DH_F16_H2_OFFSET words), G = the six
 // tap fragments of this lane.
-__device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[DH_F16_FRAGS], int lane, float k1, float k2, float* out16) {
+template <int NZ>
+__device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[2 * DH_F16_KSTEPS_OF(NZ)], int lane, float k1, float k2, float* out16) {
+    constexpr int DH_F16_KSTEPS = DH_F16_KSTEPS_OF(NZ), DH_F16_FRAGS = 2 * DH_F16_KSTEPS, DH_F16_H2_OFFSET = DH_F16_H2_OFFSET_OF(NZ);
     const int m = lane & 15, q = lane >> 4;
     const char* base = reinterpret_cast<const char*>(hw) + 32 * m + 16 * q;
     dh_h8 g[DH_F16_FRAGS];
@@ -711,11 +720,10 @@ __device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[DH_
 #pragma unroll
             for (int r = 0; r < 4; r++) out16[4 * (TT + t) + r] = __builtin_fmaf(sc[t][r], k2, mn[t][r] * k1);
         // scheduling groups (DS read = 0x100, MFMA = 0x008): the order written above
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * DH_F16_KSTEPS, 0);
+#pragma unroll
+        for (int s = 0; s < DH_F16_KSTEPS; s++) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * DH_F16_KSTEPS, 0);
     }
 }
 #else
@@ -730,7 +738,9 @@ inline void dh_f16_split4(const dh_f4& v, float scale, uint16_t* h1, uint16_t* h
         h2[i] = dh_f16_bits(r * 2048.0f);
     }
 }
+template <int NZ>
 inline void dh_fir_f16(const float* hw, const uint32_t (*G)[DH_WAVE][4], int lane, float k1, float k2, float* out16) {
+    constexpr int DH_F16_KSTEPS = DH_F16_KSTEPS_OF(NZ), DH_F16_H2_OFFSET = DH_F16_H2_OFFSET_OF(NZ);
     const uint16_t* h1 = reinterpret_cast<const uint16_t*>(hw);
     const uint16_t* h2 = reinterpret_cast<const uint16_t*>(hw + DH_F16_H2_OFFSET);
     const int n = lane & 15, g = lane >> 4;
@@ -1217,7 +1227,7 @@ template <int NZ, bool FAST, int SPS>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
     static_assert(SPS == 0 || SPS == 10, "only sps 10 is specialised");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
-    constexpr bool MF16 = DH_FIR_F16 && BOUNDED && NZ == 80;                         // its fused FIR as a split-f16 product on the matrix cores
+    constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -1331,22 +1341,27 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             e_out = P.err_coef_f16 * xmax;
         } else return false;                                                            // tiny, huge or infinite samples: outside the bound's assumptions
         k2_out = k1_out * 0.00048828125f;                                               // 2^-11
+        // (the arrays are as long as the last block's K range reaches: the halves behind the window, under zero taps, must be
+        // finite -- the lanes of the last group beyond the window store zeros there)
+        constexpr uint32_t STORE_LANES = (DH_F16_HALVES_OF(NZ) - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;
+        static_assert(STORE_LANES >= LAST_LANES && STORE_LANES <= DH_WAVE, "the partial group covers the padded arrays");
         DH_FOR_LANES_FRESH(lane) {
-            const bool in_last = (uint32_t) lane < LAST_LANES;
+            const bool in_last = (uint32_t) lane < LAST_LANES, in_store = (uint32_t) lane < STORE_LANES;
+            if (STORE_LANES > LAST_LANES && !in_last) { dh_f4 z; z.x = 0.0f; z.y = 0.0f; z.z = 0.0f; z.w = 0.0f; DH_LA(varr, lane)[DH_PF_N - 1] = z; }
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
             dh_h4* d1 = reinterpret_cast<dh_h4*>(S.xf) + lane;                          // halves 4 lane .. 4 lane + 3 of group 0; group r is 256 halves on
-            dh_h4* d2 = reinterpret_cast<dh_h4*>(S.xf + DH_F16_H2_OFFSET) + lane;
+            dh_h4* d2 = reinterpret_cast<dh_h4*>(S.xf + DH_F16_H2_OFFSET_OF(NZ)) + lane;
 #pragma unroll
             for (int r = 0; r < DH_PF_N; r++) {
                 dh_h4 a, b;
                 dh_f16_split4(varr[r], scale, a, b);
-                if (r < DH_PF_N - 1 || in_last) { d1[DH_WAVE * r] = a; d2[DH_WAVE * r] = b; }
+                if (r < DH_PF_N - 1 || in_store) { d1[DH_WAVE * r] = a; d2[DH_WAVE * r] = b; }
             }
 #else
             uint16_t* d1 = reinterpret_cast<uint16_t*>(S.xf) + 4 * lane;
-            uint16_t* d2 = reinterpret_cast<uint16_t*>(S.xf + DH_F16_H2_OFFSET) + 4 * lane;
+            uint16_t* d2 = reinterpret_cast<uint16_t*>(S.xf + DH_F16_H2_OFFSET_OF(NZ)) + 4 * lane;
             for (int r = 0; r < DH_PF_N; r++)
-                if (r < DH_PF_N - 1 || in_last) dh_f16_split4(varr[lane][r], scale, d1 + 4 * DH_WAVE * r, d2 + 4 * DH_WAVE * r);
+                if (r < DH_PF_N - 1 || in_store) dh_f16_split4(varr[lane][r], scale, d1 + 4 * DH_WAVE * r, d2 + 4 * DH_WAVE * r);
 #endif
         }
         return true;
@@ -1360,9 +1375,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // split-f16 FIR: this lane's six tap fragments -- 16-byte loads, 1 KiB per instruction, the same 6 KiB for every wavefront
     // of the chip (L1 / L2 hits).  Requested one iteration ahead (here, and again at the end of every iteration, when the
     // staging registers are free), so they have landed when P2 wants them.
-    dh_u4 tapfrag_regs[DH_F16_FRAGS];
+    dh_u4 tapfrag_regs[2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80)];
 #define DH_TAPFRAG_LOAD() do { if constexpr (MF16) { const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(P.tapfrag) + dh_fresh_lane_id_(); \
-        _Pragma("unroll") for (int f_ = 0; f_ < DH_F16_FRAGS; f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
+        _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
     DH_TAPFRAG_LOAD();
 #else
 #define DH_TAPFRAG_LOAD() ((void) 0)
@@ -1543,9 +1558,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         DH_FOR_LANES_FRESH(lane) {
                             float t = 0.0f;
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                            dh_fir_f16(S.xf, tapfrag_regs, lane, k1, k2, fo);
+                            dh_fir_f16<MF16 ? NZ : 80>(S.xf, tapfrag_regs, lane, k1, k2, fo);
 #else
-                            dh_fir_f16(S.xf, reinterpret_cast<const uint32_t (*)[DH_WAVE][4]>(P.tapfrag), lane, k1, k2, fo[lane]);
+                            dh_fir_f16<MF16 ? NZ : 80>(S.xf, reinterpret_cast<const uint32_t (*)[DH_WAVE][4]>(P.tapfrag), lane, k1, k2, fo[lane]);
 #endif
 #pragma unroll
                             for (int j = 0; j < DH_FIR_L; j++) t = __builtin_fmaf(DH_LA(fo, lane)[j], 0.0f, t);       // NaN or infinity anywhere: 0 * y is NaN

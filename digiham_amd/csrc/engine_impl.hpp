@@ -157,15 +157,15 @@ struct Engine {
             custom_gain = c.rrc_gain;
             if (be.upload(custom_taps, c.rrc_taps, sizeof(float) * (L.nz + 1)) || be.sync()) return DH_EDEVICE;   // the caller's table may go away
         }
-        if (L.fused && L.nz == 80) {
+        if (L.fused && (L.nz == 80 || L.nz == 160)) {
             DhF16Taps* F = new (std::nothrow) DhF16Taps;
             if (!F) return DH_ENOMEM;
             float half[DH_MAX_NZ / 2 + 1]; double gain;
             fill_taps(L.rrc, half, &gain);
             dh_f16_tap_fragments(half, L.nz, *F);
-            err_coef_f16 = dh_f16_error_coefficient(*F, gain);
+            err_coef_f16 = dh_f16_error_coefficient(*F, L.nz, gain);
             tapfrag = (uint32_t*) be.alloc(sizeof(F->frag));
-            rc = tapfrag ? be.upload(tapfrag, F->frag, sizeof(F->frag)) : DH_ENOMEM;
+            rc = tapfrag ? be.upload(tapfrag, F->frag, sizeof(F->frag)) : DH_ENOMEM;       // (the first 2 KS fragments are the ones a kernel reads)
             if (!rc) rc = be.sync();
             delete F;
             if (rc) return rc == DH_ENOMEM ? rc : DH_EDEVICE;
