@@ -914,7 +914,7 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 #define DH_BOUNDED_NARROW 1                 // the same for the narrow filter at a run-time samples-per-symbol (the NXDN pipe)
 #endif
 template <int NZ, bool FAST, int SPS> struct DhIsBounded {
-    static constexpr bool value = DH_BOUNDED_FIR && !FAST && ((NZ == 80 && SPS == 10) || (DH_BOUNDED_NARROW && NZ == 160 && SPS == 0));
+    static constexpr bool value = DH_BOUNDED_FIR && !FAST && ((NZ == 80 && SPS == 10) || (DH_BOUNDED_NARROW && NZ == 160 && SPS != 10));
 };
 // Diagnostic builds only (tools/phase_budget.sh): -DDH_STOP_AFTER=n leaves out the phases after Pn of every run (the
 // results are then wrong; the instruction counters of such builds, subtracted from each other, give the per-phase budget)
@@ -1225,7 +1225,7 @@ DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps
 // per-symbol loops unroll; SPS = 0 takes them from the parameters.
 template <int NZ, bool FAST, int SPS>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
-    static_assert(SPS == 0 || SPS == 10, "only sps 10 is specialised");
+    static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
     DhBoundState* const BS = DH_BOUND_STATE(S);
@@ -1851,8 +1851,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     todo &= todo - 1;
                     // (the raw samples behind each evaluation staged through the dead part of the window block: fetched one by
                     // one from HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
-                    const uint8_t sym = DH_EXACT_STAGED || SPS == 0 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, sps, ev_lo, ev_hi)
-                                                 : dh_exact_symbol<NZ, SPS ? SPS : 10>(C, S, k0 + q, S.xf + 640);
+                    const uint8_t sym = DH_EXACT_STAGED || SPS != 10 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, sps, ev_lo, ev_hi)
+                                                 : dh_exact_symbol<NZ, 10>(C, S, k0 + q, S.xf + 640);
                     DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
                     BS->n_uncertain++;
                 }
@@ -1977,7 +1977,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
                 }
             }
-            if (ordered && SPS == 0 && 2u * sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
+            if (ordered && SPS != 10 && 2u * sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
                 // Run-time sps with at least two lanes per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
                 // per phase, lane g sps + i takes a contiguous piece of row i -- `seg` = 4 ceil(25 / G) ring entries, read 16
                 // bytes at a time -- and the partial sums meet in LDS.  The bound of the sps-10 estimate holds with 8e-6 V'
@@ -2076,7 +2076,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
                 // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
                 const bool approx_ring = BOUNDED && e_blk > 0.0f;
-                for (int attempt = (approx_ring && SPS == 0 && 2u * sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
+                for (int attempt = (approx_ring && SPS != 10 && 2u * sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
                     DH_BARRIER();
                     if (approx_ring && attempt == 1) {
                         DhExactCtx C;
@@ -2086,7 +2086,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
                         // (the window block is dead here except words 512..575, where the L2 touch of the next window may
                         // still be dropping its dwords: the staged variant uses the words behind them)
-                        if (DH_EXACT_STAGED || SPS == 0) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u);
+                        if (DH_EXACT_STAGED || SPS != 10) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u);
                         else dh_exact_var_ring<NZ>(C, S, sps);
                         BS->n_exact_blocks++;
                         DH_BARRIER();
@@ -2112,19 +2112,19 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                             }
                             const double var = dsum / (double) DH_VARIANCE_SYMBOLS;
                             S.variance[lane] = var;
-                            if (BOUNDED && SPS == 0 && attempt == 0) {
+                            if (BOUNDED && SPS != 10 && attempt == 0) {
                                 // this phase's interval, as floats rounded outwards (2e-7 V covers the two conversions)
                                 const double eb = (double) e_blk;
                                 const double tol = 2.5 * eb * __builtin_sqrt(var) + 4.0 * eb * eb + 2e-10 * (var + mean * mean) + 2e-7 * var + 1e-40;
                                 DH_LA(iv_lo, lane)[0] = (float) (var - tol); DH_LA(iv_hi, lane)[0] = (float) (var + tol);
                                 DH_LA(iv_ok, lane)[0] = (var + mean * mean < 1e30) ? 1u : 0u;      // false for NaN / overflow, as in the estimate
                             }
-                        } else if (BOUNDED && SPS == 0 && attempt == 0) {
+                        } else if (BOUNDED && SPS != 10 && attempt == 0) {
                             DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u;
                         }
                     }
                     DH_BARRIER();
-                    if (BOUNDED && SPS == 0 && attempt == 0) {
+                    if (BOUNDED && SPS != 10 && attempt == 0) {
                         // is the reference's (arg-min, vmin <= 0, vmin > 5e6) beyond doubt?  One vote per question.
                         float hmin;
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)

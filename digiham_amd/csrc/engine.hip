@@ -466,6 +466,8 @@ struct HipBackend {
             if (nz == 0) return go_rrc_demod<0, false, 10>(P);
             if (nz == 80) return fast ? go_rrc_demod<80, true, 10>(P) : go_rrc_demod<80, false, 10>(P);
         }
+        if (nz == 0 && P.sps == 40) return go_rrc_demod<0, false, 40>(P);       // fsk_demodulator -s 40 (POCSAG): the generic code with the constant folded in
+        if (nz == 160 && P.sps == 20 && !fast) return go_rrc_demod<160, false, 20>(P);      // rrc_filter -n | gfsk_demodulator -s 20 (NXDN48)
         if (nz == 0) return go_rrc_demod<0, false, 0>(P);
         if (nz == 80) return fast ? go_rrc_demod<80, true, 0>(P) : go_rrc_demod<80, false, 0>(P);
         if (nz == 160) return fast ? go_rrc_demod<160, true, 0>(P) : go_rrc_demod<160, false, 0>(P);
@@ -503,7 +505,8 @@ struct HipBackend {
     }
     // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
-        if (proto == DH_PROTO_NXDN && nz == 160 && !fast) return go_chain<160, false, DH_PROTO_NXDN, 0, true>(P, D);   // rrc_filter -n | gfsk_demodulator -s 20 | nxdn_decoder
+        if (proto == DH_PROTO_NXDN && nz == 160 && !fast && P.sps == 20) return go_chain<160, false, DH_PROTO_NXDN, 20, true>(P, D);   // rrc_filter -n | gfsk_demodulator -s 20 | nxdn_decoder
+        if (proto == DH_PROTO_NXDN && nz == 160 && !fast) return go_chain<160, false, DH_PROTO_NXDN, 0, true>(P, D);    // (any other samples-per-symbol)
         // (POCSAG stays on two launches: measured 9.5 ms chained against 8.9 ms split at 16 384 channels)
         if (P.sps != 10) return 1;
         if (proto == DH_PROTO_DSTAR && nz == 0) return go_chain<0, false, DH_PROTO_DSTAR, 10, true>(P, D);    // fsk_demodulator -s 10 | dstar_decoder

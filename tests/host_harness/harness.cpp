@@ -55,6 +55,8 @@ struct HostBackend {
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
         if (P.sps == 10 && nz == 0) run_rrc_demod<0, false, 10>(P);
         else if (P.sps == 10 && nz == 80) { if (fast) run_rrc_demod<80, true, 10>(P); else run_rrc_demod<80, false, 10>(P); }
+        else if (nz == 0 && P.sps == 40) run_rrc_demod<0, false, 40>(P);                 // the same instantiations as engine.hip
+        else if (nz == 160 && P.sps == 20 && !fast) run_rrc_demod<160, false, 20>(P);
         else if (nz == 0) run_rrc_demod<0, false, 0>(P);
         else if (nz == 80) { if (fast) run_rrc_demod<80, true, 0>(P); else run_rrc_demod<80, false, 0>(P); }
         else if (nz == 160) { if (fast) run_rrc_demod<160, true, 0>(P); else run_rrc_demod<160, false, 0>(P); }
