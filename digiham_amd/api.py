@@ -217,6 +217,11 @@ class Engine:
         self.has_demod, self.has_proto = _capi.DEMOD[demod] != 0, _capi.PROTO[proto] != 0
         self.keep_filtered = (keep_filtered or rrc == "custom") and _capi.RRC[rrc] != 0
         self._keep = None
+        # DH_FLAG_OVERLAP_PUSHES: the kernels of a push run on the engine's own streams, which torch's caching allocator knows
+        # nothing about -- EVERY pushed buffer has to stay alive (and untouched) until the streams are joined again
+        # (sync, reset or any read), not just the latest one
+        self._overlap = bool(overlap_pushes)
+        self._inflight = []
 
     def close(self):
         if getattr(self, "_h", None):
@@ -227,6 +232,8 @@ class Engine:
 
     def reset(self):
         _check(self.ctx.lib.dh_engine_reset(self._h), "dh_engine_reset", self.ctx.lib)
+        if self._inflight:
+            self.sync()                          # the reset joined the streams; inputs are released once it has run
 
     def set_slot_filter(self, f):
         _check(self.ctx.lib.dh_engine_set_slot_filter(self._h, f), "dh_engine_set_slot_filter", self.ctx.lib)
@@ -248,6 +255,8 @@ class Engine:
             stride = x.shape[1]                 # a single row: its "row stride" is arbitrary (numpy reports 0 for a new axis)
         n = x.shape[1] if n is None else n
         self._keep = x          # the launch is asynchronous: keep the input alive
+        if self._overlap:
+            self._inflight.append(x)
         _check(self.ctx.lib.dh_engine_push(self._h, mem.ptr(x), stride, n), "dh_engine_push", self.ctx.lib)
 
     def push_host(self, x):
@@ -298,7 +307,10 @@ class Engine:
         return out
 
     def sync(self):
-        _check(self.ctx.lib.dh_engine_sync(self._h), "dh_engine_sync", self.ctx.lib)
+        try:
+            _check(self.ctx.lib.dh_engine_sync(self._h), "dh_engine_sync", self.ctx.lib)
+        finally:
+            del self._inflight[:-1]              # everything queued has run (the latest stays in _keep as before)
 
     def _fetch(self, getter, elem_dtype, with_counts=True):
         lib = self.ctx.lib

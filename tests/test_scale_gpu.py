@@ -186,3 +186,86 @@ def test_error_bounded_and_exact_routes_agree_at_scale(gpu_ctx, proto):
                 assert (s[ch, :sc[ch]] == s2[ch, :sc[ch]]).all(), (kw, ch)
                 assert (f[ch, :fc[ch]] == f2[ch, :fc[ch]]).all(), (kw, ch)
                 assert e[ch, :ec[ch]].tobytes() == e2[ch, :ec[ch]].tobytes(), (kw, ch)
+
+
+def test_overlapped_pushes_keep_their_temporary_inputs_alive(gpu_ctx):
+    """With DH_FLAG_OVERLAP_PUSHES the kernels read a pushed buffer on the engine's own streams, later than the caller's
+    stream knows: Engine.push holds every input until the streams are joined.  Pushes of temporaries, with the allocator
+    handing the same blocks out again for garbage in between, must give the bytes of plain pushes."""
+    import torch
+    from digiham_amd import api, synth_torch
+    B, U = 8192, 64
+    base, info = synth_torch.make_batch(torch, gpu_ctx.mem.device, "dmr", U, 12, U=U, seed=31)
+    T = info["samples_per_channel"]
+    x = base.repeat(B // U, 1).contiguous()
+    cut = [0, T // 4 // 10 * 10, T // 2 // 10 * 10, 3 * T // 4 // 10 * 10, T]
+    got = []
+    for overlap in (True, False):
+        eng = api.Engine(B, T, proto="dmr", ctx=gpu_ctx, overlap_pushes=overlap)
+        sym_total = np.zeros(B, np.int64)
+        for a, b in zip(cut[:-1], cut[1:]):
+            eng.push(x[:, a:b].contiguous())                     # a temporary: nothing here keeps it alive
+            for _ in range(3):                                   # the allocator is invited to reuse freed blocks of this size at once
+                junk = torch.full((B, b - a), float("nan"), device=x.device)
+                del junk
+        s, sc = eng.symbols()
+        f, fc = eng.frames()
+        got.append((_digest(s, sc), _digest(f, fc)))
+        eng.close()
+    assert got[0] == got[1]
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_config1_rrc_materialised_plus_gfsk_at_full_size(gpu_ctx, oracle, fast):
+    """BASELINE configs[1] as stated: 4 096 channels, RRC output materialised (k_rrc_tile's 2-D grid + k_rrc_hist) + GFSK
+    slicer, two pushes.  Replication digest over ALL channels (32 distinct signals repeated), the 32 against the oracle:
+    floats bit-exact (exact FIR) or within 1e-6 relative to max(|ref|, rms) (FMA FIR), dibits bit-exact (exact FIR)."""
+    import torch
+    from digiham_amd import api, synth_torch
+    B, U = 4096, 32
+    base, info = synth_torch.make_batch(torch, gpu_ctx.mem.device, "dmr", U, 33, U=U, seed=555)
+    T = info["samples_per_channel"]
+    x = base.repeat(B // U, 1).contiguous()
+    eng = api.Engine(B, T, proto="none", keep_filtered=True, fast_fir=fast, ctx=gpu_ctx)
+    outs = []
+    for _ in range(2):
+        eng.push(x)
+        s, sc = eng.symbols()
+        y = eng.filtered()[:, :T].copy()
+        outs.append((s, sc, y))
+    eng.close()
+    for s, sc, y in outs:
+        d = _digest(s, sc)
+        dy = [hashlib.sha256(y[b].tobytes()).hexdigest() for b in range(B)]
+        assert all(d[ch] == d[ch % U] and dy[ch] == dy[ch % U] for ch in range(B))
+    ref = oracle.chain(np.tile(base.cpu().numpy(), (1, 2)), proto=0, keep_filtered=True, threads=8)
+    yy = np.concatenate([o[2][:U] for o in outs], axis=1)
+    r = ref["filtered"]
+    if fast:
+        rms = np.sqrt(np.mean(r.astype(np.float64) ** 2)) + 1e-30
+        assert float(np.max(np.abs(yy.astype(np.float64) - r) / np.maximum(np.abs(r), rms))) <= 1e-6
+    else:
+        assert (yy.view(np.uint32) == r.view(np.uint32)).all()
+        for b in range(U):
+            gs = np.concatenate([o[0][b, :o[1][b]] for o in outs])
+            assert len(gs) == ref["sym_count"][b] and (gs == ref["syms"][b, :len(gs)]).all()
+
+
+def test_bench_runs_its_distributed_path_on_one_gpu():
+    """bench.py with DH_FORCE_DIST=1: the RCCL process group is initialised on the single rank, so init / barrier /
+    all_reduce of the multi-GPU path execute on the GPU box (the 8-GPU run itself is the driver's)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--channels", "2048", "--units", "20", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-other-configs", "--verify", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["verified"]["bit_exact_vs_oracle"]
