@@ -376,7 +376,7 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
                 stab = 0; slot = tact_slot;
                 const int other = slot ^ 1;
                 s[DS_SYNC_TYPE0 + other] = (uint32_t) -1;
-                dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) other, 0, nullptr, 0);
+                dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) other, 1, nullptr, 0);      // b = 1: the OTHER slot, after a TACT slot switch (:80)
                 if ((int) s[DS_ACTIVE_SLOT] == other) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
             } else {
                 stab--;

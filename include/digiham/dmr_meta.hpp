@@ -107,20 +107,31 @@ namespace Digiham {
                     Call& call = calls[s];
                     switch (ev.type) {
                         case DH_EV_DMR_SYNC:                   // a burst with a sync pattern (dmr_phase.cpp:109-114)
+                            settleAlias(s, ev.sym_index, ev.b == SYNCTYPE_VOICE);
                             call.fields.put(SYNC, ev.b == SYNCTYPE_DATA ? "data" : ev.b == SYNCTYPE_VOICE ? "voice" : "unknown");
                             if (ev.len > 0 && ev.payload[0]) call.endCall();       // voice -> data on this slot
                             if (ev.b != SYNCTYPE_VOICE) call.alias.reset();        // :233: every non-voice burst
                             publish(s);
                             break;
                         case DH_EV_DMR_SLOTTYPE:               // a data burst (:233)
+                            settleAlias(s, ev.sym_index, false);
                             call.alias.reset();
                             break;
                         case DH_EV_DMR_SLOT_RESET:             // the slot lost its sync (:80, :178-180, :196-198, :295)
-                            call.lose();
+                            if (ev.b == 1) {
+                                // :80, the OTHER slot after a TACT slot switch: Slot::reset() leaves the talker alias collector alone; the
+                                // collector is cleared by that slot's next burst (:233) -- unless the burst brings a voice sync
+                                call.loseKeepingAlias();
+                                aliasDeadline[s] = ev.sym_index + 144u; aliasPending[s] = true;
+                            } else {
+                                settleAlias(s, ev.sym_index, false);
+                                call.lose();
+                            }
                             publish(s);
                             break;
                         case DH_EV_DMR_META_RESET:             // the decoder fell back to its sync search (:184, :202)
                             for (Call& c : calls) { c.fields.wipe(); c.alias.reset(); }     // a new FramePhase starts with empty alias collectors
+                            aliasPending[0] = aliasPending[1] = false;
                             publish(0); publish(1);
                             break;
                         case DH_EV_DMR_SOFT_RESET:             // terminator LC / idle burst (:279-282)
@@ -128,6 +139,7 @@ namespace Digiham {
                             publish(s);
                             break;
                         case DH_EV_DMR_LC:                     // a link control word, voice header or embedded (:304-339)
+                            settleAlias(s, ev.sym_index, false);
                             if (ev.len >= 9) { linkControl(call, Lc(ev.payload)); publish(s); }
                             break;
                         default:
@@ -142,7 +154,8 @@ namespace Digiham {
                     FieldRecord<N_FIELDS> fields { { { "lat", "lon", "source", "sync", "talkeralias", "target", "type" } } };
                     TalkerAliasCollector alias;
                     void endCall() { for (Field f : { TYPE, SOURCE, TARGET, ALIAS, LAT, LON }) fields.put(f, std::string()); }   // Slot::softReset
-                    void lose() { endCall(); fields.put(SYNC, std::string()); alias.reset(); }                               // Slot::reset
+                    void loseKeepingAlias() { endCall(); fields.put(SYNC, std::string()); }                                  // Slot::reset
+                    void lose() { loseKeepingAlias(); alias.reset(); }                                                       // ... in a burst that then runs :233
                 };
                 static std::string number(uint32_t v) { return v ? std::to_string(v) : std::string(); }      // 0 = not known
                 void linkControl(Call& call, Lc lc) {
@@ -171,7 +184,16 @@ namespace Digiham {
                     calls[s].fields.addTo(m);
                     sendMetaData(std::move(m));
                 }
+                // a slot reset by the TACT switch keeps its collected alias blocks until its next burst (144 symbols on) has been
+                // seen not to carry a voice sync
+                void settleAlias(int s, uint32_t sym_index, bool voice_sync) {
+                    if (!aliasPending[s]) return;
+                    aliasPending[s] = false;
+                    if (!(voice_sync && sym_index == aliasDeadline[s])) calls[s].alias.reset();
+                }
                 Call calls[2];
+                bool aliasPending[2] = { false, false };
+                uint32_t aliasDeadline[2] = { 0, 0 };
         };
 
     }

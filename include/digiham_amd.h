@@ -153,6 +153,8 @@ typedef struct {
 } dh_event;
 
 enum {
+    /* DMR (src/dmr_decoder/dmr_phase.cpp): SLOT_RESET b = 1 when it is the OTHER slot that is reset after a TACT slot switch
+     * (:80 -- the reference leaves that slot's talker alias collector alone until its next burst), 0 otherwise */
     DH_EV_DMR_SYNC = 1, DH_EV_DMR_SLOT_RESET = 2, DH_EV_DMR_META_RESET = 3, DH_EV_DMR_LC = 4,
     DH_EV_DMR_SOFT_RESET = 5, DH_EV_DMR_BPTC = 6, DH_EV_DMR_SLOTTYPE = 7, DH_EV_DMR_EMB = 8,
     DH_EV_YSF_FICH = 16, DH_EV_YSF_MODE = 17, DH_EV_YSF_DCH = 18, DH_EV_YSF_HEADER_DCH = 19,

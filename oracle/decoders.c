@@ -175,7 +175,7 @@ static int dmr_frame(orc_decoder* d, const uint8_t* p) {
                 d->slot = tact_slot;
                 uint8_t other = (uint8_t) (d->slot ^ 1);
                 d->sync_types[other] = -1;
-                emit(d, ORC_EV_DMR_SLOT_RESET, other, 0, NULL, 0);
+                emit(d, ORC_EV_DMR_SLOT_RESET, other, 1, NULL, 0);      /* b = 1: the other slot after a TACT slot switch (:80) */
                 if (d->active_slot == other) d->active_slot = -1;
             } else {
                 d->slot_stability--;
