@@ -238,8 +238,9 @@ class Engine:
     def set_slot_filter(self, f):
         _check(self.ctx.lib.dh_engine_set_slot_filter(self._h, f), "dh_engine_set_slot_filter", self.ctx.lib)
 
-    def push(self, x, n=None):
-        """x: device array float32 [B][stride] (torch CUDA tensor); processes the first n samples of every row."""
+    def push(self, x, n=None, counts=None):
+        """x: device array float32 [B][stride] (torch CUDA tensor); processes the first n samples of every row -- or, with
+        `counts` ([B] uint32), the first counts[b] <= n samples of row b (dh_engine_push_ragged)."""
         mem = self.ctx.mem
         if not mem.is_device_array(x):
             x = mem.from_numpy(np.ascontiguousarray(x, np.float32).reshape(self.B, -1))
@@ -257,6 +258,13 @@ class Engine:
         self._keep = x          # the launch is asynchronous: keep the input alive
         if self._overlap:
             self._inflight.append(x)
+        if counts is not None:  # ragged push: channel b brings counts[b] <= n samples
+            c = counts if mem.is_device_array(counts) else mem.from_numpy(np.ascontiguousarray(counts, np.uint32))
+            self._keep = (x, c)
+            if self._overlap:
+                self._inflight.append(c)
+            _check(self.ctx.lib.dh_engine_push_ragged(self._h, mem.ptr(x), stride, mem.ptr(c), n), "dh_engine_push_ragged", self.ctx.lib)
+            return
         _check(self.ctx.lib.dh_engine_push(self._h, mem.ptr(x), stride, n), "dh_engine_push", self.ctx.lib)
 
     def push_host(self, x):

@@ -117,8 +117,20 @@ void dh_engine_destroy(dh_engine* e) {
 #define DH_ON_DEVICE(e) auto dh_on_device_ = (e)->impl.be.scope(); (void) dh_on_device_
 int dh_engine_reset(dh_engine* e) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.reset(); }
 int dh_engine_set_slot_filter(dh_engine* e, uint32_t f) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.set_slot_filter(f); }
+int dh_engine_reset_channel(dh_engine* e, uint32_t ch) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.reset_channel(ch); }
+int dh_engine_set_slot_filter_channel(dh_engine* e, uint32_t ch, uint32_t f) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.set_slot_filter_channel(ch, f); }
 int dh_engine_push(dh_engine* e, const float* d, size_t stride, size_t n) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.push(d, stride, n); }
 int dh_engine_push_host(dh_engine* e, const float* h, size_t stride, size_t n) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.push_host(h, stride, n); }
+int dh_engine_push_ragged(dh_engine* e, const float* d, size_t stride, const uint32_t* d_counts, size_t max_n) {
+    if (!e || !d_counts) return DH_EINVAL;
+    DH_ON_DEVICE(e);
+    return e->impl.push(d, stride, max_n, d_counts);
+}
+int dh_engine_push_host_ragged(dh_engine* e, const float* h, size_t stride, const uint32_t* h_counts, size_t max_n) {
+    if (!e || !h_counts) return DH_EINVAL;
+    DH_ON_DEVICE(e);
+    return e->impl.push_host(h, stride, max_n, h_counts);
+}
 int dh_engine_push_symbols(dh_engine* e, const uint8_t* d, size_t stride, const uint32_t* cnt) { if (!e) return DH_EINVAL; DH_ON_DEVICE(e); return e->impl.push_symbols(d, stride, cnt); }
 
 int dh_engine_filtered(dh_engine* e, const float** d, size_t* stride) {
@@ -176,7 +188,13 @@ int dh_engine_read_events(dh_engine* e, uint32_t ch, dh_event* h, size_t* n) {
 int dh_engine_read_filtered(dh_engine* e, uint32_t ch, float* h, size_t* n) {
     if (!e || !e->impl.filtered || !n || ch >= e->impl.L.B) return DH_EINVAL;
     DH_ON_DEVICE(e);
-    const size_t cnt = e->impl.last_n, cap = *n;
+    size_t cnt = e->impl.last_n;
+    const size_t cap = *n;
+    if (e->impl.last_counts) {                   // a ragged push: this channel's own count
+        uint32_t c = 0;
+        if (e->impl.be.download(&c, e->impl.last_counts + ch, sizeof(c))) return DH_EDEVICE;
+        if (c < cnt) cnt = c;
+    }
     *n = cnt;
     if (cnt > cap) return DH_ECAPACITY;
     if (cnt && h && e->impl.be.download(h, e->impl.filtered + (size_t) ch * e->impl.L.max_samples, sizeof(float) * cnt)) return DH_EDEVICE;

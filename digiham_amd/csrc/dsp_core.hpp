@@ -55,7 +55,8 @@ enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
 
 struct DhDspParams {
-    const float* in; size_t in_stride; uint32_t n;     // n new samples per channel
+    const float* in; size_t in_stride; uint32_t n;     // n new samples per channel (ragged pushes: the most any channel brings)
+    const uint32_t* n_per;                             // ragged pushes (dh_engine_push_ragged): [B] samples of each channel, <= n; or null
     float* state; size_t state_stride;                 // per-channel state (see above), in 4-byte words
     uint8_t* syms; size_t sym_stride;                  // symbol output [B][sym_stride]
     uint32_t* sym_count;                               // [B] symbols produced by this push
@@ -1254,7 +1255,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     uint32_t k0 = sth[DH_ST_K];
     int32_t off = (int32_t) sth[DH_ST_OFF];
     const uint32_t tc = sth[DH_ST_TAIL];
-    const uint32_t nv = tc + P.n;                       // length of the virtual input stream
+    const uint32_t n_new = P.n_per ? dh_min<uint32_t>(dh_uniform(P.n_per[ch]), P.n) : P.n;
+    const uint32_t nv = tc + n_new;                     // length of the virtual input stream
     const uint32_t nf = nv >= NZ ? nv - NZ : 0u;        // filtered samples available this push
     DH_FOR_LANES(lane) {
         for (uint32_t j = lane; j < DH_SCAN_N; j += DH_WAVE) {
@@ -2283,6 +2285,7 @@ struct DhRrcParams {
     const float* in; size_t in_stride;
     float* out; size_t out_stride;
     const float* hist;                                  // [B][nz] previous inputs (zeros after reset)
+    const uint32_t* n_per;                              // ragged pushes: [B] samples of each channel (<= n), or null
     uint32_t n, n_channels, nz;
     int32_t fast;
     double gain, rgain; float inv_gain;
@@ -2295,7 +2298,9 @@ DH_HD void dh_rrc_tile(const DhRrcParams& R, uint32_t ch, uint32_t tile, DhDspSh
     const float* hist = R.hist + (size_t) ch * NZ;
     float* out = R.out + (size_t) ch * R.out_stride;
     const uint32_t t0 = tile * DH_FTILE;
-    const uint32_t cnt = dh_min<uint32_t>(DH_FTILE, R.n - t0);
+    const uint32_t n_ch = R.n_per ? dh_min<uint32_t>(dh_uniform(R.n_per[ch]), R.n) : R.n;
+    if (t0 >= n_ch) return;                             // (ragged pushes: the grid covers the longest row)
+    const uint32_t cnt = dh_min<uint32_t>(DH_FTILE, n_ch - t0);
     // virtual stream = hist (NZ samples) ++ in; output t needs virtual [t, t+NZ]
     if (t0 >= (uint32_t) NZ) {
         // every tile but the first reads `in` only: 16 bytes per lane per load

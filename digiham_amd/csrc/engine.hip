@@ -104,9 +104,9 @@ __global__ __launch_bounds__(DH_WAVE) void k_rrc_generic(const DhRrcGenParams G)
     dh_rrc_generic_tile(G, blockIdx.y, blockIdx.x, win, taps);
 }
 
-__global__ __launch_bounds__(DH_WAVE) void k_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz) {
+__global__ __launch_bounds__(DH_WAVE) void k_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, const uint32_t* n_per, uint32_t nz) {
     __shared__ float sh[DH_MAX_NZ];
-    dh_rrc_hist_channel(hist, in, in_stride, n, nz, blockIdx.x, sh);
+    dh_rrc_hist_channel(hist, in, in_stride, n, n_per, nz, blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(DH_WAVE) void k_dmr(const DhDecParams P) {
@@ -530,8 +530,8 @@ struct HipBackend {
         hipLaunchKernelGGL(k_rrc_generic, dim3((G.n + DH_FTILE - 1) / DH_FTILE, G.n_channels), dim3(DH_WAVE), 0, ms(), G);
         return launched("k_rrc_generic");
     }
-    int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {
-        hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, ms(), hist, in, in_stride, n, nz);
+    int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, const uint32_t* n_per, uint32_t nz, uint32_t B) {
+        hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, ms(), hist, in, in_stride, n, n_per, nz);
         return launched("k_rrc_hist");
     }
     int launch_decoder(const DhDecParams& P, int proto) {

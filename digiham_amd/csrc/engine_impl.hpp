@@ -114,6 +114,8 @@ struct Engine {
     uint32_t* overflow = nullptr;
     float* filtered = nullptr; float* rrc_hist = nullptr;
     float* staging = nullptr;            // push_host staging [B][max_samples]
+    uint32_t* staging_counts = nullptr;  // ... and the per-channel counts of a ragged host push
+    const uint32_t* last_counts = nullptr;       // per-channel sample counts of the last push (device), or null
     DhFecTables* tables = nullptr;
     uint32_t* zero_counts = nullptr;
     uint32_t last_n = 0;
@@ -176,7 +178,7 @@ struct Engine {
 
     void destroy() {
         void* ptrs[] = { dsp_state, syms, sym_count, sym_carry, dec_state, frames, frame_count, events, ev_count,
-                         overflow, filtered, rrc_hist, staging, tables, custom_taps, tapfrag };
+                         overflow, filtered, rrc_hist, staging, staging_counts, tables, custom_taps, tapfrag };
         for (void* p : ptrs) if (p) be.free(p);
     }
 
@@ -201,6 +203,26 @@ struct Engine {
         slot_filter = f;
         return be.launch_set_slot_filter(dec_state, f, L.B) ? DH_EDEVICE : DH_OK;
     }
+    // one channel only (a module instance attached to a shared engine: include/digiham/shared_engine.hpp)
+    int set_slot_filter_channel(uint32_t ch, uint32_t f) {
+        if (L.proto != DH_PROTO_DMR || ch >= L.B) return DH_EINVAL;
+        return be.launch_set_slot_filter(dec_state + (size_t) ch * DH_DEC_STATE_WORDS, f, 1) ? DH_EDEVICE : DH_OK;
+    }
+    // back to the freshly-constructed state of ONE channel (the others keep streaming)
+    int reset_channel(uint32_t ch) {
+        if (ch >= L.B) return DH_EINVAL;
+        int rc = be.zero(sym_count + ch, sizeof(uint32_t));
+        if (sym_carry) rc |= be.zero(sym_carry + (size_t) ch * dh_carry_max(L.proto), dh_carry_max(L.proto));
+        if (dsp_state) rc |= be.zero(dsp_state + (size_t) ch * L.state_words, sizeof(uint32_t) * L.state_words);
+        if (syms) rc |= be.zero(syms + (size_t) ch * L.sym_stride, L.sym_stride);
+        if (dec_state) rc |= be.zero(dec_state + (size_t) ch * DH_DEC_STATE_WORDS, sizeof(uint32_t) * DH_DEC_STATE_WORDS);
+        if (frame_count) rc |= be.zero(frame_count + ch, sizeof(uint32_t));
+        if (ev_count) rc |= be.zero(ev_count + ch, sizeof(uint32_t));
+        if (rrc_hist) rc |= be.zero(rrc_hist + (size_t) ch * L.nz, sizeof(float) * L.nz);
+        rc |= be.launch_init_state(dsp_state ? dsp_state + (size_t) ch * L.state_words : nullptr, L.state_words, L.fused ? L.nz : 0u,
+                                   dec_state ? dec_state + (size_t) ch * DH_DEC_STATE_WORDS : nullptr, slot_filter, 1);
+        return rc ? DH_EDEVICE : DH_OK;
+    }
 
     void fill_dec_params(const uint8_t* d_syms, size_t stride, const uint32_t* d_count) {
         dec.syms = d_syms; dec.sym_stride = stride; dec.sym_count = d_count;
@@ -211,8 +233,11 @@ struct Engine {
         dec.overflow = overflow; dec.T = tables; dec.n_channels = L.B;
     }
 
-    int push(const float* d_in, size_t stride, size_t n) {
+    // d_counts (device, [B], or null): ragged push -- channel b brings d_counts[b] <= n samples of its row
+    int push(const float* d_in, size_t stride, size_t n, const uint32_t* d_counts = nullptr) {
         if ((!d_in && n) || n > L.max_samples || stride < n) return DH_EINVAL;
+        if (d_counts && L.rrc == DH_RRC_CUSTOM) return DH_EINVAL;          // (the generic FIR takes whole pushes only)
+        last_counts = d_counts;
         if (!L.rrc && !L.demod) return DH_EINVAL;
         // an empty push is a module call with nothing readable: it runs (zero outputs, state untouched) and never
         // dereferences the sample pointer, which may then be null
@@ -228,19 +253,19 @@ struct Engine {
             G.in = d_in; G.in_stride = stride; G.out = filtered; G.out_stride = L.max_samples; G.hist = rrc_hist; G.taps = custom_taps;
             G.n = (uint32_t) n; G.n_channels = L.B; G.nz = L.nz; G.gain = custom_gain;
             if (n) rc |= be.launch_rrc_generic(G);
-            if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, L.nz, L.B);
+            if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, nullptr, L.nz, L.B);
             demod_in = filtered; demod_stride = L.max_samples;
         } else if (L.rrc && !L.fused) {
             rrcp.in = d_in; rrcp.in_stride = stride; rrcp.out = filtered; rrcp.out_stride = L.max_samples;
-            rrcp.hist = rrc_hist; rrcp.n = (uint32_t) n; rrcp.n_channels = L.B; rrcp.nz = L.nz; rrcp.fast = fast;
+            rrcp.hist = rrc_hist; rrcp.n = (uint32_t) n; rrcp.n_per = d_counts; rrcp.n_channels = L.B; rrcp.nz = L.nz; rrcp.fast = fast;
             fill_taps(L.rrc, rrcp.taps, &rrcp.gain); rrcp.rgain = 1.0 / rrcp.gain; rrcp.inv_gain = (float) rrcp.rgain;
             if (n) rc |= be.launch_rrc_tiles(rrcp, L.nz, fast);
-            if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, L.nz, L.B);
+            if (n) rc |= be.launch_rrc_hist(rrc_hist, d_in, stride, (uint32_t) n, d_counts, L.nz, L.B);
             demod_in = filtered; demod_stride = L.max_samples;
         }
         be.timing_mark(1);
         if (L.demod) {
-            dsp.in = demod_in; dsp.in_stride = demod_stride; dsp.n = (uint32_t) n;
+            dsp.in = demod_in; dsp.in_stride = demod_stride; dsp.n = (uint32_t) n; dsp.n_per = d_counts;
             dsp.state = (float*) dsp_state; dsp.state_stride = L.state_words;
             dsp.syms = syms; dsp.sym_stride = L.sym_stride;
             dsp.sym_count = sym_count; dsp.sym_cap = L.sym_cap; dsp.overflow = overflow; dsp.n_channels = L.B;
@@ -275,12 +300,17 @@ struct Engine {
         return rc ? DH_EDEVICE : DH_OK;
     }
 
-    int push_host(const float* h_in, size_t stride, size_t n) {
+    int push_host(const float* h_in, size_t stride, size_t n, const uint32_t* h_counts = nullptr) {
         if (!h_in || n > L.max_samples || stride < n) return DH_EINVAL;
         if (!staging) { staging = (float*) be.alloc(sizeof(float) * (size_t) L.B * L.max_samples); if (!staging) return DH_ENOMEM; }
         // one strided copy for the whole batch (rows of n floats, host pitch `stride`, device pitch max_samples)
         if (be.upload2d(staging, sizeof(float) * L.max_samples, h_in, sizeof(float) * stride, sizeof(float) * n, L.B)) return DH_EDEVICE;
-        return push(staging, L.max_samples, n);
+        if (h_counts) {
+            if (!staging_counts) { staging_counts = (uint32_t*) be.alloc(sizeof(uint32_t) * L.B); if (!staging_counts) return DH_ENOMEM; }
+            for (uint32_t b = 0; b < L.B; b++) if (h_counts[b] > n) return DH_EINVAL;
+            if (be.upload(staging_counts, h_counts, sizeof(uint32_t) * L.B)) return DH_EDEVICE;
+        }
+        return push(staging, L.max_samples, n, h_counts ? staging_counts : nullptr);
     }
 
     // decoder-only engines: the caller's symbol rows are read in place

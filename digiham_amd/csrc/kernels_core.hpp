@@ -35,7 +35,8 @@ DH_HD void dh_set_slot_filter_channel(uint32_t* dec_state, uint32_t filter, uint
 
 // history of the stand-alone RRC stage: the last nz samples of (hist ++ in[0..n))
 // (one channel per wavefront; staged through LDS because old and new history overlap when n < nz)
-DH_HD void dh_rrc_hist_channel(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t ch, float* sh) {
+DH_HD void dh_rrc_hist_channel(float* hist, const float* in, size_t in_stride, uint32_t n_max, const uint32_t* n_per, uint32_t nz, uint32_t ch, float* sh) {
+    const uint32_t n = n_per ? dh_min<uint32_t>(n_per[ch], n_max) : n_max;
     float* h = hist + (size_t) ch * nz;
     const float* x = in + (size_t) ch * in_stride;
     DH_FOR_LANES(lane) {

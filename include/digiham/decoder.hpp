@@ -13,6 +13,7 @@
 
 #include "csdr_compat.hpp"
 #include "engine_handle.hpp"
+#include "shared_engine.hpp"
 #include "dmr_meta.hpp"
 #include "ysf_meta.hpp"
 #include "nxdn_meta.hpp"
@@ -25,13 +26,28 @@ namespace Digiham {
 
     class Decoder: public Csdr::Module<unsigned char, unsigned char> {
         public:
-            ~Decoder() override { dh_device_free(dSyms); dh_device_free(dCount); delete metaCollector; }
+            ~Decoder() override { if (bank) bank->detach(slot); dh_device_free(dSyms); dh_device_free(dCount); delete metaCollector; }
             bool canProcess() override {
                 std::lock_guard<std::mutex> lock(processMutex);
-                return reader->available() > 0 && writer->writeable() >= maxOutputPerCall;
+                const bool fresh = reader->available() > 0 && writer->writeable() >= maxOutputPerCall;
+                if (!shared()) return fresh;
+                const bool queued = bank->hasOutput(slot);
+                return bank->hasPending(slot) || (queued && writer->writeable() > 0) || (!queued && fresh);
             }
             void process() override {
                 std::lock_guard<std::mutex> lock(processMutex);
+                if (shared()) {                        // one engine for every decoder instance of the process (shared_engine.hpp)
+                    bank->wantEvents = bank->wantEvents || onEvent || metaCollector;
+                    deliver();
+                    if (bank->hasPending(slot)) { bank->settle(slot); deliver(); return; }
+                    if (bank->hasOutput(slot)) return;
+                    if (!(reader->available() > 0 && writer->writeable() >= maxOutputPerCall)) return;
+                    const size_t n = std::min(reader->available(), Amd::SharedEngine::chunk);
+                    bank->deposit(slot, reader->getReadPointer(), n);
+                    reader->advance(n);
+                    deliver();
+                    return;
+                }
                 ensure();
                 size_t n = reader->available();
                 if (n > chunk) n = chunk;
@@ -75,7 +91,32 @@ namespace Digiham {
             }
             std::unique_ptr<Amd::Engine> engine;
             unsigned char slotFilter = 3;
+            bool shared() {
+                if (!decided) {
+                    decided = true;
+                    if (Amd::SharedEngine::enabled()) {
+                        bank = Amd::SharedEngine::forKind(Amd::SharedEngine::DECODER, DH_RRC_NONE, DH_DEMOD_NONE, 0, proto, 0);
+                        slot = bank->attach();
+                        if (proto == DH_PROTO_DMR && slotFilter != 3) bank->setSlotFilter(slot, slotFilter);
+                    }
+                }
+                return (bool) bank;
+            }
+            std::shared_ptr<Amd::SharedEngine> bank;
+            int slot = -1;
         private:
+            void deliver() {
+                const size_t n = bank->take(slot, writer->getWritePointer(), writer->writeable());
+                if (n) writer->advance(n);
+                if (onEvent || metaCollector) {
+                    for (const dh_event& e : bank->takeEvents(slot)) {
+                        if (metaCollector) metaCollector->consume(e);
+                        if (onEvent) onEvent(e);
+                    }
+                    if (metaCollector) metaCollector->flush();
+                }
+            }
+            bool decided = false;
             static constexpr size_t chunk = 16384;
             // a call may emit one voice payload per 144-symbol burst (DMR, 27 bytes), 95 bytes per 480-symbol frame (YSF)
             // or 36 bytes per 192-symbol frame (NXDN); a POCSAG page line can take up to about half a byte per input bit
@@ -96,6 +137,7 @@ namespace Digiham {
                 void setSlotFilter(unsigned char filter) {
                     std::lock_guard<std::mutex> lock(processMutex);   // the reference races here (dmr_cli.cpp:57-69)
                     slotFilter = filter;
+                    if (bank) bank->setSlotFilter(slot, filter);
                     if (engine) Amd::check(dh_engine_set_slot_filter(engine->get(), filter), "dh_engine_set_slot_filter");
                 }
         };

@@ -19,9 +19,9 @@ namespace Digiham {
 
         class Engine {
             public:
-                Engine(int rrc, int demod, unsigned int sps, int proto, unsigned int flags, unsigned int maxSamples, unsigned int slotFilter = 3) {
+                Engine(int rrc, int demod, unsigned int sps, int proto, unsigned int flags, unsigned int maxSamples, unsigned int slotFilter = 3, unsigned int channels = 1) {
                     dh_engine_config cfg{};
-                    cfg.struct_size = sizeof(cfg); cfg.device = 0; cfg.n_channels = 1; cfg.max_samples = maxSamples;
+                    cfg.struct_size = sizeof(cfg); cfg.device = 0; cfg.n_channels = channels; cfg.max_samples = maxSamples;
                     cfg.rrc = rrc; cfg.demod = demod; cfg.sps = sps; cfg.proto = proto; cfg.flags = flags; cfg.slot_filter = slotFilter;
                     cfg.stream = nullptr;
                     check(dh_engine_create(&cfg, &handle), "dh_engine_create");

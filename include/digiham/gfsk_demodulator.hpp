@@ -12,6 +12,7 @@
 
 #include "csdr_compat.hpp"
 #include "engine_handle.hpp"
+#include "shared_engine.hpp"
 
 namespace Digiham {
 
@@ -19,13 +20,28 @@ namespace Digiham {
 
         class SlicerBase: public Csdr::Module<float, unsigned char> {
             public:
+                ~SlicerBase() override { if (bank) bank->detach(slot); }
                 bool canProcess() override {
                     std::lock_guard<std::mutex> lock(processMutex);
                     // +1 for variance calculation "jumps" (gfsk_demodulator.cpp:18-22)
-                    return reader->available() > samplesPerSymbol + 1 && writer->writeable() >= minRoom;
+                    const bool fresh = reader->available() > samplesPerSymbol + 1 && writer->writeable() >= minRoom;
+                    if (!shared()) return fresh;
+                    const size_t queued = bank->outputSize(slot);
+                    return bank->hasPending(slot) || (queued > 0 && writer->writeable() > 0) || (queued == 0 && fresh);
                 }
                 void process() override {
                     std::lock_guard<std::mutex> lock(processMutex);
+                    if (shared()) {                    // one engine for every instance of the process (shared_engine.hpp)
+                        deliver();
+                        if (bank->hasPending(slot)) { bank->settle(slot); deliver(); return; }
+                        if (bank->outputSize(slot) > 0) return;
+                        if (!(reader->available() > samplesPerSymbol + 1)) return;
+                        const size_t n = std::min(reader->available(), Amd::SharedEngine::chunk);
+                        bank->deposit(slot, reader->getReadPointer(), n);
+                        reader->advance(n);
+                        deliver();
+                        return;
+                    }
                     if (!engine) engine.reset(new Amd::Engine(DH_RRC_NONE, levels, samplesPerSymbol, DH_PROTO_NONE, invert ? DH_FLAG_FSK_INVERT : 0, chunk));
                     // never produce more symbols than the writer can take: a symbol needs at least sps - 1 samples, and the
                     // engine may still hold up to sps + 1 samples of the previous call: n samples give at most
@@ -45,6 +61,23 @@ namespace Digiham {
             protected:
                 SlicerBase(int levels, unsigned int samplesPerSymbol, bool invert): levels(levels), samplesPerSymbol(samplesPerSymbol), invert(invert) {}
             private:
+                bool shared() {
+                    if (!decided) {
+                        decided = true;
+                        if (Amd::SharedEngine::enabled()) {
+                            bank = Amd::SharedEngine::forKind(Amd::SharedEngine::SLICER, DH_RRC_NONE, levels, samplesPerSymbol, DH_PROTO_NONE, invert ? DH_FLAG_FSK_INVERT : 0);
+                            slot = bank->attach();
+                        }
+                    }
+                    return (bool) bank;
+                }
+                void deliver() {
+                    const size_t n = bank->take(slot, writer->getWritePointer(), writer->writeable());
+                    if (n) writer->advance(n);
+                }
+                std::shared_ptr<Amd::SharedEngine> bank;
+                int slot = -1;
+                bool decided = false;
                 static constexpr size_t chunk = 65536;
                 static constexpr size_t minRoom = 4;
                 int levels;

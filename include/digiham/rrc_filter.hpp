@@ -8,6 +8,7 @@
 
 #include "csdr_compat.hpp"
 #include "engine_handle.hpp"
+#include "shared_engine.hpp"
 
 namespace Digiham {
 
@@ -22,7 +23,34 @@ namespace Digiham {
                 RrcFilter(unsigned int nZeros, double gain, const float coeffs[]): kind(DH_RRC_CUSTOM), gain(gain), taps(coeffs, coeffs + nZeros + 1) {
                     if (nZeros < 1 || nZeros > 160) throw std::invalid_argument("Digiham::RrcFilter: 2 to 161 coefficients");
                 }
-                ~RrcFilter() override = default;
+                ~RrcFilter() override { if (bank) bank->detach(slot); }
+                // With Digiham::Amd::SharedEngine::enable() every instance of a process deposits into one engine (one launch per
+                // round for all of them, shared_engine.hpp); its output then arrives one call later.
+                bool canProcess() override {
+                    std::lock_guard<std::mutex> lock(this->processMutex);
+                    if (!shared()) return std::min(this->reader->available(), this->writer->writeable()) > 0;
+                    const bool pending = bank->hasPending(slot);
+                    const size_t queued = bank->outputSize(slot);
+                    return pending || (queued > 0 && this->writer->writeable() > 0) || (queued == 0 && this->reader->available() > 0);
+                }
+                void process() override {
+                    std::lock_guard<std::mutex> lock(this->processMutex);
+                    if (!shared()) {
+                        size_t n = std::min(this->reader->available(), this->writer->writeable());
+                        process(this->reader->getReadPointer(), this->writer->getWritePointer(), n);
+                        this->reader->advance(n);
+                        this->writer->advance(n);
+                        return;
+                    }
+                    deliver();
+                    if (bank->hasPending(slot)) { bank->settle(slot); deliver(); return; }
+                    if (bank->outputSize(slot) > 0) return;                       // the writer is full: nothing new until it has taken what is there
+                    const size_t n = std::min(this->reader->available(), Amd::SharedEngine::chunk);
+                    if (n == 0) return;
+                    bank->deposit(slot, this->reader->getReadPointer(), n);
+                    this->reader->advance(n);
+                    deliver();
+                }
                 void process(float* input, float* output, size_t length) override {
                     if (!engine) engine.reset(kind == DH_RRC_CUSTOM ? new Amd::Engine(taps.data(), (unsigned int) taps.size() - 1, gain, chunk)
                                                                    : new Amd::Engine(kind, DH_DEMOD_NONE, 0, DH_PROTO_NONE, DH_FLAG_KEEP_FILTERED, chunk));
@@ -37,6 +65,23 @@ namespace Digiham {
             protected:
                 explicit RrcFilter(int kind): kind(kind) {}
             private:
+                bool shared() {
+                    if (!decided) {
+                        decided = true;
+                        if (kind != DH_RRC_CUSTOM && Amd::SharedEngine::enabled()) {
+                            bank = Amd::SharedEngine::forKind(Amd::SharedEngine::RRC, kind, DH_DEMOD_NONE, 0, DH_PROTO_NONE, DH_FLAG_KEEP_FILTERED);
+                            slot = bank->attach();
+                        }
+                    }
+                    return (bool) bank;
+                }
+                void deliver() {
+                    const size_t n = bank->take(slot, this->writer->getWritePointer(), this->writer->writeable());
+                    if (n) this->writer->advance(n);
+                }
+                std::shared_ptr<Amd::SharedEngine> bank;
+                int slot = -1;
+                bool decided = false;
                 static constexpr size_t chunk = 65536;
                 int kind;
                 double gain = 0.0;

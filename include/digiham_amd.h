@@ -188,6 +188,15 @@ int  dh_engine_set_slot_filter(dh_engine* e, uint32_t filter);
 int  dh_engine_push(dh_engine* e, const float* d_samples, size_t stride, size_t n);
 /* same, from host memory (staged through an engine-owned device buffer) */
 int  dh_engine_push_host(dh_engine* e, const float* h_samples, size_t stride, size_t n);
+/* One channel of a many-channel engine: back to the freshly-constructed state / Dmr::Decoder::setSlotFilter for it alone
+ * (the other channels keep streaming).  What a module instance attached to a shared engine needs. */
+int  dh_engine_reset_channel(dh_engine* e, uint32_t channel);
+int  dh_engine_set_slot_filter_channel(dh_engine* e, uint32_t channel, uint32_t filter);
+/* Ragged pushes: channel b brings d_counts[b] (<= max_n) new samples of its row; the others stay where they are.  One launch
+ * for N module instances whose ring buffers hold different amounts (include/digiham/shared_engine.hpp); a real-time receiver
+ * whose channels arrive in blocks of unequal length.  Engines with a foreign tap table (DH_RRC_CUSTOM) take whole pushes only. */
+int  dh_engine_push_ragged(dh_engine* e, const float* d_in, size_t stride, const uint32_t* d_counts, size_t max_n);
+int  dh_engine_push_host_ragged(dh_engine* e, const float* h_in, size_t stride, const uint32_t* h_counts, size_t max_n);
 
 /* Device views of the current push's outputs (valid until the next push).
  * Any out-pointer may be NULL. counts are uint32 [B]. */

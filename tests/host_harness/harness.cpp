@@ -82,9 +82,9 @@ struct HostBackend {
             for (uint32_t t = 0; t * DH_FTILE < G.n; t++) dh_rrc_generic_tile(G, ch, t, win, taps);
         return 0;
     }
-    int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, uint32_t nz, uint32_t B) {
+    int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, const uint32_t* n_per, uint32_t nz, uint32_t B) {
         float sh[DH_MAX_NZ];
-        for (uint32_t ch = 0; ch < B; ch++) dh_rrc_hist_channel(hist, in, in_stride, n, nz, ch, sh);
+        for (uint32_t ch = 0; ch < B; ch++) dh_rrc_hist_channel(hist, in, in_stride, n, n_per, nz, ch, sh);
         return 0;
     }
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from common import assert_matches_oracle, make_channels, rel_err, run_engine, sha
-from digiham_amd import synth
+from digiham_amd import api, synth
 
 
 @pytest.mark.parametrize("proto", ["dmr", "ysf"])
@@ -220,3 +220,48 @@ def test_custom_rrc_table(ctx, oracle):
     for b in range(x.shape[0]):
         assert sc[b] == ref["sym_count"][b] and (s[b, :sc[b]] == ref["syms"][b, :sc[b]]).all()
         assert fc[b] == ref["out_count"][b] and (f[b, :fc[b]] == ref["out"][b, :fc[b]]).all()
+
+
+@pytest.mark.parametrize("kw,oproto", [(dict(proto="dmr"), 1), (dict(proto="ysf"), 2), (dict(proto="none", keep_filtered=True), 0)])
+def test_ragged_pushes_every_channel_at_its_own_pace(ctx, oracle, kw, oproto):
+    """dh_engine_push_ragged: each push brings a different number of samples per channel (some none at all); every channel's
+    concatenated outputs are those of its whole stream -- what N module instances sharing one launch need
+    (include/digiham/shared_engine.hpp)."""
+    proto = "ysf" if kw["proto"] == "ysf" else "dmr"
+    x = make_channels(proto, [21, 22, 23, 24, 25], 14)
+    B, n = x.shape
+    ref = oracle.chain(x, proto=oproto, keep_filtered=bool(kw.get("keep_filtered")))
+    rng = np.random.default_rng(5)
+    cap = 4096
+    eng = api.Engine(B, cap, ctx=ctx, **kw)
+    pos = np.zeros(B, np.int64)
+    syms, frames, filt = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)]
+    while (pos < n).any():
+        want = rng.choice([0, 1, 7, 333, 1024, 1025, 2500, cap], B)
+        cnt = np.minimum(want, n - pos).astype(np.uint32)
+        buf = np.zeros((B, cap), np.float32)
+        for b in range(B):
+            buf[b, :cnt[b]] = x[b, pos[b]:pos[b] + cnt[b]]
+            buf[b, cnt[b]:] = np.nan                               # whatever lies behind a channel's count is not its business
+        eng.push(buf, n=int(cnt.max()) if cnt.max() else 0, counts=cnt)
+        pos += cnt
+        s, sc = eng.symbols()
+        for b in range(B):
+            syms[b].append(s[b, :sc[b]].copy())
+        if kw["proto"] != "none":
+            f, fc = eng.frames()
+            for b in range(B):
+                frames[b].append(f[b, :fc[b]].copy())
+        if kw.get("keep_filtered"):
+            y = eng.filtered()
+            for b in range(B):
+                filt[b].append(y[b, :cnt[b]].copy())
+    eng.close()
+    for b in range(B):
+        gs = np.concatenate(syms[b])
+        assert len(gs) == ref["sym_count"][b] and (gs == ref["syms"][b, :len(gs)]).all(), b
+        if kw["proto"] != "none":
+            gf = np.concatenate(frames[b])
+            assert len(gf) == ref["out_count"][b] and (gf == ref["out"][b, :len(gf)]).all(), b
+        if kw.get("keep_filtered"):
+            assert (np.concatenate(filt[b]).view(np.uint32) == ref["filtered"][b].view(np.uint32)).all(), b

@@ -124,3 +124,45 @@ int main() {
     got = np.frombuffer(out, np.float32)
     ref = oracle.Rrc(taps=taps, gain=gain).process(x)
     assert len(got) == len(x) and got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
+def test_64_module_triples_share_one_launch_per_stage_and_round(oracle, tmp_path, gpu):
+    """Digiham::Amd::SharedEngine (include/digiham/shared_engine.hpp): 64 x (WideRrcFilter | GfskDemodulator | Dmr::Decoder) in
+    one process, fed raggedly, driven round-robin.  Every channel's decoder bytes and metadata lines are those of its own
+    1-channel engines (and the bytes the oracle's), with at most one launch per stage and round instead of one per module."""
+    N = 64
+    exe = str(tmp_path / ("shared_gpu" if gpu else "shared_emu"))
+    if gpu:
+        libdir, lib = os.path.join(ROOT, "digiham_amd"), "digiham_amd"
+    else:
+        import hostemu
+        hostemu.build()
+        libdir, lib = os.path.join(ROOT, "tests", "host_harness"), "dh_hostemu"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_cpp", "shared_test.cpp"),
+                    "-o", exe, "-L" + libdir, "-l" + lib, "-Wl,-rpath," + libdir], check=True)
+    chans = []
+    for i in range(N):
+        s = synth.dmr_stream(100 + i % 8, 14, two_slots=(i % 2 == 0))
+        chans.append(synth.impair(synth.shape(s), 100 + i, snr_db=[None, 25, 16][i % 3], dc=0.02 * (i % 5), delay=i % 17, gain=[1, 0.4, 2][i % 3]))
+    T = min(len(c) for c in chans)
+    x = np.stack([c[:T] for c in chans]).astype(np.float32)
+    (tmp_path / "in.f32").write_bytes(x.tobytes())
+    env = dict(os.environ)
+    if gpu:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    res = {}
+    for shared in (1, 0):
+        prefix = str(tmp_path / ("s%d" % shared))
+        r = subprocess.run([exe, str(N), str(tmp_path / "in.f32"), str(T), prefix, "3000", str(shared)], check=True, env=env, capture_output=True, text=True)
+        rounds, ticks = int(r.stdout.split()[1]), int(r.stdout.split()[3])
+        res[shared] = ([open("%s.%d.out" % (prefix, i), "rb").read() for i in range(N)],
+                       [open("%s.%d.meta" % (prefix, i), "rb").read() for i in range(N)], rounds, ticks)
+    outs, metas, rounds, ticks = res[1]
+    assert outs == res[0][0] and metas == res[0][1]                 # the same bytes and lines as with one engine per module
+    assert res[0][3] == 0 and 0 < ticks <= 3 * rounds               # at most one launch per stage and round (192 per round without)
+    for i in range(0, N, 7):                                        # and the bytes are the oracle's
+        ref = oracle.chain(x[i:i + 1], proto=1, slot_filter=1 if i % 5 == 4 else 3)
+        assert outs[i] == ref["out"][0, :ref["out_count"][0]].tobytes()
+    assert sum(len(o) for o in outs) > 0 and all(b"protocol:DMR" in m for m in metas)
