@@ -135,24 +135,20 @@ def test_exact_kernels_keep_their_two_firs_apart_and_the_hot_one_in_registers(ke
       arithmetic beside them; for the narrow filter (NXDN) packed FMAs.
     A handful of spills elsewhere (rare paths, the YSF decoder half) is what a fourth wavefront per SIMD costs."""
     exact = [n for n in kernels if "k_chain" in n and ("ILi80ELb0E" in n or "ILi160ELb0E" in n)]
-    assert len(exact) == 6                    # DMR, YSF and NXDN (161 taps), each as launch PART 0 and PART 1 (DH_FLAG_OVERLAP_PUSHES)
+    assert len(exact) == 8                    # DMR, YSF, NXDN (161 taps) at sps 20 and at a run-time sps, each as launch PART 0 and PART 1 (DH_FLAG_OVERLAP_PUSHES)
     for name in exact:
         lines, meta = kernels[name]
         narrow = "ILi160ELb0E" in name
         blocks = _blocks(lines)
         ref_fir = max(blocks, key=lambda b: sum(i.startswith("v_pk_mul_f32") for i in b))
-        assert sum(i.startswith("v_pk_mul_f32") for i in ref_fir) >= 600 and sum(i.startswith("v_pk_add_f32") for i in ref_fir) >= 600     # 81 taps x 8 pairs
+        assert sum(i.startswith("v_pk_mul_f32") for i in ref_fir) >= 600 and sum(i.startswith("v_pk_add_f32") for i in ref_fir) >= 600     # 81 (161) taps x 8 pairs
         assert not [i for i in ref_fir if i.startswith(("v_pk_fma_f32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32", "v_mfma"))], name + " fuses inside the reference FIR"
-        if narrow:
-            hot = max(blocks, key=lambda b: sum(i.startswith("v_pk_fma_f32") for i in b))
-            assert sum(i.startswith("v_pk_fma_f32") for i in hot) >= 600 and hot is not ref_fir
-        else:
-            hot = max(blocks, key=lambda b: sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in b))
-            assert sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in hot) == 36 and hot is not ref_fir
-            assert sum(i.startswith(("v_pk_fma_f32", "v_pk_mul_f32")) for i in hot) <= 40, name + ": f32 FIR arithmetic beside the MFMAs"
-            assert not [i for b in blocks for i in b if i.startswith("v_mfma_f32_16x16x4_f32")]
+        hot = max(blocks, key=lambda b: sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in b))
+        assert sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in hot) == (72 if narrow else 36) and hot is not ref_fir      # 4 tiles x 3 K-steps x 3 products (6 K-steps narrow)
+        assert sum(i.startswith(("v_pk_fma_f32", "v_pk_mul_f32")) for i in hot) <= 40, name + ": f32 FIR arithmetic beside the MFMAs"
+        assert not [i for b in blocks for i in b if i.startswith("v_mfma_f32_16x16x4_f32")]
         hot_spills = [i for i in hot if "scratch_" in i]
-        assert len(hot_spills) <= (4 if narrow else 0), name + " spills inside the hot FIR"       # (the 161-tap one at 168 VGPRs: two values)
+        assert len(hot_spills) == 0, name + " spills inside the hot FIR"
         spills = [i for b in blocks for i in b if "scratch_" in i]
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
         assert len(spills) <= 64 and vgprs <= (168 if narrow else 128), (name, len(spills), vgprs)
