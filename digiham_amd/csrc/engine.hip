@@ -233,6 +233,116 @@ __global__ __launch_bounds__(64) void k_fe_dcblock(const int16_t* in, size_t in_
     if (mode == DH_FE_IQ_S16 && n) { st[2] = (float) in[ch * in_stride + 2 * n - 2]; st[3] = (float) in[ch * in_stride + 2 * n - 1]; }
 }
 
+// The front-end in ONE launch (round 3): a workgroup of five wavefronts takes DH_FE_CH channels through tiles of DH_FE_TS
+// samples, double-buffered.  Per tile: every thread of wavefronts 1..4 converts DH_FE_SPT consecutive samples of one channel (int16 audio, or I / Q pairs through the
+// polar discriminator -- 16-byte loads, 128 contiguous bytes per channel and instruction) into an LDS tile; the first
+// wavefront then runs the DC blocker's recurrence, one channel per lane, reading its row of the tile (padded: conflict-free)
+// and writing the result back in place; every thread stores four floats of one channel (coalesced 512-byte rows).  No float
+// round trip through HBM, int16 in -> float out: 4 + 4 bytes per sample instead of 4 + 4 + 4 + 4 + a second launch.
+// Same arithmetic, operation for operation, as dh_frontend_channel (the CPU harness runs that; oracle/frontend.c is the checker).
+#ifndef DH_FE_CH
+#define DH_FE_CH 16
+#endif
+#ifndef DH_FE_TS
+#define DH_FE_TS 128
+#endif
+#define DH_FE_SPT (DH_FE_CH * DH_FE_TS / 256)          // samples a thread converts per tile (a multiple of 4)
+__global__ __launch_bounds__(320) void k_fe_fused(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // five wavefronts: the first runs the recurrence of tile k while the other four convert tile k + 1 into the second buffer
+    __shared__ float tiles[2][DH_FE_CH][DH_FE_TS + 1];
+    const int lane0 = threadIdx.x;                               // < 64: the recurrence wavefront
+    const int tid = (int) threadIdx.x - 64;                      // 0..255: converting / storing threads
+    const size_t ch0 = blockIdx.x * (size_t) DH_FE_CH;
+    static_assert(DH_FE_SPT % 4 == 0 && DH_FE_SPT >= 4 && 256 % DH_FE_CH == 0, "whole 16-byte loads per thread");
+    const int c = tid >= 0 ? tid / (256 / DH_FE_CH) : 0, s0 = tid >= 0 ? (tid % (256 / DH_FE_CH)) * DH_FE_SPT : 0;
+    const bool c_ok = tid >= 0 && ch0 + c < B;
+    const int16_t* row = in + (c_ok ? ch0 + c : ch0) * in_stride;
+    const int32_t ip0 = c_ok ? (int32_t) state[(ch0 + c) * DH_FE_STATE_WORDS + 2] : 0, qp0 = c_ok ? (int32_t) state[(ch0 + c) * DH_FE_STATE_WORDS + 3] : 0;
+    const bool aligned = (((uintptr_t) row) & 3u) == 0;          // (dword loads want 4-byte alignment; odd strides of int16 audio take the scalar route)
+    float xp = 0.0f, yp = 0.0f;
+    const bool rec = lane0 < DH_FE_CH && ch0 + lane0 < B;
+    if (rec) { xp = state[(ch0 + lane0) * DH_FE_STATE_WORDS + 0]; yp = state[(ch0 + lane0) * DH_FE_STATE_WORDS + 1]; }
+
+    auto convert = [&](size_t t0, float (*tile)[DH_FE_TS + 1]) {
+        if (!c_ok || t0 >= n) return;
+        const size_t t = t0 + s0;
+        if (t + DH_FE_SPT <= n && aligned && mode == DH_FE_IQ_S16) {
+            uint32_t w[DH_FE_SPT + 1];                           // the pair before the first sample, then this thread's pairs
+            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(row + 2 * t);
+#pragma unroll
+            for (int j = 0; j < DH_FE_SPT / 4; j++) { const dh_u4 v = *reinterpret_cast<const dh_u4*>(p32 + 4 * j); w[1 + 4 * j] = v[0]; w[2 + 4 * j] = v[1]; w[3 + 4 * j] = v[2]; w[4 + 4 * j] = v[3]; }
+            w[0] = t ? p32[-1] : (((uint32_t) (uint16_t) (int16_t) qp0) << 16) | (uint16_t) (int16_t) ip0;
+#pragma unroll
+            for (int j = 0; j < DH_FE_SPT; j++) {
+                const int32_t i = (int16_t) (w[j + 1] & 0xFFFFu), q = (int16_t) (w[j + 1] >> 16);
+                const int32_t ip = (int16_t) (w[j] & 0xFFFFu), qp = (int16_t) (w[j] >> 16);
+                tile[c][s0 + j] = dh_fe_atan2_over_pi(q * ip - i * qp, i * ip + q * qp);
+            }
+        } else if (t + DH_FE_SPT <= n && aligned && mode == DH_FE_AUDIO_S16 && DH_FE_SPT % 8 == 0 && (in_stride & 1u) == 0) {
+            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(row + t);           // eight samples per 16-byte load
+#pragma unroll
+            for (int j = 0; j < DH_FE_SPT / 8; j++) {
+                const dh_u4 v = *reinterpret_cast<const dh_u4*>(p32 + 4 * j);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    tile[c][s0 + 8 * j + 2 * k] = (float) (int16_t) (v[k] & 0xFFFFu) * 0.000030517578125f;
+                    tile[c][s0 + 8 * j + 2 * k + 1] = (float) (int16_t) (v[k] >> 16) * 0.000030517578125f;
+                }
+            }
+        } else {
+            for (int j = 0; j < DH_FE_SPT; j++) if (t + j < n) tile[c][s0 + j] = dh_fe_convert(row, t + j, mode, ip0, qp0);
+        }
+    };
+
+    if (tid >= 0) convert(0, tiles[0]);
+    __syncthreads();
+    size_t k = 0;
+    for (size_t t0 = 0; t0 < n; t0 += DH_FE_TS, k++) {
+        float (*tile)[DH_FE_TS + 1] = tiles[k & 1];
+        if (tid >= 0) convert(t0 + DH_FE_TS, tiles[(k + 1) & 1]);
+        else if (rec && dcblock) {
+            const size_t cnt = n - t0 < DH_FE_TS ? n - t0 : DH_FE_TS;
+            float* r = tile[lane0];
+            size_t i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = r[i + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const float d = x[j] - xp; const float f = 0.995f * yp; yp = d + f; xp = x[j]; r[i + j] = yp; }
+            }
+            for (; i < cnt; i++) { const float x = r[i]; const float d = x - xp; const float f = 0.995f * yp; yp = d + f; xp = x; r[i] = yp; }
+        } else if (rec) {
+            const size_t cnt = n - t0 < DH_FE_TS ? n - t0 : DH_FE_TS;
+            xp = tile[lane0][cnt - 1]; yp = xp;
+        }
+        __syncthreads();
+        if (tid >= 0) {
+#pragma unroll
+            for (int pass = 0; pass < DH_FE_CH * DH_FE_TS / (256 * 4); pass++) {
+                const int e = (pass * 256 + tid) * 4, cs = e / DH_FE_TS, q0 = e % DH_FE_TS;
+                if (ch0 + cs < B) {
+                    float* dst = out + (ch0 + cs) * out_stride + t0 + q0;
+                    if (t0 + q0 + 4 <= n && ((((uintptr_t) dst) & 15u) == 0)) {
+                        dh_f4a v; v.x = tile[cs][q0]; v.y = tile[cs][q0 + 1]; v.z = tile[cs][q0 + 2]; v.w = tile[cs][q0 + 3];
+                        *reinterpret_cast<dh_f4a*>(dst) = v;
+                    } else {
+                        for (int j = 0; j < 4; j++) if (t0 + q0 + j < n) dst[j] = tile[cs][q0 + j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (rec) {
+        float* st = state + (ch0 + lane0) * DH_FE_STATE_WORDS;
+        st[0] = xp; st[1] = yp;
+        if (mode == DH_FE_IQ_S16 && n) { const int16_t* r = in + (ch0 + lane0) * in_stride; st[2] = (float) r[2 * n - 2]; st[3] = (float) r[2 * n - 1]; }
+    }
+#endif
+}
+
 __global__ void k_div_gain(const float* in, float* out, size_t n, double gain, double rgain) {
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
         out[i] = dh_div_gain(in[i], gain, rgain);
@@ -621,11 +731,19 @@ static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t 
 
 static int dh_be_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock, void* stream) {
     if (!B || !n) return DH_OK;
+#ifdef DH_FE_TWO_LAUNCHES                   // (round 2's pair of kernels, kept for A/B: tools/build_variant.sh)
     const unsigned gx = (unsigned) std::min<size_t>((n + 1023) / 1024, 64);
-    hipLaunchKernelGGL(k_fe_convert, dim3(gx, (unsigned) B), dim3(256), 0, (hipStream_t) stream, in, in_stride, out, out_stride, (const float*) state, n, mode);
-    HIP_TRY(hipGetLastError());
+    for (size_t b0 = 0; b0 < B; b0 += 65535) {              // channels on grid.y: at most 65 535 per launch
+        const size_t nb = std::min<size_t>(B - b0, 65535);
+        hipLaunchKernelGGL(k_fe_convert, dim3(gx, (unsigned) nb), dim3(256), 0, (hipStream_t) stream, in + b0 * in_stride, in_stride, out + b0 * out_stride, out_stride, (const float*) state + b0 * DH_FE_STATE_WORDS, n, mode);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_fe_dcblock, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
     HIP_TRY(hipGetLastError());
+#else
+    hipLaunchKernelGGL(k_fe_fused, dim3((unsigned) ((B + DH_FE_CH - 1) / DH_FE_CH)), dim3(320), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
+    HIP_TRY(hipGetLastError());
+#endif
     return DH_OK;
 }
 
