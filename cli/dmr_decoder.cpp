@@ -6,6 +6,10 @@
 #include <mutex>
 #include <thread>
 
+#include <fcntl.h>
+#include <poll.h>
+#include <unistd.h>
+
 #include "digiham/cli.hpp"
 #include "digiham/dmr_decoder.hpp"
 
@@ -21,6 +25,7 @@ namespace {
             void declareOptions(std::vector<Digiham::CliOption>& table) override {
                 Digiham::DecoderCli::declareOptions(table);
                 table.push_back({ 'c', "control-fifo", "path", "read control messages from this file", [this] (const char* path) {
+                    if (control.joinable()) return true;        // a repeated -c: the first one stands (assigning to a running std::thread terminates)
                     control = std::thread([this, p = std::string(path)] () { controlLoop(p); });
                     return true;
                 } });
@@ -43,21 +48,32 @@ namespace {
             // keeps listening -- every later `echo N > control_fifo` must still arrive (dmr_cli.cpp:57-78) -- with a short
             // sleep instead of the reference's busy spin.
             void controlLoop(const std::string& path) {
-                FILE* fifo = fopen(path.c_str(), "r");
-                if (fifo == nullptr) return;
-                char line[2];
-                while (!quit && !ferror(fifo)) {
-                    if (fread(line, sizeof(char), 2, fifo) < 2) {
-                        clearerr(fifo);
-                        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+                // non-blocking open + poll with a timeout: neither a fifo without a writer nor an idle writer can keep this thread
+                // from seeing `quit` (with fopen / fread the tool hung at exit, as the reference does: dmr_cli.cpp:57-78)
+                const int fd = open(path.c_str(), O_RDONLY | O_NONBLOCK);
+                if (fd < 0) return;
+                char prev = 0;
+                bool have_prev = false;
+                while (!quit) {
+                    struct pollfd p = { fd, POLLIN, 0 };
+                    const int r = poll(&p, 1, 50);
+                    if (r <= 0 || !(p.revents & POLLIN)) {
+                        if (p.revents & (POLLHUP | POLLERR)) std::this_thread::sleep_for(std::chrono::milliseconds(20));     // no writer at the moment: keep listening
                         continue;
                     }
-                    if (line[1] != '\n') continue;
-                    std::lock_guard<std::mutex> lock(decoderMutex);
-                    filter = line[0] - '0';
-                    if (decoder != nullptr) decoder->setSlotFilter((unsigned char) filter);
+                    char buf[64];
+                    const ssize_t got = read(fd, buf, sizeof(buf));
+                    if (got <= 0) { std::this_thread::sleep_for(std::chrono::milliseconds(20)); continue; }
+                    for (ssize_t i = 0; i < got; i++) {          // "<digit>\n" pairs, as the reference reads them two bytes at a time
+                        if (!have_prev) { prev = buf[i]; have_prev = true; continue; }
+                        have_prev = false;
+                        if (buf[i] != '\n') continue;
+                        std::lock_guard<std::mutex> lock(decoderMutex);
+                        filter = prev - '0';
+                        if (decoder != nullptr) decoder->setSlotFilter((unsigned char) filter);
+                    }
                 }
-                fclose(fifo);
+                close(fd);
             }
             std::mutex decoderMutex;                    // guards `decoder` and `filter` (control thread vs. main thread)
             Digiham::Dmr::Decoder* decoder = nullptr;

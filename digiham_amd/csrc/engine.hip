@@ -604,9 +604,13 @@ struct HipBackend {
                 hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 0>), dim3(first), dim3(DH_WAVE), lds, side, P, D);
                 timing_mark(5);
                 hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 1>), dim3(P.n_channels - first), dim3(DH_WAVE), lds, side_lo, Q, D);
+                join_pending = true;                // work is on the side streams from here on: whatever happens next, they must be joined
                 if (hip_fail(hipEventRecord(ev_join, side), "hipEventRecord") ||
-                    hip_fail(hipEventRecord(ev_join_lo, side_lo), "hipEventRecord")) return -1;
-                join_pending = true;
+                    hip_fail(hipEventRecord(ev_join_lo, side_lo), "hipEventRecord")) {
+                    (void) hipStreamSynchronize(side); (void) hipStreamSynchronize(side_lo);       // no event to wait on: drain them here
+                    join_pending = false;
+                    return -1;
+                }
                 return launched("k_chain");
             }
         }
@@ -628,8 +632,16 @@ struct HipBackend {
     }
     template <int NZ, bool FAST> int go_rrc_tiles(const DhRrcParams& R) {
         const uint32_t tiles = (R.n + DH_FTILE - 1) / DH_FTILE;
-        hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3((tiles + DH_TILES_PER_WG - 1) / DH_TILES_PER_WG, R.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), ms(), R);
-        return launched("k_rrc_tile");
+        // channels on grid.y: at most 65 535 per launch
+        for (uint32_t b0 = 0; b0 < R.n_channels; b0 += 65535u) {
+            DhRrcParams Q = R;
+            Q.n_channels = std::min<uint32_t>(R.n_channels - b0, 65535u);
+            Q.in = R.in + (size_t) b0 * R.in_stride; Q.out = R.out + (size_t) b0 * R.out_stride; Q.hist = R.hist + (size_t) b0 * NZ;
+            if (R.n_per) Q.n_per = R.n_per + b0;
+            hipLaunchKernelGGL((k_rrc_tile<NZ, FAST>), dim3((tiles + DH_TILES_PER_WG - 1) / DH_TILES_PER_WG, Q.n_channels), dim3(DH_WAVE), dh_dsp_shared_bytes(0, NZ), ms(), Q);
+            if (launched("k_rrc_tile")) return -1;
+        }
+        return 0;
     }
     int launch_rrc_tiles(const DhRrcParams& R, uint32_t nz, bool fast) {
         if (nz == 80) return fast ? go_rrc_tiles<80, true>(R) : go_rrc_tiles<80, false>(R);
@@ -637,8 +649,14 @@ struct HipBackend {
         return -1;
     }
     int launch_rrc_generic(const DhRrcGenParams& G) {
-        hipLaunchKernelGGL(k_rrc_generic, dim3((G.n + DH_FTILE - 1) / DH_FTILE, G.n_channels), dim3(DH_WAVE), 0, ms(), G);
-        return launched("k_rrc_generic");
+        for (uint32_t b0 = 0; b0 < G.n_channels; b0 += 65535u) {      // channels on grid.y: at most 65 535 per launch
+            DhRrcGenParams Q = G;
+            Q.n_channels = std::min<uint32_t>(G.n_channels - b0, 65535u);
+            Q.in = G.in + (size_t) b0 * G.in_stride; Q.out = G.out + (size_t) b0 * G.out_stride; Q.hist = G.hist + (size_t) b0 * G.nz;
+            hipLaunchKernelGGL(k_rrc_generic, dim3((G.n + DH_FTILE - 1) / DH_FTILE, Q.n_channels), dim3(DH_WAVE), 0, ms(), Q);
+            if (launched("k_rrc_generic")) return -1;
+        }
+        return 0;
     }
     int launch_rrc_hist(float* hist, const float* in, size_t in_stride, uint32_t n, const uint32_t* n_per, uint32_t nz, uint32_t B) {
         hipLaunchKernelGGL(k_rrc_hist, dim3(B), dim3(DH_WAVE), 0, ms(), hist, in, in_stride, n, n_per, nz);

@@ -310,3 +310,39 @@ def test_ysf_gps_lines_from_engine_events(ctx, tmp_path):
     lines = _lines_from_engine(ctx, tmp_path, "ysf", np.array(out, np.uint8))
     assert any((";lat:%f;lon:%f;mode:DN;protocol:YSF" % (lat, lon)).encode() in b";" + l for l in lines), lines
     assert any(b"source:DL1ABC" in l and b"target:CQCQCQ" in l for l in lines)
+
+
+def test_dmr_decoder_control_fifo_takes_commands_and_lets_the_tool_exit(oracle, tmp_path):
+    """dmr_decoder -c <fifo> (src/dmr_decoder/dmr_cli.cpp:57-78): a slot filter written to the fifo arrives, a fifo nobody writes
+    to -- or whose writer sits idle -- does not keep the tool from exiting at the end of its input (the reference hangs there),
+    and a second -c is ignored."""
+    import time
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    import hostemu
+    hostemu.build()
+    libdir = os.path.join(ROOT, "tests", "host_harness")
+    exe = str(bindir / "dmr_decoder")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "cli", "dmr_decoder.cpp"),
+                    "-o", exe, "-L" + libdir, "-ldh_hostemu", "-Wl,-rpath," + libdir, "-pthread"], check=True)
+    fifo = str(tmp_path / "ctl.fifo")
+    os.mkfifo(fifo)
+    syms = synth.dmr_stream(91, 30, two_slots=True)
+    # (1) no writer at all: the tool must come back at the end of its input
+    t0 = time.time()
+    r = subprocess.run([exe, "-c", fifo, "-c", fifo], input=syms.tobytes(), capture_output=True, timeout=20)
+    assert r.returncode == 0 and time.time() - t0 < 10
+    both = np.frombuffer(r.stdout, np.uint8)
+    # (2) a writer that sets the filter first and then sits idle with the fifo open
+    p = subprocess.Popen([exe, "-c", fifo], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    w = os.open(fifo, os.O_WRONLY)
+    os.write(w, b"2\n")
+    time.sleep(0.5)                                               # the control thread has seen it before the symbols arrive
+    out, _ = p.communicate(syms.tobytes(), timeout=20)
+    os.close(w)
+    assert p.returncode == 0
+    d = oracle.Decoder("dmr"); d.set_slot_filter(2)
+    want, _ = d.process(syms)
+    got = np.frombuffer(out, np.uint8)
+    assert len(want) > 0 and len(got) == len(want) and (got == want).all()
+    assert got.tobytes() != both.tobytes()                        # (unfiltered, the first slot to speak wins)
