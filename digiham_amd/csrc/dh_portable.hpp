@@ -40,7 +40,13 @@
 static __device__ __forceinline__ int dh_fresh_lane_id_() { int l = (int) threadIdx.x; asm volatile("" : "+v"(l)); return l; }
 #define DH_FOR_LANES(lane) for (int lane = (int) threadIdx.x, dh_once_ = 1; dh_once_; dh_once_ = 0)
 #define DH_FOR_LANES_FRESH(lane) for (int lane = dh_fresh_lane_id_(), dh_once_ = 1; dh_once_; dh_once_ = 0)
-#define DH_BARRIER() __syncthreads()
+// The phases of a body exchange data through LDS only, so the barrier orders LDS traffic only: __syncthreads() also fences
+// GLOBAL memory, which makes the compiler wait (s_waitcnt vmcnt(0)) for every global load in flight -- the next window's
+// loads, requested a phase earlier precisely so that they can stay in flight through the phases that follow (round 3: the wait
+// sat in front of the slicing phase and cost 1 ms of a 6.8 ms step).  Where a body hands data to another one through global
+// memory the caller fences explicitly (k_chain: __threadfence() between slicer and decoder).
+#define DH_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #define DH_BALLOT_ACC(mask, pred, lane) (mask) = __ballot((pred) ? 1 : 0)
 #define DH_IS_LANE0(lane) ((lane) == 0)
 #else

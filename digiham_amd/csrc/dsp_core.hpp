@@ -1381,8 +1381,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #define DH_TAPFRAG_LOAD() do { if constexpr (MF16) { const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(P.tapfrag) + dh_fresh_lane_id_(); \
         _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
     DH_TAPFRAG_LOAD();
+    // Every path through P2 must leave these loads landed, also the rare ones that never look at the fragments: otherwise the
+    // compiler's wait-count bookkeeping still sees them in flight further down, and the first instruction that reuses one of
+    // their registers -- in the slicing phase -- gets an s_waitcnt vmcnt(0), which also waits for the NEXT window's loads,
+    // requested after P3 precisely so that they can stay in flight through P4 - P6 (it cost 1 ms of a 6.8 ms step).
+#define DH_TAPFRAG_SETTLE() do { if constexpr (MF16) { _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) \
+        asm volatile("" :: "v"(tapfrag_regs[f_])); } } while (0)
 #else
 #define DH_TAPFRAG_LOAD() ((void) 0)
+#define DH_TAPFRAG_SETTLE() ((void) 0)
 #endif
     for (;;) {
         // ---- run planning (wave-uniform): symbols k0 .. k0+m-1 of the current variance block.
@@ -1662,6 +1669,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
 #endif
         }
+        DH_TAPFRAG_SETTLE();
         DH_CLK(1);
         const float* fbuf = S.xf;
 #define DH_FB(n) fbuf[n]
