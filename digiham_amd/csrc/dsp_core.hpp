@@ -125,8 +125,13 @@ DH_HD uint32_t dh_dsp_xf_words(uint32_t nz) {
     const uint32_t padded = DH_XPAD(DH_FTILE + nz) + 1u, with_sums = DH_FTILE + 4u + DH_SCAN_N;
     return ((padded > with_sums ? padded : with_sums) + 3u) & ~3u;
 }
+#ifdef DH_NO_RING                           // diagnostic builds (WRONG timing decisions): the variance ring aliases the window block -- what would a smaller LDS block buy?
+#define DH_RING_WORDS(sps) 0u
+#else
+#define DH_RING_WORDS(sps) (DH_VARIANCE_SYMBOLS * (sps))
+#endif
 DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz) {
-    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + DH_VARIANCE_SYMBOLS * sps + dh_dsp_xf_words(nz));
+    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + DH_RING_WORDS(sps) + dh_dsp_xf_words(nz));
 }
 DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {          // base: 16-byte aligned
     float* f = reinterpret_cast<float*>(base);
@@ -142,7 +147,7 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {     
         S.stats = reinterpret_cast<uint32_t*>(f + 256 + 124); S.clk = reinterpret_cast<uint32_t*>(f + 384);
     }
     S.var_rb = f + dh_lds_fixed_words(nz);
-    S.xf = S.var_rb + DH_VARIANCE_SYMBOLS * sps;
+    S.xf = S.var_rb + DH_RING_WORDS(sps);
     S.mn = S.xf; S.mx = S.xf + DH_SCAN_N;
     S.variance = reinterpret_cast<double*>(S.xf + 2 * DH_SCAN_N);
     S.sum = S.xf + DH_FTILE + 4;
@@ -1690,7 +1695,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     for (uint32_t i = 0; i < (SPS ? SPS : 1); i++) {
                         if (i >= ev_lo && i < ev_hi) sum += value[i];
                         volume_sum += value[i];
+#ifndef DH_NO_RING
                         S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
+#endif
                     }
                 } else {
                     // four samples at a time, all four requested before the first is used (see above); sums in sample order
@@ -1703,14 +1710,18 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         for (uint32_t j = 0; j < 4u; j++) {
                             if (i + j >= ev_lo && i + j < ev_hi) sum += value[j];
                             volume_sum += value[j];
+#ifndef DH_NO_RING
                             S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
+#endif
                         }
                     }
                     for (; i < sps; i++) {
                         const float value = DH_FB(s + i);
                         if (i >= ev_lo && i < ev_hi) sum += value;
                         volume_sum += value;
+#ifndef DH_NO_RING
                         S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
+#endif
                     }
                 }
                 S.sum[q] = sum;
