@@ -8,6 +8,7 @@ oracle/decoders.c -- or by the product, which must emit the same records) into t
             (call sites), talkeralias.cpp:23-143, gps.cpp:7-16, lc.cpp:26-43
   YSF       src/ysf_decoder/ysf_meta.cpp:13-105, ysf_phase.cpp:50,73,87,112,133,139-164,258-305,351-361, data.cpp:24-88, gps.cpp:5-82
   NXDN      src/nxdn_decoder/nxdn_meta.cpp:6-76, nxdn_phase.cpp:50,115,138,153, sacch.cpp:141-155
+  D-Star    src/dstar_decoder/dstar_meta.cpp:9-135, dstar_phase.cpp:50,97,105,110,205-290, header.cpp:150-181, crc.cpp:6-23
 
 PARITY UNPINNED: those translation units include <csdr/module.hpp> or ICU and cannot be built in this image; this file
 follows them line by line and is what the product's collectors (include/digiham/*_meta.hpp) are compared with.
@@ -458,8 +459,207 @@ class NxdnLines:
                 self._set("destination", pay[5] << 8 | pay[6])
 
 
+# ------------------------------------------------------------------------------------------------- D-Star
+def dstar_crc_ok(data, to_check):
+    """Crc::isCrcValid (src/dstar_decoder/crc.cpp:6-23)"""
+    c = 0xFFFF
+    for byte in data:
+        for i in range(8):
+            c ^= (byte >> i) & 1
+            c = (c >> 1) ^ 0x8408 if c & 1 else c >> 1
+    return (c ^ 0xFFFF) == to_check
+
+
+def hex_extract_u16(text):
+    """`std::stringstream ss; ss << std::hex << text; ss >> (uint16_t) v` (dstar_phase.cpp:222-225, :262-265) as libstdc++'s
+    num_get does it: white space skipped, an optional sign, an optional 0x, hex digits; no digit -> 0."""
+    i, n = 0, len(text)
+    while i < n and text[i] in b" \t\n\v\f\r":
+        i += 1
+    neg = False
+    if i < n and text[i] in b"+-":
+        neg = text[i] == 0x2D
+        i += 1
+    found_zero, sep_pos, had_x = False, 0, False       # num_get::_M_extract_int, base 16 (checked against libstdc++ 11)
+    while i < n:
+        if text[i] == 0x30 and not found_zero:
+            found_zero, sep_pos = True, sep_pos + 1
+        elif found_zero and text[i] in b"xX" and not had_x:
+            found_zero, sep_pos, had_x = False, 0, True
+        else:
+            break
+        i += 1
+    v = 0
+    while i < n and text[i] in b"0123456789abcdefABCDEF":
+        v = v * 16 + int(chr(text[i]), 16)
+        sep_pos += 1
+        i += 1
+    if not sep_pos and not found_zero:
+        return 0                                       # failbit, value 0 (C++11)
+    if v > 0xFFFF:
+        return 0xFFFF                                  # overflow: failbit, the largest value
+    return (-v) & 0xFFFF if neg else v
+
+
+def stof(text):
+    """std::stof: strtof's longest valid prefix after white space; None where it throws"""
+    import re
+    m = re.match(rb"[ \t\n\v\f\r]*[+-]?(?:0[xX](?:[0-9a-fA-F]+\.?[0-9a-fA-F]*|\.[0-9a-fA-F]+)(?:[pP][+-]?[0-9]+)?|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?|[iI][nN][fF](?:[iI][nN][iI][tT][yY])?|[nN][aA][nN])", text)
+    if not m:
+        return None
+    t = m.group(0).strip().decode()
+    try:
+        v = float.fromhex(t) if "x" in t.lower() else float(t)
+    except (ValueError, OverflowError):
+        return None
+    with np.errstate(over="ignore"):
+        r = F32(v)
+    if (np.isinf(r) and not np.isinf(v)) or (v != 0 and abs(float(r)) < 1.1754943508222875e-38):
+        return None                                    # out_of_range (glibc's strtof reports overflow and underflow)
+    return r
+
+
+class DstarLines:
+    """dstar_meta.cpp:9-135 on the calls of dstar_phase.cpp:50,97,105,110,205-290 (header.cpp:150-181 for the fields)"""
+    KEYS = (("sync", "sync"), ("departure", "departure"), ("destination", "destination"), ("ourcall", "ourcall"),
+            ("yourcall", "yourcall"), ("message", "message"), ("dprs", "dprs"))
+
+    def __init__(self):
+        self.v = {k: b"" for k, _ in self.KEYS}
+        self.coord = None
+        self.header = bytearray(41)
+        self.simple = b""
+        self.held, self.dirty, self.lines = 0, False, []
+
+    def _send(self):                                   # meta.cpp:93-99
+        if self.held:
+            self.dirty = True
+            return
+        d = {"protocol": "DSTAR"}                      # dstar_meta.cpp:100-135
+        for k, name in self.KEYS:
+            if self.v[k]:
+                d[name] = self.v[k]
+        if self.coord is not None:
+            d["lat"], d["lon"] = f2s(self.coord[0]), f2s(self.coord[1])
+        self.lines.append(serialize(d))
+
+    def _hold(self):
+        self.held += 1
+
+    def _release(self):                                # meta.cpp:79-91
+        self.held -= 1
+        if self.held == 0:
+            if self.dirty:
+                self._send()
+            self.dirty = False
+
+    def _set(self, k, v):
+        v = _b(v)
+        if self.v[k] == v:
+            return
+        self.v[k] = v
+        self._send()
+
+    def _set_gps(self, c):                             # dstar_meta.cpp:71-81
+        if self.coord is None and c is None:
+            return
+        if self.coord is not None and c is not None and self.coord[0] == c[0] and self.coord[1] == c[1]:
+            return
+        self.coord = c
+        self._send()
+
+    def _field(self, at, n):
+        return latin1(self.header[at:at + n]).rstrip(" ")
+
+    def _from_header(self):                            # dstar_meta.cpp:15-27
+        self._hold()
+        self._set("sync", "data" if (self.header[0] >> 7) & 1 else "voice")
+        self._set("departure", self._field(11, 8))
+        self._set("destination", self._field(3, 8))
+        own, suffix = self._field(27, 8), self._field(35, 4)
+        self._set("ourcall", own + "/" + suffix if suffix != "" else own)
+        self._set("yourcall", self._field(19, 8))
+        self._release()
+
+    def _nmea(self, s):                                # dstar_phase.cpp:248-290
+        star = s.rfind(b"*")
+        if star < 0 or star + 2 > len(s):
+            return
+        if star < 1:
+            return                                     # (the reference's substr(1, npos-ish) case; see the product's note)
+        body = s[1:star]
+        if len(body) < 2:
+            return                                     # where body.substr(2, 3) would throw
+        sentence = body[2:5]
+        x = 0
+        for ch in body:
+            x ^= ch
+        if x != hex_extract_u16(s[star + 1:star + 3]):
+            return
+        fields = body.split(b",")
+        if body.endswith(b","):
+            fields = fields[:-1]                       # getline() yields no empty item behind a trailing separator
+        if sentence == b"GGA":
+            if len(fields) < 6:
+                return                                 # (undefined behaviour in the reference)
+            la, lo = stof(fields[2]), stof(fields[4])
+            if la is None or lo is None:
+                return                                 # (an exception ends the reference's process)
+            with np.errstate(all="ignore"):
+                if not np.isfinite(la) or not np.isfinite(lo) or abs(float(la)) >= 2 ** 31 or abs(float(lo)) >= 2 ** 31:
+                    return                             # (int) of such a float is undefined; the streams do not carry one
+                lat = F32(int(la) // 100 if la >= 0 else -((-int(la)) // 100))
+                lat = F32(lat + F32(F32(la - F32(lat * F32(100))) / F32(60)))
+                if fields[3] == b"S":
+                    lat = F32(-lat)
+                lon = F32(int(lo) // 100 if lo >= 0 else -((-int(lo)) // 100))
+                lon = F32(lon + F32(F32(lo - F32(lon * F32(100))) / F32(60)))
+                if fields[5] == b"W":
+                    lon = F32(-lon)
+            self._set_gps((lat, lon))
+
+    def _parse_simple(self):                           # dstar_phase.cpp:218-245
+        while True:
+            pos = self.simple.find(b"\r")
+            if pos < 0:
+                break
+            s = self.simple[:pos + 1]
+            if len(s) >= 10 and s[:5] == b"$$CRC" and s[9:10] == b",":
+                if dstar_crc_ok(s[10:], hex_extract_u16(s[5:9])):
+                    self._set("dprs", s[10:len(s) - 1])
+            elif len(s) > 5 and s[:1] == b"$":
+                self._nmea(s)
+            self.simple = self.simple[pos + 1 + (1 if self.simple[pos + 1:pos + 2] == b"\n" else 0):]
+
+    def consume(self, ev):
+        t = int(ev["type"])
+        pay = bytes(bytearray(ev["payload"][:int(ev["len"])]))
+        if t == 64:                                    # the 41 header bytes come as two records
+            if int(ev["a"]) == 0:
+                self.header[:24] = pay[:24]
+            else:
+                self.header[24:41] = pay[:17]
+                self._from_header()
+        elif t == 65:                                  # a new VoicePhase (dstar_phase.hpp:77)
+            self.simple = b""
+        elif t == 66:
+            self._set("sync", "voice")
+        elif t == 67:                                  # :207
+            self._set("message", latin1(pay[:20]))
+        elif t == 68:                                  # :178
+            self.simple += pay
+        elif t == 69:
+            self._parse_simple()
+        elif t == 70:                                  # dstar_meta.cpp:83-94
+            self._hold()
+            for k, _ in self.KEYS:
+                self._set(k, "")
+            self._set_gps(None)
+            self._release()
+
+
 def lines(proto, events):
-    m = {"dmr": DmrLines, "ysf": YsfLines, "nxdn": NxdnLines}[proto]()
+    m = {"dmr": DmrLines, "ysf": YsfLines, "nxdn": NxdnLines, "dstar": DstarLines}[proto]()
     for ev in events:
         m.consume(ev)
     if hasattr(m, "finish"):

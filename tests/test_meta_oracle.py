@@ -146,6 +146,76 @@ def _ysf_stream(rng):
     return out
 
 
+def _dstar_sentence(rng):
+    """One slow-data sentence: DPRS / NMEA, valid or broken in one of the ways the parser has a branch for"""
+    kind = int(rng.integers(0, 14))
+    call = "".join(chr(int(c)) for c in rng.integers(65, 91, 6))
+    if kind <= 2:
+        s = synth.dstar_dprs_sentence("%s>APDPRS,DSTAR*:!%04d.%02dN/%05d.%02dE>%s" % (call, rng.integers(0, 9000), rng.integers(0, 100), rng.integers(0, 18000),
+                                                                                     rng.integers(0, 100), "".join(chr(int(c)) for c in rng.integers(0x20, 0x100, int(rng.integers(0, 12))))))
+        if kind == 1:
+            s = s[:5] + s[5:9].lower() + s[9:]                       # the checksum's hex digits in lower case
+        if kind == 2 and rng.integers(0, 2):
+            s = s[:12] + bytes([s[12] ^ 1]) + s[13:]                 # CRC failure
+        return s
+    if kind <= 6:
+        s = synth.dstar_gga_sentence(float(rng.uniform(-89, 89)), float(rng.uniform(-179, 179)))
+        if kind == 4:
+            s = s.replace(b"\r\n", b"\r")                            # termination may be \r or \r\n
+        if kind == 5:
+            s = s[:8] + bytes([s[8] ^ 2]) + s[9:]                    # checksum failure
+        if kind == 6:
+            s = s.replace(b"*", b"*0x"[:int(rng.integers(1, 4))], 1) if rng.integers(0, 2) else s[:-4].lower() + s[-4:]
+        return s
+    if kind == 7:                                                    # another NMEA sentence: checked, then ignored
+        body = "GPRMC,123519,A,4807.038,N,01131.000,E,022.4,084.4,230394,003.1,W"
+        cs = 0
+        for ch in body.encode():
+            cs ^= ch
+        return ("$%s*%02X\r\n" % (body, cs)).encode()
+    if kind == 8:                                                    # GGA with fields missing or not numeric; the checksum holds
+        body = str(rng.choice(["GPGGA,1,,N,,E", "GPGGA,1,x,N,1.0,E", "GPGGA,1,4807.038", "GPGGA,1,4807.038,S,01131.000,W,", "GP", "G", "GPGGA,,,,,,,,,"]))
+        cs = 0
+        for ch in body.encode():
+            cs ^= ch
+        return ("$%s*%02X\r" % (body, cs)).encode()
+    if kind == 9:
+        return b"$$CRC" + bytes(rng.integers(0x20, 0x7F, int(rng.integers(0, 12))).astype(np.uint8)) + b"\r"
+    if kind == 10:
+        return b"$" + bytes(rng.integers(0x20, 0x7F, int(rng.integers(0, 20))).astype(np.uint8)) + b"\r\n"
+    if kind == 11:
+        return bytes(rng.integers(0, 256, int(rng.integers(1, 25))).astype(np.uint8)) + b"\r"
+    if kind == 12:
+        return b"$GPGGA,no star\r\n*\r*1\r"
+    return b"\r\n\r"
+
+
+def _dstar_stream(rng):
+    def call(n):
+        k = int(rng.integers(0, n + 1))
+        if rng.integers(0, 5) == 0:
+            return "".join(chr(int(c)) for c in rng.choice([0x41, 0xC4, 0xE9, 0x20, 0x31, 0x00], k))
+        return "".join(chr(int(c)) for c in rng.choice(list(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 /"), k))
+    out = [rng.integers(0, 2, int(rng.integers(30, 200))).astype(np.uint8)]
+    for _ in range(int(rng.integers(1, 5))):
+        simple = b"".join(_dstar_sentence(rng) for _ in range(int(rng.integers(0, 4))))
+        msg = "".join(chr(int(c)) for c in rng.integers(0x20, 0x100, int(rng.integers(0, 21))))
+        if rng.integers(0, 6) == 0:
+            msg = msg[:len(msg) // 2] + "\0" + msg[len(msg) // 2 + 1:]
+        nsf = max(int(rng.integers(1, 6)), 2 * (-(-len(simple) // 30)) - 1 + int(rng.integers(0, 2)))
+        b, _, _ = synth.dstar_transmission(rng, my=call(8), your=call(8), rpt1=call(8), rpt2=call(8), suffix=call(4), message=msg, n_superframes=nsf,
+                                           simple=simple, with_header=bool(rng.integers(0, 5)), inline_header=bool(rng.integers(0, 4)),
+                                           data_flag=rng.integers(0, 8) == 0)
+        if rng.integers(0, 5) == 0:
+            b = b[:len(b) - int(rng.integers(48, 2000))]           # the transmission fades away: no terminator, syncs run out
+        out += [b, rng.integers(0, 2, int(rng.integers(30, 3000))).astype(np.uint8)]
+    bits = np.concatenate(out)
+    ber = float(rng.choice([0, 0, 0, 0.001, 0.004]))
+    if ber:
+        bits = bits ^ (rng.random(bits.size) < ber).astype(np.uint8)
+    return bits
+
+
 def _product_lines(ctx, exe, proto, syms, chunk):
     eng = api.Engine(1, len(syms), rrc="none", demod="none", proto=proto, ctx=ctx)
     batches = b""
@@ -163,9 +233,9 @@ def _oracle_lines(oracle, proto, syms):
     return list(M.lines(proto, ev))
 
 
-@pytest.mark.parametrize("proto,count", [("dmr", 120), ("ysf", 80), ("nxdn", 30)])
+@pytest.mark.parametrize("proto,count", [("dmr", 120), ("ysf", 80), ("nxdn", 30), ("dstar", 100)])
 def test_collector_lines_equal_the_oracle_lines(ctx, oracle, meta_exe, proto, count):
-    rng = np.random.default_rng({"dmr": 1, "ysf": 2, "nxdn": 3}[proto])
+    rng = np.random.default_rng({"dmr": 1, "ysf": 2, "nxdn": 3, "dstar": 4}[proto])
     total = 0
     kinds = set()
     for case in range(count):
@@ -173,6 +243,8 @@ def test_collector_lines_equal_the_oracle_lines(ctx, oracle, meta_exe, proto, co
             syms = _dmr_stream(rng)
         elif proto == "ysf":
             syms = _ysf_stream(rng)
+        elif proto == "dstar":
+            syms = _dstar_stream(rng)
         else:
             syms = synth.nxdn_stream(int(rng.integers(0, 1 << 30)), int(rng.integers(8, 40)), src=int(rng.integers(1, 65535)), dst=int(rng.integers(1, 65535)))
             if rng.integers(0, 3) == 0:
@@ -183,7 +255,8 @@ def test_collector_lines_equal_the_oracle_lines(ctx, oracle, meta_exe, proto, co
         assert got == ref, "%s case %d:\n%s\n--- oracle ---\n%s" % (proto, case, b"\n".join(got[:40]).decode(errors="replace"), b"\n".join(ref[:40]).decode(errors="replace"))
         total += len(ref)
         for l in ref:
-            for key in (b"talkeralias:", b"lat:", b"sync:data", b"type:direct", b"type:group", b"mode:DN", b"mode:V1", b"source:", b"type:conference", b"type:individual"):
+            for key in (b"talkeralias:", b"lat:", b"sync:data", b"type:direct", b"type:group", b"mode:DN", b"mode:V1", b"source:", b"type:conference", b"type:individual", b"dprs:", b"message:", b"ourcall:",
+                        b"departure:"):
                 if key in l:
                     kinds.add(key)
     assert total > 3 * count                                      # the streams do produce metadata
@@ -191,3 +264,5 @@ def test_collector_lines_equal_the_oracle_lines(ctx, oracle, meta_exe, proto, co
         assert {b"talkeralias:", b"lat:", b"sync:data", b"type:group", b"type:direct"} <= kinds
     if proto == "ysf":
         assert {b"lat:", b"mode:DN", b"source:"} <= kinds
+    if proto == "dstar":
+        assert {b"lat:", b"dprs:", b"message:", b"ourcall:", b"departure:", b"sync:data"} <= kinds
