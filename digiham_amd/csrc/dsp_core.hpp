@@ -160,6 +160,10 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {     
 #if defined(DH_PHASE_CLOCKS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 #define DH_CLK_BEGIN() uint64_t dh_clk_t = clock64()
 #define DH_CLK(i) do { const uint64_t dh_clk_n = clock64(); if (threadIdx.x == 0) S.clk[i] += (uint32_t) (dh_clk_n - dh_clk_t); dh_clk_t = clock64(); } while (0)
+#elif defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// (static census of the phases in the assembly: tools/asm_census.py counts the instructions between these comments)
+#define DH_CLK_BEGIN() asm volatile("; DH_PHASE begin" ::: "memory")
+#define DH_CLK(i) asm volatile("; DH_PHASE " #i ::: "memory")
 #else
 #define DH_CLK_BEGIN() ((void) 0)
 #define DH_CLK(i) ((void) 0)

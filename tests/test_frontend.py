@@ -56,6 +56,36 @@ def test_frontend_bit_exact_and_streamable(ctx, oracle, mode):
     assert abs(float(np.stack([oracle.frontend(r, mode, True)[0] for r in raw])[:, 3000:].mean())) < 0.02
 
 
+def test_frontend_iq_edge_values(ctx, oracle):
+    """The discriminator on I / Q that hits every branch of the arctangent: zero vectors (either sample 0), products on the
+    axes and the diagonals, both signs, full-scale values; odd and even tile boundaries (the GPU evaluates pairs of samples)."""
+    rng = np.random.default_rng(77)
+    n = 3 * 4096 + 37
+    rows = []
+    for kind in range(4):
+        z = rng.integers(-32768, 32768, (n, 2))
+        if kind == 1:
+            z = rng.integers(-3, 4, (n, 2))                              # tiny values: zeros, axes and diagonals are common
+        if kind == 2:
+            z[rng.random(n) < 0.3] = 0
+            rep = rng.random(n) < 0.3
+            z[1:][rep[1:]] = z[:-1][rep[1:]]                             # repeated samples: Im d = 0, Re d > 0
+            neg = rng.random(n) < 0.2
+            z[1:][neg[1:]] = -z[:-1][neg[1:]]                            # opposite samples: Im d = 0, Re d < 0
+        if kind == 3:
+            z = rng.choice([-32768, 32767, 0, 1, -1], (n, 2))
+        rows.append(np.clip(z, -32768, 32767).astype(np.int16).reshape(-1))
+    raw = np.stack(rows)
+    ref = np.stack([oracle.frontend(r, "iq", True)[0] for r in raw])
+    got, st, pos = [], None, 0
+    for c in (127, 1, 4096, 130, n):
+        c = min(c, n - pos)
+        out, st = ctx.frontend(np.ascontiguousarray(raw[:, 2 * pos:2 * (pos + c)]), "iq", True, st)
+        got.append(ctx.mem.to_numpy(out).copy())
+        pos += c
+    assert np.concatenate(got, axis=1).tobytes() == ref.tobytes()
+
+
 @pytest.mark.parametrize("mode", ["audio", "iq"])
 def test_frontend_in_front_of_the_dmr_chain(ctx, oracle, mode):
     """IQ (or int16 audio) in, DMR frames out: front-end -> rrc(wide) -> gfsk(10) -> dmr_decoder on the engine equals the
