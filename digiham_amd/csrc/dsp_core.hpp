@@ -799,6 +799,7 @@ DH_HD float dh_virtual_sample(const float* tail, uint32_t tc, const float* in, u
 // right after symbol k was written.  The reference seeds min with FLT_MAX and max with FLT_MIN
 // (sic: the smallest positive float), which are exactly the identities used for padding here.
 #define DH_FLT_MAX 3.402823466e+38f
+#define DH_DBL_MAX 1.7976931348623157e+308
 #define DH_FLT_MIN 1.175494351e-38f
 DH_HD float dh_fmin_(float a, float b) { return b < a ? b : a; }
 DH_HD float dh_fmax_(float a, float b) { return b > a ? b : a; }
@@ -1090,10 +1091,20 @@ DH_HD float dh_exact_filtered_lds(const float* raw, int32_t base, uint32_t nv, c
     if (f < 0 || (uint32_t) f + (uint32_t) NZ >= nv) return 0.0f;
     const float* x = raw + (f - base);
     float acc = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i <= NZ; i++) {
-        const float c = tapsf[i <= NZ / 2 ? i : NZ - i];
-        const float prod = c * x[i];
+    // eight products at a time, their sixteen LDS reads in flight together, then the eight additions in tap order (written
+    // tap by tap this compiled to a read - wait - multiply - add per tap: 110 cycles each, 620 000 for a variance ring)
+    // (the 161-tap kernels only: in the 81-tap ones, at 128 registers, the eight products push spills into the hot loop --
+    // 24 scratch accesses in the commit phase, DMR chain 6.8 -> 11.9 ms -- and their exact evaluations are 4x rarer and 2x shorter)
+    int i = 0;
+    for (; NZ > 80 && i + 8 <= NZ + 1; i += 8) {
+        float prod[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int t = i + j; prod[j] = tapsf[t <= NZ / 2 ? t : NZ - t] * x[t]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc = acc + prod[j];
+    }
+    for (; i <= NZ; i++) {
+        const float prod = tapsf[i <= NZ / 2 ? i : NZ - i] * x[i];
         acc = acc + prod;
     }
     return dh_div_gain(acc, gain, rgain);
@@ -1102,9 +1113,21 @@ DH_HD float dh_exact_filtered_lds(const float* raw, int32_t base, uint32_t nv, c
 DH_HD void dh_stage_raw(float* raw, const float* tail, uint32_t tc, const float* in, uint32_t nv, int32_t base, uint32_t count) {
     DH_BARRIER();
     DH_FOR_LANES_FRESH(lane) {
-        for (uint32_t e = (uint32_t) lane; e < count; e += DH_WAVE) {
-            const int32_t idx = base + (int32_t) e;
-            raw[e] = (idx >= 0 && (uint32_t) idx < nv) ? dh_virtual_sample(tail, tc, in, (uint32_t) idx) : 0.0f;
+        // four loads per lane in flight (one address each: the tail or the input), then their stores
+        for (uint32_t e0 = (uint32_t) lane; e0 < count; e0 += 4u * DH_WAVE) {
+            float v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t e = e0 + u * DH_WAVE;
+                const int32_t idx = base + (int32_t) e;
+                const bool have = e < count && idx >= 0 && (uint32_t) idx < nv;
+                const uint32_t at = have ? (uint32_t) idx : tc;                  // (any valid address for the lanes that store a zero)
+                const float* src = at < tc ? tail + at : in + (at - tc);
+                v[u] = (have || nv > tc) ? *src : 0.0f;
+                if (!have) v[u] = 0.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) { const uint32_t e = e0 + u * DH_WAVE; if (e < count) raw[e] = v[u]; }
         }
     }
     DH_BARRIER();
@@ -1174,18 +1197,32 @@ DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint
     return average > center ? (uint8_t) !C.invert : (uint8_t) (C.invert != 0);
 }
 // the variance ring of the block that just ended, recomputed exactly, a chunk of symbols at a time through `stage` (cap floats)
+// `rows`: the phases (rows of the transposed ring) to recompute -- all of them, or only those the float estimate could not
+// rule out as the arg-min (the others keep their approximate values and are not looked at: see P6)
 template <int NZ>
-DH_COLD void dh_exact_var_ring_staged(const DhExactCtx& C, DhDspShared& S, uint32_t sps, float* stage, uint32_t cap) {
+DH_COLD void dh_exact_var_ring_staged(const DhExactCtx& C, DhDspShared& S, uint32_t sps, float* stage, uint32_t cap, uint64_t rows) {
     const uint32_t spc = (cap - (uint32_t) NZ - 3u) / sps;            // symbols per chunk
+    const uint64_t all = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
+    const bool full = (rows & all) == all;
+    const uint32_t nrows = full ? sps : (uint32_t) (dh_popc32((uint32_t) (rows & all)) + dh_popc32((uint32_t) ((rows & all) >> 32)));
     for (uint32_t j0 = 0; j0 < DH_VARIANCE_SYMBOLS; j0 += spc) {
         const uint32_t nj = dh_min<uint32_t>(spc, DH_VARIANCE_SYMBOLS - j0);
         const int32_t base = C.cur_start + (int32_t) (j0 * sps) - 1;      // one sample of slack for the block's +-1 step
         dh_stage_raw(stage, C.tail, C.tc, C.in, C.nv, base, nj * sps + (uint32_t) NZ + 3u);
-        for (uint32_t r = 0; r * DH_WAVE < nj * sps; r++) {
+        for (uint32_t r = 0; r * DH_WAVE < nj * nrows; r++) {
             DH_FOR_LANES_FRESH(lane) {
                 const uint32_t e = r * DH_WAVE + (uint32_t) lane;
-                if (e < nj * sps) {
-                    const uint32_t jj = e / sps, i = e - jj * sps, j = j0 + jj;
+                if (e < nj * nrows) {
+                    uint32_t jj, i;
+                    if (full) { jj = e / sps; i = e - jj * sps; }
+                    else {
+                        const uint32_t c = e / nj;                     // the c-th phase of the set
+                        jj = e - c * nj;
+                        uint64_t m = rows & all;
+                        for (uint32_t b = 0; b < c; b++) m &= m - 1;
+                        i = (uint32_t) dh_ffs64(m);
+                    }
+                    const uint32_t j = j0 + jj;
                     const int32_t f = C.cur_start + (int32_t) (j * sps) + (j ? C.cur_off : 0) + (int32_t) i;
                     S.var_rb[i * DH_VARIANCE_SYMBOLS + j] = dh_exact_filtered_lds<NZ>(stage, base, C.nv, C.tapsf, C.gain, C.rgain, f);
                 }
@@ -1905,6 +1942,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done && DH_STOP_AFTER >= 6) {
             bool ordered = true;
+            // Phases that can still be the reference's arg-min once an estimate has been taken and could not decide: those whose
+            // interval [V' - tol, V' + tol] reaches below the smallest upper end.  Every other phase has V_ref > that upper end
+            // >= the smallest V_ref, strictly, so neither the minimum nor a tie: the ordered chain (and, in the error-bounded
+            // kernels, the exact recomputation of the ring in front of it) only has to look at these rows.  All rows when no
+            // valid set of intervals exists (no estimate, NaN / overflow, an estimate of exactly 0).
+            uint64_t chain_rows = ~0ull;
             if (SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
@@ -2001,6 +2044,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
                     else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
                 }
+                // (the candidates are not handed on here: one more live value costs the 81-tap kernels four scratch accesses in
+                // their hot loop, and they reach this point in 0.02 % of the blocks -- the 161-tap, sps-20 kernel in 1.3 %)
             }
             if (ordered && SPS != 10 && 2u * sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
                 // Run-time sps with at least two lanes per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
@@ -2087,6 +2132,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     if (v_big & cand) {
                     } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
                     else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+                } else if (cand != 0 && (v_ok & phases) == phases) {
+                    chain_rows = cand;
                 }
             }
             if (ordered) {
@@ -2111,14 +2158,17 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
                         // (the window block is dead here except words 512..575, where the L2 touch of the next window may
                         // still be dropping its dwords: the staged variant uses the words behind them)
-                        if (DH_EXACT_STAGED || SPS != 10) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u);
+                        if (DH_EXACT_STAGED || SPS != 10) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, chain_rows);
                         else dh_exact_var_ring<NZ>(C, S, sps);
                         BS->n_exact_blocks++;
                         DH_BARRIER();
                     }
                     DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1); DH_LANE_ARRAY(uint32_t, iv_ok, 1);
                     DH_FOR_LANES_FRESH(lane) {
-                        if ((uint32_t) lane < sps) {
+                        if ((uint32_t) lane < sps && !((chain_rows >> (uint32_t) lane) & 1ull)) {
+                            S.variance[lane] = DH_DBL_MAX;               // ruled out by its interval: never the smallest
+                            if (BOUNDED && SPS != 10 && attempt == 0) { DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u; }
+                        } else if ((uint32_t) lane < sps) {
                             const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
                             float total = 0.0f;
 #pragma unroll 5

@@ -106,3 +106,42 @@ def test_non_finite_and_huge_samples(ctx, oracle):
     syms, blocks, ordered = _run(ctx, x, [n], rrc="none")
     _check(syms, ref, len(x))
     assert ordered[0] >= 1 and ordered[1] >= 1 and ordered[2] >= 1
+
+
+@pytest.mark.parametrize("rrc,sps", [("wide", 10), ("narrow", 20), ("narrow", 8)])
+def test_half_sample_offsets_go_through_the_candidate_rows(ctx, oracle, rrc, sps):
+    """A clean signal whose symbol instants fall half way between two samples: the two phases next to the optimum have
+    (nearly) the same variance, closer than the error-bounded ring can tell apart.  The estimate then names its candidates
+    and only those rows of the ring are recomputed with the reference's arithmetic before the in-order chain decides --
+    the dibits and every timing step must still be the reference's.  Slow drifts walk the grid across many such ties."""
+    from digiham_amd import _taps
+    rng = np.random.default_rng(5 + sps)
+    taps = _taps.narrow() if rrc == "narrow" else None
+    chans = []
+    for i in range(6):
+        dibits = rng.integers(0, 4, 1500 if sps == 10 else 3000)
+        fine = synth.shape(dibits, sps=2 * sps, taps=None if taps is None else np.repeat(taps, 2)[: 2 * len(taps) - 1] / 2.0)
+        x = fine[1::2] if i % 2 == 0 else fine[::2]
+        if i >= 4:                                                     # a resampled copy: the offset drifts through every phase
+            t = np.arange(len(x) - 2) * (1.0 + [2e-4, -3e-4][i - 4])
+            x = np.interp(t, np.arange(len(x)), x).astype(np.float32)
+        chans.append(synth.impair(x.astype(np.float32), 70 + i, snr_db=[None, None, 40, 40, None, 35][i], gain=[1, 0.3, 1, 2, 1, 1][i]))
+    n = min(len(c) for c in chans)
+    x = np.stack([c[:n] for c in chans]).astype(np.float32)
+    ref = oracle.chain(x, rrc=2 if rrc == "narrow" else 1, sps=sps, proto=0)
+    for chunks in ([n], [4096, 1001]):
+        eng = api.Engine(len(x), max(chunks), proto="none", ctx=ctx, rrc=rrc, sps=sps)
+        syms = [[] for _ in range(len(x))]
+        pos = i = 0
+        while pos < n:
+            c = min(chunks[i % len(chunks)], n - pos); i += 1
+            eng.push(np.ascontiguousarray(x[:, pos:pos + c])); pos += c
+            s_, sc = eng.symbols()
+            for b in range(len(x)):
+                syms[b].append(s_[b, :sc[b]].copy())
+        blocks, ordered = eng.timing_stats()
+        recomputed = eng.debug_header(18).astype(np.int64)
+        eng.close()
+        _check([np.concatenate(s_) for s_ in syms], ref, len(x))
+        need = {10: 3, 20: 1, 8: 20}[sps]                            # (sps 8: eight lanes per phase, short chains -- its estimate is rarely sure)
+        assert int(ordered.sum()) >= need and int(recomputed.sum()) >= need, (blocks, ordered, recomputed)
