@@ -44,7 +44,7 @@ static __device__ __forceinline__ int dh_fresh_lane_id_() { int l = (int) thread
 // GLOBAL memory, which makes the compiler wait (s_waitcnt vmcnt(0)) for every global load in flight -- the next window's
 // loads, requested a phase earlier precisely so that they can stay in flight through the phases that follow (round 3: the wait
 // sat in front of the slicing phase and cost 1 ms of a 6.8 ms step).  Where a body hands data to another one through global
-// memory the caller fences explicitly (k_chain: __threadfence() between slicer and decoder).
+// memory the caller fences explicitly (k_chain: __syncthreads() between slicer and decoder, workgroup scope).
 #define DH_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #define DH_BALLOT_ACC(mask, pred, lane) (mask) = __ballot((pred) ? 1 : 0)

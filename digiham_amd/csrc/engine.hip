@@ -71,7 +71,9 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
         DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
         dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, L);
     }
-    __threadfence();                        // this wave's symbol / count stores are read back by the decoder below
+    // This wavefront's symbol / count stores are read back by its own decoder half below: a WORKGROUP-scope fence (part of
+    // __syncthreads) orders them.  A device-scope __threadfence() here made every wavefront write back its XCD's L2 --
+    // 16 384 times per launch, 0.7 ms of a push of 4 752 samples (tools/push_size.py).
     __syncthreads();
 #if DH_PRIO_MODE >= 1 && DH_PRIO_MODE <= 5
     DH_SETPRIO(3);
