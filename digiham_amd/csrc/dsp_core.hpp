@@ -592,6 +592,9 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #endif
 #ifndef DH_PF_REG
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
+#ifndef DH_F16_EDGE_WINDOWS
+#define DH_F16_EDGE_WINDOWS 1                // split-f16 kernels: the first / last windows of a push take the split-f16 FIR too (0: the reference-order FIR, as before)
+#endif
 #endif
 // K = taps + 15 rounded up to whole MFMAs of 32: three for the wide filter (96), six for the narrow one (192; taps beyond the
 // response are zeros in the fragments, and the halves beyond the window are stored as zeros)
@@ -1536,6 +1539,34 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     static_assert(DH_PF_N == 5, "four full groups + a partial one");
                     if constexpr (LAST_LANES > 0) { if (in_last) dh_lds_store4_at<4 * GSTEP>(ldst, DH_LA(v, lane)[4]); }
                     dh_lds_stores_done();
+                }
+            }
+        } else if (MF16 && !use_exact && DH_F16_EDGE_WINDOWS) {
+            // The first window of a push (it starts in the carried tail) and the last ones (they end within DH_FTILE + NZ of
+            // the input buffer's end): gathered sample by sample, then the same two arrays of halves as everywhere else.  These
+            // runs used to go through the reference-order FIR -- one or two of every push, which is most of a push of a few
+            // thousand samples (tools/push_size.py).
+            const uint32_t have = dh_min<uint32_t>(DH_FTILE + NZ, nv - p);
+            DH_LANE_ARRAY(dh_f4, v, DH_PF_N);
+            DH_FOR_LANES_FRESH(lane) {
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    dh_f4 w;
+                    w.x = e + 0u < have ? dh_virtual_sample(tail, tc, in, p + e + 0u) : 0.0f;
+                    w.y = e + 1u < have ? dh_virtual_sample(tail, tc, in, p + e + 1u) : 0.0f;
+                    w.z = e + 2u < have ? dh_virtual_sample(tail, tc, in, p + e + 2u) : 0.0f;
+                    w.w = e + 3u < have ? dh_virtual_sample(tail, tc, in, p + e + 3u) : 0.0f;
+                    DH_LA(v, lane)[r] = w;
+                }
+            }
+            xmax_done = true;
+            if (stage_f16(v, have, e_run, k1, k2)) f16_staged = true;
+            else {
+                use_exact = true;
+                DH_FOR_LANES_FRESH(lane) {
+                    for (uint32_t e = lane; e < DH_FTILE + NZ; e += DH_WAVE)
+                        S.xf[DH_XP(e)] = p + e < nv ? dh_virtual_sample(tail, tc, in, p + e) : 0.0f;
                 }
             }
         } else if (p >= tc) {
