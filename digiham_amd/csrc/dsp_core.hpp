@@ -2078,8 +2078,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // (the candidates are not handed on here: one more live value costs the 81-tap kernels four scratch accesses in
                 // their hot loop, and they reach this point in 0.02 % of the blocks -- the 161-tap, sps-20 kernel in 1.3 %)
             }
-            if (ordered && SPS != 10 && 2u * sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
-                // Run-time sps with at least two lanes per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
+            if (ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
+                // (sps 33 .. 64, e.g. POCSAG's 40: one lane per phase, chains of 100 + 1 fused terms -- (1 + u)^102 - 1 < 6.1e-6, still
+                // inside the 8e-6 V' below; the float mean is then the reference's own chain, within 100.1 u A of the true one.  The
+                // in-order double chain cost that slicer a fifth of its time, every block.)
+                // Run-time sps with at least one lane per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
                 // per phase, lane g sps + i takes a contiguous piece of row i -- `seg` = 4 ceil(25 / G) ring entries, read 16
                 // bytes at a time -- and the partial sums meet in LDS.  The bound of the sps-10 estimate holds with 8e-6 V'
                 // for 4e-6 V' (chains of up to 52 fused terms + G partials); in the error-bounded kernels the ring holds
@@ -2154,7 +2157,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
 #endif
                 DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(v_above, DH_LA(iv_lo, lane)[0] > hmin, lane); }
-                const uint64_t phases = (1ull << sps) - 1ull;                    // sps <= 32 here
+                const uint64_t phases = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
                 const uint64_t cand = ~v_above & phases;                          // phases whose interval reaches below the smallest upper end
                 const bool one = cand != 0 && (cand & (cand - 1)) == 0;
                 if (one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand))) {
@@ -2179,7 +2182,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
                 // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
                 const bool approx_ring = BOUNDED && e_blk > 0.0f;
-                for (int attempt = (approx_ring && SPS != 10 && 2u * sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
+                for (int attempt = (approx_ring && SPS != 10 && sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
                     DH_BARRIER();
                     if (approx_ring && attempt == 1) {
                         DhExactCtx C;

@@ -145,3 +145,32 @@ def test_half_sample_offsets_go_through_the_candidate_rows(ctx, oracle, rrc, sps
         _check([np.concatenate(s_) for s_ in syms], ref, len(x))
         need = {10: 3, 20: 1, 8: 20}[sps]                            # (sps 8: eight lanes per phase, short chains -- its estimate is rarely sure)
         assert int(ordered.sum()) >= need and int(recomputed.sum()) >= need, (blocks, ordered, recomputed)
+
+
+@pytest.mark.parametrize("sps", [40, 33, 37, 24])
+def test_float_estimate_at_one_lane_per_phase(ctx, oracle, sps):
+    """sps 33 .. 40, the largest the engine takes (POCSAG's 40): the float estimate runs with one lane per phase and chains of a hundred terms.  Ordinary
+    FSK audio is decided by it; silence, a constant, and two phases carrying the same values in another order must be left to
+    the in-order chain -- and all of them give the reference's bits."""
+    rng = np.random.default_rng(sps)
+    nblk = 8
+    n = nblk * 100 * sps + 3 * sps
+    bits = rng.integers(0, 2, n // sps + 2)
+    x = np.zeros((6, n), np.float32)
+    x[0] = synth.impair(synth.fsk_shape(bits, sps=sps)[:n], 1, snr_db=15)
+    x[1] = synth.impair(synth.fsk_shape(bits, sps=sps)[:n], 2, snr_db=30, dc=0.1, delay=sps // 3)
+    x[2] = 0.25                                                       # a constant: every phase ties at rounding level
+    x[3, n // 2:] = synth.fsk_shape(bits, sps=sps)[:n - n // 2]       # silence, then signal
+    for b, (pa, pb) in ((4, (0, sps - 1)), (5, (3, sps // 2 + 1))):   # two quiet phases with the same multiset of values
+        for blk in range(nblk):
+            v = rng.normal(0, 0.3, (100, sps)).astype(np.float32)
+            lo = (rng.normal(0, 0.01, 100) + 0.2).astype(np.float32)
+            v[:, pa] = lo
+            v[:, pb] = rng.permutation(lo)
+            x[b, blk * 100 * sps:(blk + 1) * 100 * sps] = v.reshape(-1)
+    ref = oracle.chain(x, rrc=0, levels=2, sps=sps, proto=0)
+    for chunks in ([n], [7000, 1234]):
+        syms, blocks, ordered = _run(ctx, x, chunks, rrc="none", demod="fsk", sps=sps)
+        _check(syms, ref, len(x))
+        assert blocks[0] >= nblk - 1 and ordered[0] <= 1 and ordered[1] <= 1, (blocks, ordered)
+        assert ordered[2] == blocks[2] and ordered[4] >= 1 and ordered[5] >= 1, (blocks, ordered)
