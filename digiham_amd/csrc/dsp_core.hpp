@@ -490,6 +490,19 @@ inline void dh_fir_lane(const float* taps, double gain, double rgain, float inv_
 struct __attribute__((aligned(4))) dh_f4 { float x, y, z, w; };
 struct alignas(16) dh_f4a { float x, y, z, w; };     // 16-byte aligned: one ds_read_b128
 DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
+// the same for the one-touch input stream: DH_NT_INPUT=1 marks the loads non-temporal (A/B: see DESIGN.md section 5)
+#ifndef DH_NT_INPUT
+#define DH_NT_INPUT 0
+#endif
+#if DH_NT_INPUT && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+typedef float dh_f4nt __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ dh_f4 dh_load4_stream(const float* p) {
+    const dh_f4nt t = __builtin_nontemporal_load(reinterpret_cast<const dh_f4nt*>(p));
+    dh_f4 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v;
+}
+#else
+DH_HD dh_f4 dh_load4_stream(const float* p) { return dh_load4_unaligned(p); }
+#endif
 DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
 DH_HD void dh_store4_unaligned(float* q, const dh_f4& v) { __builtin_memcpy(q, &v, sizeof(v)); }   // global_store_dwordx4
 
@@ -1829,8 +1842,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const float* lsrc = src + 4u * (uint32_t) lane;
                 const bool in_last = (uint32_t) lane < LAST_LANES;
 #pragma unroll
-                for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(pfr, lane)[PF_REG ? r : 0] = dh_load4_unaligned(lsrc + 4 * DH_WAVE * r);
-                DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_unaligned(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+                for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(pfr, lane)[PF_REG ? r : 0] = dh_load4_stream(lsrc + 4 * DH_WAVE * r);
+                DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_stream(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
             }
         } else {
 #if DH_PF_L2
