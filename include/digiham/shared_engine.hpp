@@ -17,6 +17,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -74,6 +75,8 @@ namespace Digiham {
                 void deposit(int s, const void* data, size_t n) {
                     std::lock_guard<std::mutex> l(mutex);
                     Slot& sl = slots[s];
+                    if (n > chunk || sl.pending) throw std::runtime_error("Digiham::Amd::SharedEngine::deposit: more than one chunk, or a deposit still pending");
+                    if (n == 0) return;
                     const size_t w = stage == DECODER ? 1 : sizeof(float);
                     std::memcpy(staging.data() + (size_t) s * chunk * w, data, n * w);
                     sl.pending = (uint32_t) n;
@@ -100,7 +103,7 @@ namespace Digiham {
                     std::lock_guard<std::mutex> l(mutex);
                     check(dh_engine_set_slot_filter_channel(engine.get(), (uint32_t) s, filter), "dh_engine_set_slot_filter_channel");
                 }
-                bool wantEvents = false;                         // DECODER banks: fetch the event rows as well
+                std::atomic<bool> wantEvents { false };          // DECODER banks: fetch the event rows as well (set by any instance with a meta writer)
 
             private:
                 struct Slot { bool used = false, dirty = false; uint32_t pending = 0; std::vector<unsigned char> out; std::vector<dh_event> events; };
@@ -165,7 +168,7 @@ namespace Digiham {
                 std::vector<uint32_t> counts;
                 void* dSyms = nullptr; void* dCounts = nullptr;
                 unsigned int attached = 0, pendingCount = 0;
-                unsigned long ticks = 0;
+                std::atomic<unsigned long> ticks { 0 };      // (read by ticksTotal() without the bank's mutex)
         };
 
     }
