@@ -204,6 +204,58 @@ def cpu_baseline(x_host_fn, proto, budget_s=12.0):
                       % (chans, x.shape[1], proto, cores, dt)}
 
 
+def reference_fec_baseline(torch, ctx, seconds=1.5):
+    """The one piece of the reference that builds in this image -- its FEC sources, compiled in place into
+    oracle/_ref/libdigiham_ref_fec.so -- timed single-threaded on this box beside the product's batch entries on the same
+    blocks (inputs resident in HBM, outputs compared).  kind = "reference"."""
+    import numpy as np
+    from oracle import oracle as O
+    if O.ref() is None:
+        return {"error": "oracle/_ref/libdigiham_ref_fec.so not built on this box"}
+    rng = np.random.default_rng(5)
+    out = {"kind": "reference", "cores": 1, "what": "src/dmr_decoder/bptc_196_96.c and src/ysf_decoder/trellis.c of the reference, compiled in place "
+                                                    "(oracle/Makefile), one thread; gpu_* = dh_bptc_196_96 / dh_trellis on the same blocks"}
+    n = 200000
+    pay = rng.integers(0, 256, (n, 25)).astype(np.uint8)
+    pay[:, 24] &= 0xF0
+    t0 = time.perf_counter(); r_out, r_ok = O.bptc_196_96(pay[:20000], which="ref"); per = (time.perf_counter() - t0) / 20000
+    k = int(min(n, max(20000, seconds / per)))
+    t0 = time.perf_counter(); r_out, r_ok = O.bptc_196_96(pay[:k], which="ref"); dt = time.perf_counter() - t0
+    d_in = ctx.mem.from_numpy(pay[:k]); d_out = ctx.mem.zeros((k, 12), np.uint8); d_ok = ctx.mem.zeros((k,), np.uint8)
+
+    def launch():
+        rc = ctx.lib.dh_bptc_196_96(ctx.mem.ptr(d_in), ctx.mem.ptr(d_out), ctx.mem.ptr(d_ok), k, ctx.mem.stream())
+        assert rc == 0
+    launch(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        launch()
+    torch.cuda.synchronize(); gdt = (time.perf_counter() - t0) / 20
+    g_out, g_ok = ctx.mem.to_numpy(d_out), ctx.mem.to_numpy(d_ok)
+    good = r_ok.astype(bool)
+    out["bptc_196_96"] = {"blocks": k, "reference_blocks_per_s": k / dt, "gpu_blocks_per_s": k / gdt,
+                          "identical": bool((g_ok == r_ok).all() and (g_out[good] == r_out[good]).all())}
+    m = 100000
+    packed = rng.integers(0, 256, (m, 45)).astype(np.uint8)
+    t0 = time.perf_counter(); t_out, t_metric = O.trellis(packed[:10000], 180, which="ref"); per = (time.perf_counter() - t0) / 10000
+    k = int(min(m, max(10000, seconds / per)))
+    t0 = time.perf_counter(); t_out, t_metric = O.trellis(packed[:k], 180, which="ref"); dt = time.perf_counter() - t0
+    ob = (180 + 7) // 8
+    d_in = ctx.mem.from_numpy(packed[:k]); d_out = ctx.mem.zeros((k, ob), np.uint8); d_m = ctx.mem.zeros((k,), np.uint8)
+
+    def launch2():
+        rc = ctx.lib.dh_trellis(ctx.mem.ptr(d_in), 45, 180, ctx.mem.ptr(d_out), ob, ctx.mem.ptr(d_m), k, ctx.mem.stream())
+        assert rc == 0
+    launch2(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        launch2()
+    torch.cuda.synchronize(); gdt = (time.perf_counter() - t0) / 20
+    out["trellis_180"] = {"blocks": k, "reference_blocks_per_s": k / dt, "gpu_blocks_per_s": k / gdt,
+                          "identical": bool((ctx.mem.to_numpy(d_out) == t_out).all() and (ctx.mem.to_numpy(d_m) == t_metric).all())}
+    return out
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: become N ranks, or fail loudly."""
     import torch
@@ -549,6 +601,10 @@ def main():
                 cb["gpu_outputs_sha256"] = outputs_sha(gs, gsc, gf, gfc)
                 cb["gpu_matches_baseline_outputs"] = cb["gpu_outputs_sha256"] == cb["outputs_sha256"]
                 assert cb["gpu_matches_baseline_outputs"], "GPU output differs from the oracle run of the CPU baseline"
+            try:
+                cb["reference_fec"] = reference_fec_baseline(torch, ctx)
+            except Exception as e:
+                cb["reference_fec"] = {"error": repr(e)}
     job.close()
     del job
     if rank == 0:
