@@ -24,10 +24,12 @@
 #define DH_LANE_VALUE(type, name) type name
 #define DH_LV(name, lane) name
 #define DH_LV_READ(name, k) ((uint32_t) __builtin_amdgcn_readlane((int) (name), (int) (k)))
+#define DH_LV_DOWN(name, lane, d) ((uint32_t) __shfl_down((int) (name), (unsigned) (d), DH_WAVE))      // the value of lane + d
 #else
 #define DH_LANE_VALUE(type, name) type name[DH_WAVE]
 #define DH_LV(name, lane) name[lane]
 #define DH_LV_READ(name, k) ((uint32_t) name[k])
+#define DH_LV_DOWN(name, lane, d) ((uint32_t) name[((lane) + (d)) < DH_WAVE ? (lane) + (d) : (lane)])
 #endif
 
 #define DH_SYM_CARRY_MAX 512          // symbols a decoder may leave unread between pushes (<= 480)
@@ -511,11 +513,16 @@ DH_HD void dh_stage_decoder_lds(const DhDecParams& P, DhDecShared& S, const uint
 DH_HD const DhFecTables& dh_lds_tables(const DhDecShared& S) { return *reinterpret_cast<const DhFecTables*>(S.fec_small); }
 
 // BPTC(196,96) of a data burst, columns on lanes (bptc_196_96.c:5-59 on the dibits of dmr_phase.cpp:256-269)
-DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, uint8_t* out12) {
-    // 15 columns on 15 lanes: gather through the interleave from the bit planes (reading the symbol window directly
-    // instead measured slower: 1.97 against 1.77 ms), Hamming(13,9); the corrected column words stay in registers
+#ifndef DH_BPTC_MODE
+#define DH_BPTC_MODE 2       // 0: 15 lanes gather 13 bits each from the bit planes; 1: four groups of 15 lanes, 4 bits each, from the planes; 2: the same from the symbol window (no planes)
+#endif
+DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSymView& syms, uint32_t pos0, uint8_t* out12) {
     uint64_t okmask = 0;
     DH_LANE_VALUE(uint32_t, colw);
+#if DH_BPTC_MODE == 0
+    // 15 columns on 15 lanes: gather through the interleave from the bit planes, Hamming(13,9); the corrected column words
+    // stay in registers
+    (void) syms; (void) pos0;
     DH_FOR_LANES(lane) {
         bool ok = true;
         uint32_t w = 0;
@@ -533,6 +540,38 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, uint8_t* ou
         DH_BALLOT_ACC(okmask, ok, lane);
         DH_LV(colw, lane) = w;
     }
+#else
+    // The 13 x 15 gather costs one instruction per bit whatever the number of lanes that execute it: four groups of 15 lanes
+    // take rows k = g, g + 4, g + 8 (and 12) of their column -- four bits per lane instead of thirteen -- and the partial words
+    // meet in the lanes of the first group.  Source bit of (row k, column c): r = ((15 k + c + 1) 181) mod 196 (bptc_196_96.c:
+    // 8-16), which advances by 4 * 15 * 181 mod 196 = 80 from one of a lane's rows to the next.  With idle bursts on a quiet
+    // slot, a BPTC block per burst, this decoder was a tenth of the whole chain kernel's instructions.
+    DH_LANE_VALUE(uint32_t, part);
+    DH_FOR_LANES(lane) {
+        const uint32_t g = (uint32_t) lane >> 4, cidx = (uint32_t) lane & 15u;
+        uint32_t r = ((15u * g + cidx + 1u) * 181u) % 196u;
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) {
+            const uint32_t k = g + 4u * q;
+            const uint32_t d = r >> 1;
+            const uint32_t spos = d < 49u ? 12u + d : 46u + d;                      // dh_dmr_info_dibit_pos
+            uint32_t bit;
+            if (DH_BPTC_MODE == 2) bit = (dh_view_at(syms, pos0 + spos) >> (1u - (r & 1u))) & 1u;    // even bit of a dibit = its bit 1
+            else { const uint64_t* plane = (r & 1u) ? p.l : p.h; bit = (uint32_t) ((plane[spos >> 6] >> (spos & 63u)) & 1ull); }
+            if (cidx < 15u && k < 13u) w |= bit << (12u - k);
+            r += 80u; if (r >= 196u) r -= 196u;
+        }
+        DH_LV(part, lane) = w;
+    }
+    DH_FOR_LANES(lane) {
+        uint32_t w = DH_LV(part, lane) | DH_LV_DOWN(part, lane, 16) | DH_LV_DOWN(part, lane, 32) | DH_LV_DOWN(part, lane, 48);
+        bool ok = true;
+        if (lane < 15) ok = dh_block_decode(T.h139, T.lut_h139, w);
+        DH_BALLOT_ACC(okmask, ok, lane);
+        DH_LV(colw, lane) = w;
+    }
+#endif
     if (okmask != ~0ull) return false;
     // the 9 data rows: row i is bit 12-i of every column word -- one vote per row (column k in bit k, the row word wants
     // it in bit 14-k); then the rows on 9 lanes for Hamming(15,11)
@@ -649,11 +688,11 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
 #else
             if (R.want_bptc) {
 #endif
-                dh_load_planes(syms, pos, total, pl, 3);
+                if (DH_BPTC_MODE != 2) dh_load_planes(syms, pos, total, pl, 3);
                 uint8_t lc[12];
                 for (int i = 0; i < 12; i++) lc[i] = 0;
                 const int slot = (int) s[DS_SLOT];
-                if (dh_dmr_bptc_wave(dh_lds_tables(S), pl, lc)) {
+                if (dh_dmr_bptc_wave(dh_lds_tables(S), pl, syms, pos, lc)) {
                     dh_emit(c, DH_EV_DMR_BPTC, (uint8_t) slot, R.data_type, lc, 12);
                     if (R.data_type == 1) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 0, lc, 9);
                     else if (R.data_type == 2 || R.data_type == 9) dh_emit(c, DH_EV_DMR_SOFT_RESET, (uint8_t) slot, R.data_type, nullptr, 0);
