@@ -187,6 +187,9 @@ struct DhDecCtx {
 };
 
 DH_HD void dh_emit(DhDecCtx& c, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, int len) {
+#ifdef DH_SKIP_EVENTS                       // diagnostic builds (no events come out): what does writing them cost?
+    if (type != 255) return;
+#endif
     if (c.ev == nullptr) return;
     if (c.nev >= c.P->ev_cap) { c.overflow = true; return; }
     if (c.writer) {
@@ -293,7 +296,7 @@ DH_HD bool dh_dmr_embedded_lc(const DhFecTables& T, const uint32_t* data, uint32
                 const uint32_t x = (data[j] >> (7 - lane)) & 0x01010101u;
                 row |= ((x * 0x10204080u) >> 28) << (12 - 4 * j);
             }
-            if (lane < 7) ok = dh_block_decode(T.h1611, T.lut_h1611, row);
+            if (lane < 7) ok = dh_block_decode_rows<5>(T.h1611, T.lut_h1611, row);
             S.colword[lane] = row;
         }
         DH_BALLOT_ACC(okmask, ok, lane);
@@ -535,7 +538,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
                 const uint64_t* plane = (r & 1) ? p.l : p.h;        // even bit of a dibit = its bit1
                 w |= (uint32_t) ((plane[pos >> 6] >> (pos & 63)) & 1ull) << (12 - k);
             }
-            ok = dh_block_decode(T.h139, T.lut_h139, w);
+            ok = dh_block_decode_rows<4>(T.h139, T.lut_h139, w);
         }
         DH_BALLOT_ACC(okmask, ok, lane);
         DH_LV(colw, lane) = w;
@@ -567,7 +570,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
     DH_FOR_LANES(lane) {
         uint32_t w = DH_LV(part, lane) | DH_LV_DOWN(part, lane, 16) | DH_LV_DOWN(part, lane, 32) | DH_LV_DOWN(part, lane, 48);
         bool ok = true;
-        if (lane < 15) ok = dh_block_decode(T.h139, T.lut_h139, w);
+        if (lane < 15) ok = dh_block_decode_rows<4>(T.h139, T.lut_h139, w);
         DH_BALLOT_ACC(okmask, ok, lane);
         DH_LV(colw, lane) = w;
     }
@@ -588,7 +591,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
         uint32_t w = 0;
         if (lane < 9) {
             for (int i = 0; i < 9; i++) if (lane == i) w = rows[i];
-            ok = dh_block_decode(T.h1511, T.lut_h1511, w);
+            ok = dh_block_decode_rows<4>(T.h1511, T.lut_h1511, w);
         }
         DH_BALLOT_ACC(rowok, ok, lane);
         DH_LV(roww, lane) = w;

@@ -47,7 +47,7 @@ static __device__ __forceinline__ int dh_fresh_lane_id_() { int l = (int) thread
 // memory the caller fences explicitly (k_chain: __syncthreads() between slicer and decoder, workgroup scope).
 #define DH_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
-#define DH_BALLOT_ACC(mask, pred, lane) (mask) = __ballot((pred) ? 1 : 0)
+#define DH_BALLOT_ACC(mask, pred, lane) (mask) = __builtin_amdgcn_ballot_w64((bool) (pred))      /* (v_cmp straight into the scalar pair; __ballot((pred) ? 1 : 0) left a v_cndmask + v_cmp behind every vote) */
 #define DH_IS_LANE0(lane) ((lane) == 0)
 #else
 #define DH_FOR_LANES(lane) for (int lane = 0; lane < DH_WAVE; ++lane)

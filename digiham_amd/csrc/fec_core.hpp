@@ -48,6 +48,23 @@ DH_HD bool dh_block_decode(const DhCode& c, const LutT* lut, uint32_t& word) {
     return true;
 }
 
+// the same with the number of parity checks known at compile time: straight-line code (the run-time loop above compiles to an
+// unrolled-by-eight loop plus a remainder loop, with the row count fetched from the table first)
+template <int R, typename LutT>
+DH_HD bool dh_block_decode_rows(const DhCode& c, const LutT* lut, uint32_t& word) {
+    uint32_t h[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) h[i] = c.h[i];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < R; i++) s = (s << 1) | (uint32_t) (dh_popc32(word & h[i]) & 1);
+    if (s == 0) return true;
+    const uint32_t p = lut[s];
+    if (p == 0) return false;
+    word ^= p;
+    return true;
+}
+
 // Same decode for a wave-uniform word with the wavefront's help: lane i evaluates parity-check row i, a vote
 // collects the syndrome (first row in the MSB), the pattern lookup is one load.  R = n - k.
 template <int R, typename LutT>
