@@ -214,7 +214,9 @@ DH_HD void dh_dmr_enter_frame_phase(DhState& s) {
 }
 
 // ------------------------------------------------------------------------------------------
+#ifndef DH_SYMWIN
 #define DH_SYMWIN 1024               // fresh symbols staged in LDS per refill (a DMR burst is 144, a YSF frame 480)
+#endif
 struct DhDecShared {
     uint8_t  carry[DH_SYM_CARRY_MAX];     // symbols carried from the previous push
     uint8_t  symwin[DH_SYMWIN];           // window of this push's symbols (refilled with 16-byte-per-lane loads)
