@@ -620,7 +620,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
 #define DH_DCLK(i) ((void) 0)
 #endif
 
-DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
 #ifdef DH_PHASE_CLOCKS
     DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
 #endif
@@ -632,7 +632,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.st = &s;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
-    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.nout = append ? P.out_count[ch] : 0u; c.nev = append && P.ev_count ? P.ev_count[ch] : 0u; c.overflow = false;      // (append: the second part of a split push, k_chain)
     c.consumed = s[DS_CONSUMED];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     c.writer = threadIdx.x == 0;
@@ -640,8 +640,8 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.writer = true;
 #endif
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
-    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride + sym_base;
+    syms.nfresh = P.sym_count[ch] - sym_base; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0;
@@ -789,7 +789,164 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
     DH_BARRIER();
 }
 
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#ifndef DH_VIT_DPP
+#define DH_VIT_DPP 0                 // 1: the in-place forward pass below (measured: no gain alone, a loss inside the chain kernels -- DESIGN.md section 5)
+#endif
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_VIT_DPP
+// gfx950 forward pass, in-place form.  The 16 path metrics of a codeword never leave their lanes: the butterfly that takes
+// the states (2j, 2j+1) to (j, j+8) writes the new metrics over the old ones, so after t steps lane L (of the row of 16)
+// holds state ror4^t(L), and the two predecessors of the state a lane computes in step t are its own metric and the one of
+// lane L ^ (1 << (t & 3)): one DPP move inside the row (quad_perm / row_shr+row_shl / row_ror) instead of two ds_bpermute
+// round trips per step.  MEASURED AND NOT USED: the forward pass is 1.1 ms of the 7.7 ms YSF chain and 0.9 ms of the 11.1 ms
+// NXDN chain (-DDH_VIT_SKIP=0 builds), but it is bound by vector issue, not by LDS latency: this form has ten vector
+// instructions per step where the ds_bpermute form has six (the LDS pipe did the exchange for free), and the YSF decoder
+// alone stays at 3.15 ms, the YSF chain goes 7.7 -> 8.3 ms, NXDN 11.1 -> 11.5 (profiles/r03_d_ab_logs.txt).  Same decisions as the reference's decoder
+// (src/ysf_decoder/trellis.c:32-109, src/nxdn_decoder/trellis.cpp:35-60): uint8 metrics that wrap, the k = 0 predecessor
+// wins ties.  Which of the two is "own" depends on bit (t & 3) of the lane number (HI lanes hold the odd predecessor), so
+//   take_other = other < own + hi        (one v_subb_co_u32: the borrow, with the HI lanes as carry-in)
+//   decision k = take_other ^ hi         (a scalar XOR of the vote with a constant mask)
+// Branch metrics: the expected dibits of a lane's two transitions in the four rotation phases sit in the four bytes of
+// two registers; XOR with the input word (one dibit per byte, four steps) and a 2-bit population count per byte give the
+// metrics of four steps at once.  Decisions are stored per LANE (bit 16 g + L of word t), and the trace-back walks lanes:
+// the predecessor of lane L in step t is L with bit (t & 3) replaced by the decision, and the decoded bit of step t is the
+// bit that gets replaced -- two dependent operations per step where the state-indexed form needed four.
+__device__ __forceinline__ uint32_t dh_ror4(uint32_t x, uint32_t r) { r &= 3u; return ((x >> r) | (x << (4u - r))) & 15u; }
+template <int Q> __device__ __forceinline__ uint32_t dh_row_xor_lane(uint32_t v) {
+    const int x = (int) v;
+    if constexpr (Q == 0) return (uint32_t) __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);            // quad_perm:[1,0,3,2]
+    else if constexpr (Q == 1) return (uint32_t) __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);       // quad_perm:[2,3,0,1]
+    else if constexpr (Q == 2) {
+        const int up = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xA, false);                                // row_shr:4 into lanes 4-7, 12-15
+        return (uint32_t) __builtin_amdgcn_update_dpp(up, x, 0x104, 0xF, 0x5, false);                            // row_shl:4 into lanes 0-3, 8-11
+    } else return (uint32_t) __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);                          // row_ror:8
+}
+// the lanes whose number has bit Q set
+template <int Q> __device__ __forceinline__ constexpr uint64_t dh_hi_lanes() {
+    return Q == 0 ? 0xAAAAAAAAAAAAAAAAull : Q == 1 ? 0xCCCCCCCCCCCCCCCCull : Q == 2 ? 0xF0F0F0F0F0F0F0F0ull : 0xFF00FF00FF00FF00ull;
+}
+// one trellis step: C = step & 63 = the lane of the decision registers that takes this step's vote, Q = C & 3 = which lane
+// bit pairs the butterfly; GENERIC: some lanes may be held (`active`, ragged codewords) or restricted to their k = 0 predecessor
+// (`allow`, the first four steps of the NXDN flavour)
+template <int C, bool GENERIC>
+__device__ __forceinline__ void dh_vit_step(uint32_t& m, uint32_t pc_own, uint32_t pc_oth, uint32_t& dlo, uint32_t& dhi,
+                                            uint64_t allow, uint64_t active) {
+    constexpr int Q = C & 3;
+    const uint32_t oth = dh_row_xor_lane<Q>(m);
+    const uint32_t c_own = (m + ((pc_own >> (8 * Q)) & 0xFFu)) & 0xFFu;
+    const uint32_t c_oth = (oth + ((pc_oth >> (8 * Q)) & 0xFFu)) & 0xFFu;
+    uint64_t take_oth; uint32_t diff;
+    const uint64_t hi = dh_hi_lanes<Q>();
+    asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(diff), "=s"(take_oth) : "v"(c_oth), "v"(c_own), "s"(hi));
+    uint64_t dec = take_oth ^ hi;                                                   // k = 1 predecessor taken
+    if (GENERIC) {
+        dec &= allow & active;
+        const uint64_t sel_oth = dec ^ hi;
+        uint32_t nm;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nm) : "v"(c_own), "v"(c_oth), "s"(sel_oth));
+        { uint32_t keep_ = m; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(m) : "v"(keep_), "v"(nm), "s"(active)); }
+    } else {
+        m = c_oth < c_own ? c_oth : c_own;
+    }
+    // (v_writelane takes one scalar register and an inline constant as the lane: C is a template parameter for that)
+    asm("v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(dlo), "+v"(dhi) : "s"((uint32_t) dec), "s"((uint32_t) (dec >> 32)), "n"(C));
+}
+template <bool NXDN = false, bool RAGGED = NXDN>
+__device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
+    const int lane = (int) threadIdx.x, g = lane >> 4;
+    const uint32_t L = (uint32_t) lane & 15u;
+    int steps = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) steps = sizes[q] > steps ? sizes[q] : steps;
+#ifdef DH_VIT_SKIP
+    steps = DH_VIT_SKIP;            // timing experiment: forward pass cut short (results are wrong)
+#endif
+    const int mysize = g == 0 ? sizes[0] : g == 1 ? sizes[1] : g == 2 ? sizes[2] : sizes[3];   // static indices only
+    // expected dibits of this lane's two transitions in the four phases, phase b in byte b
+    uint32_t t_own = 0, t_oth = 0;
+    uint64_t allow4[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) {
+        const uint32_t sig = dh_ror4(L, b), n = dh_ror4(L, b + 1u), outbit = n >> 3;       // own predecessor, new state
+        t_own |= dh_trellis_out(sig, outbit) << (8 * b);
+        t_oth |= dh_trellis_out(sig ^ 1u, outbit) << (8 * b);
+        // NXDN: in the first four steps a state that overlaps the shifting `blocked` mask only looks at its k = 0 predecessor
+        allow4[b] = NXDN ? __builtin_amdgcn_ballot_w64((n & ((0xFu << b) & 0xFu)) == 0u) : ~0ull;
+    }
+    const uint32_t* inw = S.vit_in[g];                  // one dibit per byte, four steps per word
+    uint32_t m = 0;
+    for (int blk = 0; blk * 64 < steps; blk++) {
+        // decisions of 64 steps collect in one register pair, step (64 blk + c) in lane c, written with v_writelane
+        uint32_t dlo = 0, dhi = 0;
+#define DH_VIT_WORD(WQ) \
+        if (blk * 64 + (WQ) * 4 < steps) { \
+            const uint32_t w = inw[blk * 16 + (WQ)]; \
+            const uint32_t x_own = w ^ t_own, x_oth = w ^ t_oth; \
+            const uint32_t pc_own = (x_own & 0x01010101u) + ((x_own >> 1) & 0x01010101u); \
+            const uint32_t pc_oth = (x_oth & 0x01010101u) + ((x_oth >> 1) & 0x01010101u); \
+            /* (codeword lengths are multiples of four on every ragged path: `active` is taken once per word) */ \
+            const uint64_t active = RAGGED ? __builtin_amdgcn_ballot_w64(blk * 64 + (WQ) * 4 < mysize) : ~0ull; \
+            const int pos0 = blk * 64 + (WQ) * 4; \
+            if (RAGGED || (NXDN && (WQ) == 0 && blk == 0)) { \
+                const bool first = NXDN && (WQ) == 0 && blk == 0; \
+                if (pos0 + 0 < steps) dh_vit_step<(WQ) * 4 + 0, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[0] : ~0ull, active); \
+                if (pos0 + 1 < steps) dh_vit_step<(WQ) * 4 + 1, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[1] : ~0ull, active); \
+                if (pos0 + 2 < steps) dh_vit_step<(WQ) * 4 + 2, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[2] : ~0ull, active); \
+                if (pos0 + 3 < steps) dh_vit_step<(WQ) * 4 + 3, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[3] : ~0ull, active); \
+            } else { \
+                if (pos0 + 0 < steps) dh_vit_step<(WQ) * 4 + 0, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
+                if (pos0 + 1 < steps) dh_vit_step<(WQ) * 4 + 1, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
+                if (pos0 + 2 < steps) dh_vit_step<(WQ) * 4 + 2, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
+                if (pos0 + 3 < steps) dh_vit_step<(WQ) * 4 + 3, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
+            } \
+        }
+        DH_VIT_WORD(0) DH_VIT_WORD(1) DH_VIT_WORD(2) DH_VIT_WORD(3) DH_VIT_WORD(4) DH_VIT_WORD(5) DH_VIT_WORD(6) DH_VIT_WORD(7)
+        DH_VIT_WORD(8) DH_VIT_WORD(9) DH_VIT_WORD(10) DH_VIT_WORD(11) DH_VIT_WORD(12) DH_VIT_WORD(13) DH_VIT_WORD(14) DH_VIT_WORD(15)
+#undef DH_VIT_WORD
+        S.vit_dec[blk * 64 + lane] = (uint64_t) dhi << 32 | dlo;
+    }
+    S.vit_metric[0][lane] = m;
+    __syncthreads();
+    // best end state of every codeword (lowest STATE index among the minimum metric, trellis.c:94-98; state i sits in lane
+    // rol4^size(i)) and the trace-back over lanes
+    if ((lane & 15) == 0) {
+        const int size = mysize;
+        if (size > 0) {
+            const uint32_t r = (uint32_t) size & 3u;
+            uint32_t bestl = 0, bm = S.vit_metric[0][g * 16];
+            for (uint32_t i = 1; i < 16; i++) {
+                const uint32_t li = dh_ror4(i, 4u - r);
+                const uint32_t mi = S.vit_metric[0][g * 16 + li];
+                if (mi < bm) { bm = mi; bestl = li; }
+            }
+            S.vit_best_metric[g] = (uint8_t) bm;
+            const int nbytes = (size + 7) >> 3;
+            for (int b = nbytes; b < 24; b++) S.vit_out[g][b] = 0;
+            uint32_t Lc = bestl;
+            const uint16_t* dec16 = reinterpret_cast<const uint16_t*>(S.vit_dec) + g;
+            for (int b = nbytes - 1; b >= 0; b--) {
+                uint32_t d[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) d[j] = (uint32_t) dec16[4 * ((b * 8 + j) < 192 ? (b * 8 + j) : 191)] << (j & 3);
+                // steps 8b+7 .. 8b+4, then 8b+3 .. 8b: the four decoded bits of a group are the four bits of the lane number
+                // the group starts from (bit j & 3 belongs to step j and is replaced by that step's decision)
+                const int va = size - (b * 8 + 4), vb = size - b * 8;
+                const uint32_t mask_a = va >= 4 ? 15u : va <= 0 ? 0u : (1u << va) - 1u, mask_b = vb >= 4 ? 15u : (1u << vb) - 1u;
+                const uint32_t la = Lc & mask_a;
+#pragma unroll
+                for (int j = 7; j >= 4; j--)
+                    if (b * 8 + j < size) Lc = (Lc & ~(1u << (j & 3))) | ((d[j] >> Lc) & (1u << (j & 3)));
+                const uint32_t lb = Lc & mask_b;
+#pragma unroll
+                for (int j = 3; j >= 0; j--)
+                    if (b * 8 + j < size) Lc = (Lc & ~(1u << (j & 3))) | ((d[j] >> Lc) & (1u << (j & 3)));
+                // byte bit 7 - j = decoded bit of step 8b + j: the bit reversal of (la << 4 | lb) ... la bit 3 = step 7 -> bit 0
+                S.vit_out[g][b] = (uint8_t) (dh_brev32((la << 4) | lb) >> 24);
+            }
+        }
+    }
+    DH_BARRIER();
+}
+#elif DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // gfx950 forward pass: path metrics stay in registers, the two predecessor metrics come through ds_bpermute
 // (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.  Per step and lane: two byte
 // adds (SDWA: uint8 wrap for free, like the reference's uint8 metrics), a compare, a min, two v_writelane; the branch
@@ -971,7 +1128,7 @@ DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.c
 }
 
 // One YSF channel, one push.
-DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
 #ifdef DH_PHASE_CLOCKS
     DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
 #endif
@@ -982,7 +1139,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
-    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.nout = append ? P.out_count[ch] : 0u; c.nev = append && P.ev_count ? P.ev_count[ch] : 0u; c.overflow = false;      // (append: the second part of a split push, k_chain)
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     c.writer = threadIdx.x == 0;
 #else
@@ -992,8 +1149,8 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.st = &s;
     c.consumed = s[DS_CONSUMED];
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
-    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride + sym_base;
+    syms.nfresh = P.sym_count[ch] - sym_base; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0, phase = s[DS_PHASE];
@@ -1271,7 +1428,7 @@ DH_HD bool dh_nxdn_crc_ok(const uint8_t* in, int nbits, int width, uint32_t init
 }
 
 // One NXDN channel, one push.
-DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
     DhDecCtx c;
     c.P = &P; c.T = &dh_lds_tables(S);
     uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
@@ -1279,7 +1436,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.st = &s;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
-    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.nout = append ? P.out_count[ch] : 0u; c.nev = append && P.ev_count ? P.ev_count[ch] : 0u; c.overflow = false;      // (append: the second part of a split push, k_chain)
     c.consumed = s[DS_CONSUMED];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     c.writer = threadIdx.x == 0;
@@ -1287,8 +1444,8 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.writer = true;
 #endif
     uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
-    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride + sym_base;
+    syms.nfresh = P.sym_count[ch] - sym_base; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0, phase = s[DS_PHASE];
@@ -1895,7 +2052,7 @@ DH_HD bool dh_dstar_is_terminator(uint32_t d0, uint32_t d1) {
 
 #define DH_DSTAR_BATCH 5          // data frames handled per round on the fast path (5 x 96 + 24 bits <= 512)
 
-DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
+DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
 #ifdef DH_PHASE_CLOCKS
     DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
 #endif
@@ -1907,7 +2064,7 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     c.st = &s;
     c.out = P.out + (size_t) ch * P.out_stride;
     c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
-    c.nout = 0; c.nev = 0; c.overflow = false;
+    c.nout = append ? P.out_count[ch] : 0u; c.nev = append && P.ev_count ? P.ev_count[ch] : 0u; c.overflow = false;      // (append: the second part of a split push, k_chain)
     c.consumed = s[DS_CONSUMED];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     c.writer = threadIdx.x == 0;
@@ -1918,8 +2075,8 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S) {
     uint8_t* const lds_carry = reinterpret_cast<uint8_t*>(S.vit_dec);          // 1536 bytes, no K=5 Viterbi in this protocol
     static_assert(sizeof(S.vit_dec) >= DH_DSTAR_CARRY_MAX, "D-Star carry");
     DhDstarScratch& X = *reinterpret_cast<DhDstarScratch*>(S.carry);
-    DhSymView syms; syms.carry = lds_carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride;
-    syms.nfresh = P.sym_count[ch]; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    DhSymView syms; syms.carry = lds_carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride + sym_base;
+    syms.nfresh = P.sym_count[ch] - sym_base; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
     const uint32_t total = syms.nc + syms.nfresh;
     DH_FOR_LANES(lane) { for (uint32_t j = (uint32_t) lane; j < syms.nc; j += DH_WAVE) lds_carry[j] = carry_buf[j]; }
     DH_BARRIER();

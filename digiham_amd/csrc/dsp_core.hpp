@@ -50,6 +50,7 @@ enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED
        DH_ST_BLOCK_FLAGS = 11,       // bit 0: the current block's start is known, bit 1: the previous block's
        DH_ST_E_CUR = 12, DH_ST_E_PREV = 13, DH_ST_E_COUNT = 14, DH_ST_E_BLOCK = 15,          // error radii of the ring entries (floats), symbols in the current bucket
        DH_ST_UNCERTAIN = 16, DH_ST_EXACT_RUNS = 17, DH_ST_EXACT_BLOCKS = 18,                    // statistics: symbols / runs / timing blocks decided by exact arithmetic
+       DH_ST_PART = 19,              // tail split (k_chain): epoch of the last push whose first part has been written back | XCC id << 28
        DH_ST_DIAG = 20 };            // 20..31: diagnostic builds (phase clocks 20..27, wave timeline 28..31)
 #define DH_ST_VOL DH_STATE_HDR
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
@@ -75,6 +76,10 @@ struct DhDspParams {
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
     const uint32_t* tapfrag;                           // split-f16 FIR: the per-lane tap fragments (DhF16Taps::frag), or null
     float err_coef_f16;                                // its error radius per unit of max |x| (dh_f16_error_coefficient)
+    // tail split (engine.hip, HipBackend::go_chain): the launch has two or three workgroups per channel; workgroup
+    // k * split_pad + channel takes the samples [0, split_n0), [split_n0, split_n1 or the end), [split_n1, end) of the
+    // channel's row for k = 0, 1, 2.  split_n0 = 0: one workgroup per channel; split_n1 = 0: two.
+    uint32_t split_n0, split_n1, split_pad, part_epoch;
 };
 
 DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }
@@ -1286,8 +1291,11 @@ DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps
 // once (host harness; the DH_FOR_LANES loops then iterate the lanes).
 // SPS = 10 bakes the DMR / YSF samples-per-symbol (and its evaluation window 3..6) into the code so the
 // per-symbol loops unroll; SPS = 0 takes them from the parameters.
+// part_lo / part_hi / sym_base: the tail split of the chain kernels -- this call takes the samples [part_lo, part_hi) of the
+// push and appends its symbols behind the sym_base symbols the earlier parts produced (a part is a push: results do not
+// depend on where pushes end).
 template <int NZ, bool FAST, int SPS>
-DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S) {
+DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu, uint32_t sym_base = 0) {
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
@@ -1301,7 +1309,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #ifdef DH_SAME_ROW                          // diagnostic builds: every channel reads the rows of the first 64 (the input then lives in L2: what does HBM cost?)
     const float* in = P.in + (size_t) (ch & 63u) * P.in_stride;
 #else
-    const float* in = P.in + (size_t) ch * P.in_stride;
+    const float* in = P.in + (size_t) ch * P.in_stride + part_lo;
 #endif
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
     const float* in_end = P.in + (size_t) (P.n_channels - 1u) * P.in_stride + P.n;    // end of the readable input
@@ -1317,7 +1325,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     uint32_t k0 = sth[DH_ST_K];
     int32_t off = (int32_t) sth[DH_ST_OFF];
     const uint32_t tc = sth[DH_ST_TAIL];
-    const uint32_t n_new = P.n_per ? dh_min<uint32_t>(dh_uniform(P.n_per[ch]), P.n) : P.n;
+    const uint32_t n_push = P.n_per ? dh_min<uint32_t>(dh_uniform(P.n_per[ch]), P.n) : P.n;
+    const uint32_t n_new = dh_min<uint32_t>(n_push, part_hi) > part_lo ? dh_min<uint32_t>(n_push, part_hi) - part_lo : 0u;
     const uint32_t nv = tc + n_new;                     // length of the virtual input stream
     const uint32_t nf = nv >= NZ ? nv - NZ : 0u;        // filtered samples available this push
     DH_FOR_LANES(lane) {
@@ -1430,7 +1439,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         return true;
     };
-    uint32_t nsym = 0;
+    uint32_t nsym = sym_base;                           // symbols of this push so far (a later part of a split push starts behind the earlier ones')
     bool overflow = false;
     const uint32_t max_run = (DH_FTILE - 2) / sps;      // symbols whose windows fit one FIR pass
 
@@ -2373,7 +2382,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             sth[DH_ST_K] = k0;
             sth[DH_ST_OFF] = (uint32_t) off;
             sth[DH_ST_TAIL] = new_tc < tail_max ? new_tc : tail_max;
-            sth[DH_ST_NSYM] += nsym;
+            // (sym_base is not kept through the loop: a later part finds it where it read it, until the store below)
+            sth[DH_ST_NSYM] += nsym - (part_lo ? P.sym_count[ch] : 0u);
             if (BOUNDED) {
                 sth[DH_ST_P0] = keep;
                 sth[DH_ST_CUR_START] = (uint32_t) (BS->cur_start - (int32_t) base); sth[DH_ST_CUR_OFF] = (uint32_t) BS->cur_off;

@@ -29,6 +29,7 @@ int hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return -1;
 }
+#define DH_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))        // an opaque copy: the compiler must not tie it to an earlier computation of the same value
 #define HIP_TRY(expr) do { if (hip_fail((expr), #expr)) return DH_EDEVICE; } while (0)
 
 #ifndef DH_TILE_LB
@@ -42,6 +43,18 @@ int hip_fail(hipError_t e, const char* what) {
 #endif
 #ifndef DH_SPLIT_MIN_CHANNELS
 #define DH_SPLIT_MIN_CHANNELS 8192   // DH_FLAG_OVERLAP_PUSHES takes effect for engines at least this large (HipBackend::go_chain)
+#endif
+#ifndef DH_TAIL_SPLIT_PCT
+#define DH_TAIL_SPLIT_PCT 80
+#endif
+#ifndef DH_TAIL_SPLIT_PCT2
+#define DH_TAIL_SPLIT_PCT2 0       // a third workgroup per channel from this percentage on (0 = two parts)
+#endif
+#ifndef DH_TAIL_SPLIT_MIN_CHANNELS
+#define DH_TAIL_SPLIT_MIN_CHANNELS 8192     // the tail split of the chain kernels (HipBackend::go_chain) takes effect for launches at least this wide ...
+#endif
+#ifndef DH_TAIL_SPLIT_MIN_SAMPLES
+#define DH_TAIL_SPLIT_MIN_SAMPLES 65536     // ... and pushes at least this long
 #endif
 #ifndef DH_LB
 #define DH_LB 4          // minimum waves per SIMD the wide-filter kernels are register-budgeted for (128 VGPRs)
@@ -66,10 +79,42 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_r
 template <int NZ, bool FAST, int PROTO, int SPS = 10, int PART = 0>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_chain(const DhDspParams P, const DhDecParams D) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    const uint32_t ch = blockIdx.x + P.ch_base;
+    // Tail split (HipBackend::go_chain): two (or three) workgroups per channel.  Workgroup c takes the first split_n0
+    // samples of channel c's push, workgroup split_pad + c the rest (up to split_n1, where workgroup 2 split_pad + c takes
+    // over), each starting from the state the one before wrote back -- a part is a push, and results do not depend on where
+    // pushes end.  Workgroups are dispatched in index order, so every first part is on the machine (most have long
+    // finished) before any second part is; the short later parts are what the launch drains with.  Hand-over: the
+    // workgroups of a channel run on the same XCD (workgroup i goes to XCD i mod 8, split_pad is a multiple of 8), so a
+    // part's stores only have to reach that XCD's L2 (s_waitcnt, no write-back) and the next part only has to drop its
+    // CU's L1 / scalar cache; the flag word carries the epoch of the push, the number of parts written back and the XCC
+    // id, and a part that finds another XCC id, or no flag at all, reports an error instead of reading stale state.
+    uint32_t bid = blockIdx.x, part = 0, sym_base = 0, part_lo = 0, part_hi = 0xFFFFFFFFu;
+    const uint32_t last_part = P.split_n0 ? (P.split_n1 ? 2u : 1u) : 0u;
+    if (P.split_n0) {
+        while (part < last_part && bid >= P.split_pad) { part++; bid -= P.split_pad; }
+        if (bid >= P.n_channels) return;                // padding between the parts of the grid
+        part_lo = part == 0 ? 0u : part == 1 ? P.split_n0 : P.split_n1;
+        part_hi = part == 0 ? P.split_n0 : (part == 1 && P.split_n1) ? P.split_n1 : 0xFFFFFFFFu;
+    }
+    const uint32_t ch = bid + P.ch_base;
+    // flag word: epoch of the push (24 bits) | parts written back << 24 | XCC id << 28
+    uint32_t* const part_flag = reinterpret_cast<uint32_t*>(P.state) + (size_t) ch * P.state_stride + DH_ST_PART;
+    if (part) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;      // HW_REG_XCC_ID
+        bool ok = false;
+        for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+            const uint32_t v = dh_uniform(__hip_atomic_load(part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if ((v & 0x00FFFFFFu) == P.part_epoch && ((v >> 24) & 3u) >= part) { ok = (v >> 28) == xcc; break; }
+            __builtin_amdgcn_s_sleep(64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // buffer_inv: this CU's L1 holds nothing older than the flag
+        __builtin_amdgcn_s_dcache_inv();
+        if (!ok) { if (threadIdx.x == 0 && P.overflow) P.overflow[1] = 1u; return; }      // (never seen; the push then reports DH_EDEVICE)
+        sym_base = dh_uniform(__hip_atomic_load(P.sym_count + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     {
         DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
-        dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, L);
+        dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, L, part_lo, part_hi, sym_base);
     }
     // This wavefront's symbol / count stores are read back by its own decoder half below: a WORKGROUP-scope fence (part of
     // __syncthreads) orders them.  A device-scope __threadfence() here made every wavefront write back its XCD's L2 --
@@ -84,10 +129,23 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
 #ifdef DH_SKIP_DECODER                      // diagnostic builds (tools/phase_budget.sh): the slicer half alone
     if (P.n_channels) return;
 #endif
-    if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, ch, S);
-    else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, ch, S);
-    else if (PROTO == DH_PROTO_NXDN) dh_nxdn_channel(D, ch, S);
-    else dh_ysf_channel(D, ch, S);
+    if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, ch, S, sym_base, part != 0);
+    else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, ch, S, sym_base, part != 0);
+    else if (PROTO == DH_PROTO_NXDN) dh_nxdn_channel(D, ch, S, sym_base, part != 0);
+    else dh_ysf_channel(D, ch, S, sym_base, part != 0);
+    // (which part this is, and its flag word, worked out again: nothing of the hand-over stays live through the two halves)
+    uint32_t part_end = 0, bid_end = blockIdx.x;
+    DH_OPAQUE_SGPR(bid_end);
+    while (P.split_n0 && part_end < (P.split_n1 ? 2u : 1u) && bid_end >= P.split_pad) { part_end++; bid_end -= P.split_pad; }
+    if (P.split_n0 && part_end < (P.split_n1 ? 2u : 1u)) {
+        uint32_t* const flag_end = reinterpret_cast<uint32_t*>(P.state) + (size_t) (bid_end + P.ch_base) * P.state_stride + DH_ST_PART;
+        // everything this workgroup stored is in the XCD's L2 before the flag is
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (threadIdx.x == 0)
+            __hip_atomic_store(flag_end, P.part_epoch | (part_end + 1u) << 24 | (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 28,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <int NZ, bool FAST>
@@ -434,6 +492,12 @@ struct HipBackend {
         if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) return DH_ENODEV;
         if (dev < 0 || dev >= count) return DH_EINVAL;
         device = dev; stream = (hipStream_t) s;
+        if (const char* e = std::getenv("DH_TAIL_SPLIT")) {       // "80" or "75,93" (percent of a push where the second / third workgroup of a channel starts), "0" = off
+            char* end = nullptr;
+            const long v = std::strtol(e, &end, 10), w = end && *end == ',' ? std::strtol(end + 1, nullptr, 10) : 0;
+            tail_split_pct = v > 0 && v < 100 ? (uint32_t) v : 0u;
+            tail_split_pct2 = tail_split_pct && w > v && w < 100 ? (uint32_t) w : 0u;
+        }
         return DH_OK;
     }
     void drop_timing_events() {
@@ -458,6 +522,9 @@ struct HipBackend {
     // anything is read, reset or synchronised through the engine: until then the INPUT BUFFER OF A PUSH MUST STAY
     // UNTOUCHED (that is the contract of the flag).  Measured: -6..8 % step time at 8 192 .. 32 768 channels.
     bool overlap_pushes = false;
+    // tail split of the chain launches (go_chain): share of a push, in percent, that the first workgroup of a channel
+    // takes; 0 = off.  DH_TAIL_SPLIT in the environment overrides it when the engine is created (A/B runs).
+    uint32_t tail_split_pct = DH_TAIL_SPLIT_PCT, tail_split_pct2 = DH_TAIL_SPLIT_PCT2, part_epoch = 0;
     hipStream_t side = nullptr, side_lo = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_lo = nullptr;
     bool side_failed = false, join_pending = false;
@@ -613,6 +680,23 @@ struct HipBackend {
                     join_pending = false;
                     return -1;
                 }
+                return launched("k_chain");
+            }
+        }
+        if constexpr (MAY_SPLIT) {
+            // Tail split (see k_chain): a launch of one workgroup per channel ends with a drain of about one workgroup's
+            // duration during which the chip runs half empty (tools/wave_timeline.py: 0.65 ms of a 6.2 ms step).  With the
+            // last quarter of every row handed to a second workgroup of the same launch the drain consists of workgroups a
+            // third as long.  Only for launches that fill the chip several times over and pushes long enough to be worth
+            // two prologues.
+            if (tail_split_pct > 0 && P.n_channels >= DH_TAIL_SPLIT_MIN_CHANNELS && P.n >= DH_TAIL_SPLIT_MIN_SAMPLES) {
+                DhDspParams Q = P;
+                Q.split_n0 = (uint32_t) ((uint64_t) P.n * tail_split_pct / 100u);
+                Q.split_n1 = tail_split_pct2 > tail_split_pct ? (uint32_t) ((uint64_t) P.n * tail_split_pct2 / 100u) : 0u;
+                Q.split_pad = (P.n_channels + 7u) & ~7u;
+                part_epoch = (part_epoch % 0x00FFFFFEu) + 1u;
+                Q.part_epoch = part_epoch;
+                hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 0>), dim3((Q.split_n1 ? 2u : 1u) * Q.split_pad + P.n_channels), dim3(DH_WAVE), lds, ms(), Q, D);
                 return launched("k_chain");
             }
         }

@@ -321,9 +321,9 @@ struct Engine {
     }
 
     int check_overflow() {
-        uint32_t flag = 0;
-        if (be.download(&flag, overflow, sizeof(flag))) return DH_EDEVICE;
-        return flag ? DH_ECAPACITY : DH_OK;
+        uint32_t flag[2] = { 0, 0 };                     // [0] a capacity was hit, [1] a split push's hand-over failed (k_chain)
+        if (be.download(flag, overflow, sizeof(flag))) return DH_EDEVICE;
+        return flag[1] ? DH_EDEVICE : flag[0] ? DH_ECAPACITY : DH_OK;
     }
 
     // per-channel header words of the slicer state: timing blocks evaluated / decided by the ordered chain

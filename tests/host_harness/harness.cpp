@@ -8,6 +8,7 @@
 // package has no code path that loads it: the product fails loudly without the gfx950 library.
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/digiham_amd.h"
@@ -90,6 +91,31 @@ struct HostBackend {
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
         // same order of work as the device kernel: channel by channel, slicer then decoder
         if (P.sps != 10 || (nz != 0 && nz != 80) || (proto != DH_PROTO_DMR && proto != DH_PROTO_YSF)) return 1;
+        // the tail split of the device's chain launches (engine.hip, k_chain): DH_TAIL_SPLIT = percent of a push the first
+        // part takes.  Here the two parts of a channel simply run one after the other -- what is exercised is the part
+        // arithmetic of the kernel bodies (offsets into the rows, appended symbols / frames / events).
+        uint32_t pct = 0, pct2 = 0;
+        if (const char* e = getenv("DH_TAIL_SPLIT")) {
+            char* end = nullptr;
+            const long v = strtol(e, &end, 10), w = end && *end == ',' ? strtol(end + 1, nullptr, 10) : 0;
+            pct = v > 0 && v < 100 ? (uint32_t) v : 0u; pct2 = pct && w > v && w < 100 ? (uint32_t) w : 0u;
+        }
+        if (pct && nz == 80 && !fast && P.n >= 2) {
+            const uint32_t b0 = std::max<uint32_t>(1u, (uint32_t) ((uint64_t) P.n * pct / 100u));
+            const uint32_t b1 = pct2 ? std::max<uint32_t>(b0, (uint32_t) ((uint64_t) P.n * pct2 / 100u)) : 0u;
+            const uint32_t lo[3] = { 0u, b0, b1 }, hi[3] = { b0, b1 ? b1 : 0xFFFFFFFFu, 0xFFFFFFFFu };
+            std::vector<float> lds(dh_dsp_shared_bytes(P.sps, 80) / sizeof(float));
+            DhDspShared S = dh_dsp_carve(lds.data(), P.sps, 80);
+            DhDecShared* DS = new DhDecShared;
+            for (uint32_t ch = 0; ch < P.n_channels; ch++)
+                for (uint32_t part = 0; part < (b1 ? 3u : 2u); part++) {
+                    const uint32_t sym_base = part ? P.sym_count[ch] : 0u;
+                    dh_rrc_demod_channel<80, false, 10>(P, ch, S, lo[part], hi[part], sym_base);
+                    if (proto == DH_PROTO_DMR) dh_dmr_channel(D, ch, *DS, sym_base, part != 0); else dh_ysf_channel(D, ch, *DS, sym_base, part != 0);
+                }
+            delete DS;
+            return 0;
+        }
         if (launch_rrc_demod(P, nz, fast)) return -1;
         return launch_decoder(D, proto) ? -1 : 0;
     }
