@@ -577,7 +577,10 @@ def main():
                        "channels_per_gpu": sum(per_gpu), "samples_per_channel_per_step": T,
                        "total_channels": int(round(samples_all / args.steps / T)) if not mixed else
                                          (args.total_channels if args.scaling == "strong" else sum(per_gpu) * world),
-                       "sharding": "channels, no collective", "streams": args.streams, "overlap_pushes": bool(args.overlap)},
+                       "sharding": "channels, no collective", "streams": args.streams, "overlap_pushes": bool(args.overlap),
+                       # chain launches of >= 8192 channels x >= 65536 samples: two workgroups per channel in ONE launch, the second takes
+                       # the rows from this percentage on (engine.hip: go_chain / k_chain); "0" = one workgroup per channel
+                       "tail_split_pct": os.environ.get("DH_TAIL_SPLIT", "80")},
             "msamples_per_s": rate / 1e6,
             "roofline": roof, "stage_ms": stage, "verified": verified,
         }

@@ -8,8 +8,9 @@ from digiham_amd import api, synth_torch
 proto = sys.argv[1] if len(sys.argv) > 1 else "dmr"
 pcts = sys.argv[2:] or ["0", "80", "70,92", "0", "80"]
 B = 16384
-units = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198}[proto]
-ekw = {"nxdn": dict(rrc="narrow", sps=20), "dstar": dict(rrc="none", demod="fsk", sps=10)}.get(proto, {})
+units = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}[proto]
+ekw = {"nxdn": dict(rrc="narrow", sps=20), "dstar": dict(rrc="none", demod="fsk", sps=10),
+       "pocsag": dict(rrc="none", demod="fsk", sps=40, invert=True)}.get(proto, {})
 x, info = synth_torch.make_batch(torch, torch.device("cuda", 0), proto, B, units, seed=1000, sps=ekw.get("sps", 10))
 T = info["samples_per_channel"]
 ref = None
