@@ -377,8 +377,8 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
 
     int slot = (int) s[DS_SLOT], stab = (int) s[DS_SLOT_STABILITY];
     const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
-    if (has_tact) {
-        if (tact_slot != next) {
+    if (DH_LIKELY(has_tact)) {
+        if (DH_UNLIKELY(tact_slot != next)) {
             if (stab < 5) {
                 stab = 0; slot = tact_slot;
                 const int other = slot ^ 1;
@@ -398,7 +398,7 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
         slot = next;
     }
     s[DS_SLOT] = (uint32_t) slot; s[DS_SLOT_STABILITY] = (uint32_t) stab;
-    if (slot == -1) return R;
+    if (DH_UNLIKELY(slot == -1)) return R;
 
     int sync_count = (int) s[DS_SYNC_COUNT];
     const int sync_type = dh_dmr_sync_type_bits(sync_h, sync_l);
@@ -437,7 +437,7 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
             s[DS_EMB_OFF0 + slot] = off;
         } else {
             dh_dmr_slot_sync_lost(c, slot);
-            if (--sync_count < 0) {
+            if (DH_UNLIKELY(--sync_count < 0)) {
                 dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
                 R.to_sync = true; return R;
             }
@@ -446,7 +446,7 @@ DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uin
         s[DS_SUPERFRAME0 + slot] = 0;
         s[DS_EMB_OFF0 + slot] = 0;
         dh_dmr_slot_sync_lost(c, slot);
-        if (--sync_count < 0) {
+        if (DH_UNLIKELY(--sync_count < 0)) {
             dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
             R.to_sync = true; return R;
         }
@@ -651,7 +651,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     for (;;) {
         const uint32_t avail = total - pos;
         DhPlanes& pl = S.planes;
-        if (phase == 0) {                                              // SyncPhase (dmr_phase.cpp:35-47)
+        if (DH_UNLIKELY(phase == 0)) {                                 // SyncPhase (dmr_phase.cpp:35-47)
             if (!(avail > 90)) break;
             dh_view_ensure(syms, pos, 192);
             dh_load_planes(syms, pos, total, pl, 3);
@@ -675,7 +675,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             DH_DCLK(1);
             const DhDmrFrameResult R = dh_dmr_frame_head(c, syms, pos, S);
             DH_DCLK(2);
-            if (R.to_sync) { phase = 0; continue; }
+            if (DH_UNLIKELY(R.to_sync)) { phase = 0; continue; }
 #ifdef DH_DMR_SKIP_VOICE
             if (false) {        // timing experiment (results are wrong)
 #else
@@ -1161,7 +1161,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     for (;;) {
         const uint32_t avail = total - pos;
         DhPlanes& pl = S.planes;
-        if (phase == 0) {                                          // SyncPhase (ysf_phase.cpp:20-34)
+        if (DH_UNLIKELY(phase == 0)) {                             // SyncPhase (ysf_phase.cpp:20-34)
             if (!(avail > 20)) break;
             dh_view_ensure(syms, pos, 128);
             dh_load_planes(syms, pos, total, pl, 2);
@@ -1189,7 +1189,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         DH_DCLK(1);
         int sync_count = (int) s[DS_SYNC_COUNT];
         if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
-        else if (--sync_count < 0) {
+        else if (DH_UNLIKELY(--sync_count < 0)) {
             dh_emit(c, DH_EV_YSF_META_RESET, 0, 0, nullptr, 0);
             phase = 0; continue;
         }
@@ -1313,7 +1313,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                         c.nout += nbytes;
                     }
                 }
-            } else if (frame_type == 0) {                                           // header (:139-161)
+            } else if (DH_UNLIKELY(frame_type == 0)) {                              // header (:139-161)
                 dh_emit(c, DH_EV_YSF_META_RESET, 0, 1, nullptr, 0);
                 // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333); this pass uses
                 // the slots of a frame decoded ahead, which is then simply decoded again when its turn comes
@@ -1489,7 +1489,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
         int sync_count = (int) s[DS_SYNC_COUNT];
         const uint32_t sh = (uint32_t) headvote & 0x3FFu, sl = (uint32_t) (headvote >> 10) & 0x3FFu;
         if (dh_popc32(sh ^ DH_NXDN_SYNC_H) + dh_popc32(sl ^ DH_NXDN_SYNC_L) <= 2) { if (++sync_count > 6) sync_count = 6; }
-        else if (--sync_count < 0) {
+        else if (DH_UNLIKELY(--sync_count < 0)) {
             dh_emit(c, DH_EV_NXDN_META_RESET, 0, 0, nullptr, 0);
             phase = 0; continue;
         }

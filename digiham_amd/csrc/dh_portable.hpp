@@ -105,3 +105,7 @@ DH_HD int dh_ffs64(uint64_t x) {   // index of lowest set bit, x != 0
 
 template <typename T> DH_HD T dh_min(T a, T b) { return a < b ? a : b; }
 template <typename T> DH_HD T dh_max(T a, T b) { return a > b ? a : b; }
+
+// branch weights: what the register allocator keeps out of the hot path (spill code goes where the weights are low)
+#define DH_LIKELY(x) __builtin_expect(!!(x), 1)
+#define DH_UNLIKELY(x) __builtin_expect(!!(x), 0)

@@ -389,6 +389,24 @@ template <int NZ, int B> __device__ __forceinline__ void dh_fir_issue(uint32_t a
     dh_fir_issue_one<NZ, B * DH_FIR_G + 0>(addr, d[0]); dh_fir_issue_one<NZ, B * DH_FIR_G + 1>(addr, d[1]);
     dh_fir_issue_one<NZ, B * DH_FIR_G + 2>(addr, d[2]); dh_fir_issue_one<NZ, B * DH_FIR_G + 3>(addr, d[3]);
 }
+// The same batch, issued AND waited for inside one asm statement: nothing of the compiler's (a spill of a destination
+// pair, say) can come between a load and its wait.  For the FIR bodies that are rare paths of a kernel at its register
+// limit -- the reference-order FIR of the error-bounded chain kernels, which the compiler is told is cold and which it
+// therefore spills around freely (tests/test_isa_contract.py caught a destination pair stored to scratch ahead of its wait).
+template <int NZ, int B> __device__ __forceinline__ void dh_fir_issue_wait(uint32_t addr, dh_f2 (&d)[DH_FIR_G]) {
+    if constexpr (B * DH_FIR_G < NZ) {
+        static_assert(NZ % DH_FIR_G == 0, "a batch is all taps or all padding");
+        asm volatile("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b32 %1, %4 offset0:%7 offset1:%8\n\t"
+                     "ds_read2_b32 %2, %4 offset0:%9 offset1:%10\n\tds_read2_b32 %3, %4 offset0:%11 offset1:%12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(addr),
+                       "n"(DH_XLOFF(DH_FIR_H + B * DH_FIR_G + 0)), "n"(DH_XLOFF(2 * DH_FIR_H + B * DH_FIR_G + 0)),
+                       "n"(DH_XLOFF(DH_FIR_H + B * DH_FIR_G + 1)), "n"(DH_XLOFF(2 * DH_FIR_H + B * DH_FIR_G + 1)),
+                       "n"(DH_XLOFF(DH_FIR_H + B * DH_FIR_G + 2)), "n"(DH_XLOFF(2 * DH_FIR_H + B * DH_FIR_G + 2)),
+                       "n"(DH_XLOFF(DH_FIR_H + B * DH_FIR_G + 3)), "n"(DH_XLOFF(2 * DH_FIR_H + B * DH_FIR_G + 3)) : "memory");
+    } else {
+        d[0] = dh_f2_make(0.0f, 0.0f); d[1] = d[0]; d[2] = d[0]; d[3] = d[0];
+    }
+}
 __device__ __forceinline__ void dh_fir_arrived(dh_f2 (&d)[DH_FIR_G]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) :: "memory");
 }
@@ -399,7 +417,7 @@ __device__ __forceinline__ void dh_fir_arrived(dh_f2 (&d)[DH_FIR_G]) {
 // product of -0 stays -0 where the reference's `sum = 0; sum += c * x` gives +0.  The sign of a zero cannot reach a
 // dibit (the slicer only adds, subtracts and compares filtered samples), so the slicer kernels drop the eight packed
 // adds and the zeroing; the materialised RRC output (k_rrc_tile) keeps the reference's bits.
-template <int NZ, bool FAST, int B, bool SG = false, bool ZINIT = true> struct DhFirBatch {
+template <int NZ, bool FAST, int B, bool SG = false, bool ZINIT = true, bool SAFE = false> struct DhFirBatch {
     // tap I = B * DH_FIR_G + G: accumulate it on the eight window pairs, then slide the window by one sample
     template <int G> static __device__ __forceinline__ void tap(const float* taps, dh_f2 (&accp)[DH_FIR_H], dh_f2 (&w)[DH_FIR_H], dh_f2 (&cur)[DH_FIR_G]) {
         constexpr int I = B * DH_FIR_G + G;
@@ -428,21 +446,32 @@ template <int NZ, bool FAST, int B, bool SG = false, bool ZINIT = true> struct D
     static __device__ __forceinline__ void run(const float* taps, uint32_t addr, dh_f2 (&accp)[DH_FIR_H], dh_f2 (&w)[DH_FIR_H], dh_f2 (&cur)[DH_FIR_G]) {
         if constexpr (B * DH_FIR_G <= NZ) {
             dh_f2 nxt[DH_FIR_G];
-            dh_fir_issue<NZ, B + 1>(addr, nxt);
+            if constexpr (SAFE) dh_fir_issue_wait<NZ, B + 1>(addr, nxt); else dh_fir_issue<NZ, B + 1>(addr, nxt);
             tap<0>(taps, accp, w, cur); tap<1>(taps, accp, w, cur); tap<2>(taps, accp, w, cur); tap<3>(taps, accp, w, cur);
             static_assert(DH_FIR_G == 4, "four taps per batch");
-            if constexpr ((B + 1) * DH_FIR_G < NZ) dh_fir_arrived(nxt);
-            DhFirBatch<NZ, FAST, B + 1, SG, ZINIT>::run(taps, addr, accp, w, nxt);
+            if constexpr (!SAFE && (B + 1) * DH_FIR_G < NZ) dh_fir_arrived(nxt);
+            DhFirBatch<NZ, FAST, B + 1, SG, ZINIT, SAFE>::run(taps, addr, accp, w, nxt);
         }
     }
 };
 
-template <int NZ, bool FAST, bool SG = false>
+template <int NZ, bool FAST, bool SG = false, bool SAFE = false>
 __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, double rgain, float inv_gain, const float* xs_all, int lane, float* out16, bool* nonfinite = nullptr) {
     constexpr bool ZINIT = SG;                             // the stand-alone RRC kernel (scalar taps) materialises its output
     // element e of this lane's window sits at DH_XPAD(16*lane + e) = 17*lane + e + (e >> 4): static offsets from one base
     const uint32_t addr = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (xs_all + (DH_FIR_L + 1) * lane);
     dh_f2 accp[DH_FIR_H], w[DH_FIR_H], cur[DH_FIR_G];
+    if constexpr (SAFE) {
+        // (the first eight window pairs as two batches of the slide sequence shifted by -8: pair i = (x[i], x[8 + i]))
+        asm volatile("ds_read2_b32 %0, %8 offset0:%9 offset1:%10\n\tds_read2_b32 %1, %8 offset0:%11 offset1:%12\n\t"
+                     "ds_read2_b32 %2, %8 offset0:%13 offset1:%14\n\tds_read2_b32 %3, %8 offset0:%15 offset1:%16\n\t"
+                     "ds_read2_b32 %4, %8 offset0:%17 offset1:%18\n\tds_read2_b32 %5, %8 offset0:%19 offset1:%20\n\t"
+                     "ds_read2_b32 %6, %8 offset0:%21 offset1:%22\n\tds_read2_b32 %7, %8 offset0:%23 offset1:%24\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]) : "v"(addr),
+                       "n"(DH_XLOFF(0)), "n"(DH_XLOFF(8)), "n"(DH_XLOFF(1)), "n"(DH_XLOFF(9)), "n"(DH_XLOFF(2)), "n"(DH_XLOFF(10)), "n"(DH_XLOFF(3)), "n"(DH_XLOFF(11)),
+                       "n"(DH_XLOFF(4)), "n"(DH_XLOFF(12)), "n"(DH_XLOFF(5)), "n"(DH_XLOFF(13)), "n"(DH_XLOFF(6)), "n"(DH_XLOFF(14)), "n"(DH_XLOFF(7)), "n"(DH_XLOFF(15)) : "memory");
+        dh_fir_issue_wait<NZ, 0>(addr, cur);
+    } else {
     w[0] = dh_lds_read2<DH_XLOFF(0), DH_XLOFF(8)>(addr);  w[1] = dh_lds_read2<DH_XLOFF(1), DH_XLOFF(9)>(addr);
     w[2] = dh_lds_read2<DH_XLOFF(2), DH_XLOFF(10)>(addr); w[3] = dh_lds_read2<DH_XLOFF(3), DH_XLOFF(11)>(addr);
     w[4] = dh_lds_read2<DH_XLOFF(4), DH_XLOFF(12)>(addr); w[5] = dh_lds_read2<DH_XLOFF(5), DH_XLOFF(13)>(addr);
@@ -450,11 +479,12 @@ __device__ __forceinline__ void dh_fir_lane(const float* taps, double gain, doub
     dh_fir_issue<NZ, 0>(addr, cur);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) :: "memory");
     dh_fir_arrived(cur);
+    }
     if constexpr (ZINIT) {
 #pragma unroll
         for (int j = 0; j < DH_FIR_H; j++) accp[j] = dh_f2_make(0.0f, 0.0f);
     }
-    DhFirBatch<NZ, FAST, 0, SG, ZINIT>::run(taps, addr, accp, w, cur);
+    DhFirBatch<NZ, FAST, 0, SG, ZINIT, SAFE>::run(taps, addr, accp, w, cur);
     float acc[DH_FIR_L];
 #pragma unroll
     for (int j = 0; j < DH_FIR_H; j++) { acc[j] = accp[j].x; acc[j + DH_FIR_H] = accp[j].y; }
@@ -1262,7 +1292,7 @@ DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t ne
         if ((uint32_t) (lane * DH_FIR_L) < need) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
             (void) fo_all;
-            dh_fir_lane<NZ, false>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, fo_dev);
+            dh_fir_lane<NZ, false, false, DH_FIR_F16 != 0>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, fo_dev);      // (a rare path next to the split-f16 FIR: loads waited for where they are issued)
 #else
             (void) fo_dev;
             dh_fir_lane<NZ, false>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, fo_all[lane]);
@@ -1374,7 +1404,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_LANE_ARRAY(float, xm, 1);
         DH_FOR_LANES_FRESH(lane) {
             const uint32_t l4 = 4u * (uint32_t) lane;
-            if (have < DH_FTILE + NZ) {                // the last window of the push: zeros beyond the input
+            if (DH_UNLIKELY(have < DH_FTILE + NZ)) {   // the last window of the push: zeros beyond the input
 #pragma unroll
                 for (int r = 0; r < DH_PF_N; r++) {
                     const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
@@ -1495,7 +1525,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // After the first run of a push the whole window comes straight from `in`: 16 B per lane per load,
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
         // From the second run on, the window was already put there by the previous iteration's prefetch.
-        if (staged && staged_p == p) {
+        if (DH_LIKELY(staged && staged_p == p)) {
             static_assert(DH_PF_L2 || !BOUNDED, "the register-prefetch build does not compute max |x| of a prefetched window: error-bounded kernels need DH_PF_L2");
             if (PF_REG) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; }      // (put there by P7 of the previous run)
         } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
@@ -1660,7 +1690,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             int mf_layout = 0;                          // fo[] holds a matrix-core output layout: 1 = DH_MF_OUT, 2 = DH_F16_OUT
             if (BOUNDED) {
                 uint64_t vote_bad = 0;
-                if (!use_exact) {
+                if (DH_LIKELY(!use_exact)) {
                     if constexpr (MF16) {
                         // (f16_staged holds: every staging path that does not fill the two arrays of halves sets use_exact)
                         DH_FOR_LANES_FRESH(lane) {
@@ -1696,7 +1726,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         }
                     }
                 }
-                if (use_exact || vote_bad) {            // a NaN / infinity among the samples: the reference's arithmetic decides
+                if (DH_UNLIKELY(use_exact || vote_bad)) {            // a NaN / infinity among the samples: the reference's arithmetic decides
                     use_exact = true; e_run = 0.0f; BS->n_exact_runs++; mf_layout = 0;
                     if (MF16 && f16_staged) {           // the window block holds halves: the reference's FIR wants the raw samples back
                         DH_BARRIER();
@@ -1841,7 +1871,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
         const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
         const bool pf_reg = PF_REG && pf_plain && P.exact_mode != 2;
-        if (pf_reg) {
+        if (DH_LIKELY(pf_reg)) {
             // The split-f16 FIR leaves registers free where the packed-FMA FIR had none: the next window's five 16-byte loads
             // per lane are issued here, straight from HBM, land while P4 - P6 run, and P7 turns them into the two arrays of
             // halves -- the next iteration starts at the matrix cores.
@@ -1952,7 +1982,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         unsure[h] = vote_unsure;
         }
         }
-        if (BOUNDED && (unsure[0] | unsure[1])) {
+        if (BOUNDED && DH_UNLIKELY((unsure[0] | unsure[1]) != 0)) {
             DhExactCtx C;
             C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
             C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
@@ -2192,7 +2222,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     chain_rows = cand;
                 }
             }
-            if (ordered) {
+            if (DH_UNLIKELY(ordered)) {
                 // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
                 // ring and fetched 16 bytes at a time.
                 // Error-bounded kernels: the ring holds values within e_blk of the reference's.  At sps 10 the estimate above
@@ -2331,7 +2361,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #else
         staged = pf_plain; staged_p = p_next;
 #endif
-        if (pf_reg) {
+        if (DH_LIKELY(pf_reg)) {
             if constexpr (PF_REG) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = p_next; }
         }
         DH_BARRIER();
