@@ -1324,7 +1324,10 @@ DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps
 // part_lo / part_hi / sym_base: the tail split of the chain kernels -- this call takes the samples [part_lo, part_hi) of the
 // push and appends its symbols behind the sym_base symbols the earlier parts produced (a part is a push: results do not
 // depend on where pushes end).
-template <int NZ, bool FAST, int SPS>
+// LV = 4 / 2: the number of levels is known where the kernel is instantiated (the chain kernels: 4 for DMR / YSF / NXDN, 2 for
+// D-Star; engine.hip checks P.levels against it) and the other slicer's selects, its invert mask and two scalar register
+// pairs drop out of the slicing phase; 0 = taken from P.levels.
+template <int NZ, bool FAST, int SPS, int LV = 0>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu, uint32_t sym_base = 0) {
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
@@ -1935,8 +1938,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // guards the store -- written as a loop over the lane's symbols this compiled to a real loop with exec-mask
         // bookkeeping (half of this phase's instructions were scalar).  The wave-uniform choices (4 / 2 levels, invert,
         // exact_mode) are selects, not branches.
-        const bool four_levels = P.levels == 4;
+        const bool four_levels = LV ? LV == 4 : P.levels == 4;
+        // (DH_FLAG_EXACT_SYMBOLS -- every symbol decided exactly -- is an infinite threshold, not another mask)
         const bool force_doubt = BOUNDED && P.exact_mode == 1;
+        const bool e_pos = e_eff > 0.0f || force_doubt;
+        const float T_eff = force_doubt ? __builtin_inff() : T;
         const float inv_width = 1.0f / (float) (ev_hi - ev_lo);                       // (a power of two for sps 10: the product below is the division)
         const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
 #pragma unroll
@@ -1959,7 +1965,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             const float lmid = __builtin_fmaf(mn - center, 0.625f, center);
             const bool above = average > center;
             const uint8_t sym4 = above ? (average > umid ? 1 : 0) : (average < lmid ? 3 : 2);
-            const uint8_t sym2 = above ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+            const uint8_t sym2 = LV == 4 ? (uint8_t) 0 : above ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
             const uint8_t sym = four_levels ? sym4 : sym2;
             bool doubt = false;
             if (BOUNDED) {
@@ -1967,7 +1973,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // reference's; those symbols are not stored here but decided exactly below
                 const float d_mid = __builtin_fminf(__builtin_fabsf(average - umid), __builtin_fabsf(average - lmid));
                 const float d_all = __builtin_fminf(four_levels ? d_mid : DH_FLT_MAX, __builtin_fabsf(average - center));
-                doubt = valid && ((e_eff > 0.0f && !(d_all > T)) || force_doubt);       // (!(d > T): a NaN distance is a doubt)
+                doubt = valid && e_pos && !(d_all > T_eff);                            // (!(d > T): a NaN distance is a doubt)
             }
 #ifdef DH_IGNORE_DOUBT                      // diagnostic builds: undecided symbols are NOT re-evaluated (wrong in a few symbols per 100 000; what do the exact evaluations cost?)
             doubt = false;

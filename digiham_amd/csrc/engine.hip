@@ -114,7 +114,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     }
     {
         DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
-        dh_rrc_demod_channel<NZ, FAST, SPS>(P, ch, L, part_lo, part_hi, sym_base);
+        dh_rrc_demod_channel<NZ, FAST, SPS, (PROTO == DH_PROTO_DSTAR ? 2 : 4)>(P, ch, L, part_lo, part_hi, sym_base);      // (launch_chain checked P.levels)
     }
     // This wavefront's symbol / count stores are read back by its own decoder half below: a WORKGROUP-scope fence (part of
     // __syncthreads) orders them.  A device-scope __threadfence() here made every wavefront write back its XCD's L2 --
@@ -705,6 +705,7 @@ struct HipBackend {
     }
     // 1 = not available for this configuration (the caller launches the two stages separately), 0 = launched
     int launch_chain(const DhDspParams& P, const DhDecParams& D, uint32_t nz, bool fast, int proto) {
+        if (P.levels != (proto == DH_PROTO_DSTAR ? 2 : 4)) return 1;        // the chain kernels are built for their pipe's slicer (k_chain); anything else runs as two launches
         if (proto == DH_PROTO_NXDN && nz == 160 && !fast && P.sps == 20) return go_chain<160, false, DH_PROTO_NXDN, 20, true>(P, D);   // rrc_filter -n | gfsk_demodulator -s 20 | nxdn_decoder
         if (proto == DH_PROTO_NXDN && nz == 160 && !fast) return go_chain<160, false, DH_PROTO_NXDN, 0, true>(P, D);    // (any other samples-per-symbol)
         // (POCSAG stays on two launches: measured 9.5 ms chained against 8.9 ms split at 16 384 channels)
