@@ -852,6 +852,17 @@ DH_HD float dh_virtual_sample(const float* tail, uint32_t tc, const float* in, u
 #define DH_FLT_MAX 3.402823466e+38f
 #define DH_DBL_MAX 1.7976931348623157e+308
 #define DH_FLT_MIN 1.175494351e-38f
+// an upper bound of sqrt(x), x >= 0 (a tolerance may be generous, never short): the hardware's v_sqrt_f32 (1 ulp, one
+// instruction -- the correctly rounded square root this file is compiled for is twenty) on an argument kept away from
+// the denormals, times 1 + 2^-20
+DH_HD float dh_sqrt_upper(float x) {
+    const float a = x > 1e-30f ? x : 1e-30f;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(a) * 1.00000095367431640625f;
+#else
+    return __builtin_sqrtf(a) * 1.00000095367431640625f;
+#endif
+}
 DH_HD float dh_fmin_(float a, float b) { return b < a ? b : a; }
 DH_HD float dh_fmax_(float a, float b) { return b > a ? b : a; }
 
@@ -1505,7 +1516,16 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             uint32_t lim = dh_min<uint32_t>(DH_VARIANCE_SYMBOLS - k0, max_run);
             lim = dh_min<uint32_t>(lim, P.sym_cap - nsym);
             const int64_t room = (int64_t) nf - (int64_t) p - (int64_t) sps - 2;     // >= 0  <=>  symbol 0 fits
-            if (room >= 0 && lim > 0) {
+            if (DH_LIKELY(nf >= p && nf - p < 0x40000000u)) {
+                // (the same in 32 bits -- every push but an absurdly long one: there is no 64-bit scalar compare or divide, the
+                // general form below costs two vector compares and twenty scalar instructions per run)
+                const int32_t room32 = (int32_t) (nf - p) - (int32_t) sps - 2;
+                if (room32 >= 0 && lim > 0) {
+                    const int32_t r1 = room32 - step_off;
+                    const uint32_t qmax = r1 >= (int32_t) sps ? (uint32_t) r1 / sps : 0u;
+                    m = dh_min<uint32_t>(lim, qmax + 1u);
+                }
+            } else if (room >= 0 && lim > 0) {
                 const int64_t r1 = room - step_off;                                   // q*sps <= r1 for q >= 1
                 const uint32_t qmax = r1 >= (int64_t) sps ? (uint32_t) (r1 / sps) : 0u;
                 m = dh_min<uint32_t>(lim, qmax + 1u);
@@ -2085,7 +2105,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         // error-bounded mode: the ring holds values within e_blk of the reference's; moving every sample by
                         // up to e_blk moves the mean by <= e_blk, every deviation by <= 2 e_blk and the variance by
                         // <= 4 e_blk sqrt(V) + 4 e_blk^2 (Cauchy-Schwarz); taken twice over for the float mean's own rounding
-                        if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * __builtin_sqrtf(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
+                        if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
                         guard = e < 1e30f;                           // false for NaN, and for samples beyond ~1e15 (e overflows first)
                         vzero = v == 0.0f;
                         l = v - tol; h = v + tol;
