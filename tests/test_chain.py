@@ -265,3 +265,15 @@ def test_ragged_pushes_every_channel_at_its_own_pace(ctx, oracle, kw, oproto):
             assert len(gf) == ref["out_count"][b] and (gf == ref["out"][b, :len(gf)]).all(), b
         if kw.get("keep_filtered"):
             assert (np.concatenate(filt[b]).view(np.uint32) == ref["filtered"][b].view(np.uint32)).all(), b
+
+
+@pytest.mark.parametrize("proto,oproto,demod,levels", [("dmr", 1, "fsk", 2), ("dstar", 5, "gfsk", 4)])
+def test_decoder_behind_the_other_slicer_runs_as_two_launches(ctx, oracle, proto, oproto, demod, levels):
+    """The chain kernels are built for their pipe's slicer (4 levels for DMR / YSF / NXDN, 2 for D-Star: k_chain,
+    dh_rrc_demod_channel<..., LV>); a decoder configured behind the other one is a legal, if pointless, engine and must take
+    the two-launch route with the generic slicer -- same symbols and decoder bytes as the oracle's."""
+    x = make_channels("dmr", [41, 42], 6)
+    kw = dict(rrc="none", demod=demod, sps=10)
+    ref = oracle.chain(x, proto=oproto, rrc=0, levels=levels)
+    res = run_engine(ctx, x, proto, [x.shape[1] // 2, x.shape[1] - x.shape[1] // 2], **kw)
+    assert_matches_oracle(res, ref, 2, "%s behind %s" % (proto, demod))
