@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the tail split (engine.hip: k_chain): batches of > 8192 DISTINCT noisy channels, every channel's symbols,
 frames and events of two consecutive pushes compared between launches split at random points (two and three parts) and
-whole launches; 64 channels of every batch also against the oracle.   tools/soak_split.py [seeds]"""
+whole launches; 64 channels of every batch also against the oracle.   tools/soak_split.py [seeds] [channels]"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,13 +12,14 @@ from oracle import oracle as O
 ctx = api.Context()
 dev = torch.device("cuda", 0)
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+base_B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192            # channels per batch (plus a random 1..199)
 PROTOS = {"dmr": (50, {}, dict(proto=1)), "ysf": (15, {}, dict(proto=2)), "nxdn": (19, dict(rrc="narrow", sps=20), dict(proto=3, rrc=2, sps=20)),
           "dstar": (76, dict(rrc="none", demod="fsk"), dict(proto=5, rrc=0, levels=2))}
 cases = 0
 for seed in range(n_seeds):
     rng = np.random.default_rng(9100 + seed)
     for proto, (units, kw, okw) in PROTOS.items():
-        B = 8192 + int(rng.integers(1, 200))
+        B = base_B + int(rng.integers(1, 200))
         x, info = synth_torch.make_batch(torch, dev, proto, B, units, seed=5000 + 17 * seed, sps=kw.get("sps", 10))
         T = info["samples_per_channel"]
         assert T >= 65536, (proto, T)
