@@ -947,6 +947,39 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
     DH_BARRIER();
 }
 #elif DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+// One trellis step of the forward pass below; C = step & 63 = the lane of the decision registers that takes its vote, an
+// IMMEDIATE of v_writelane (the steps are spelled out, not looped over: as a loop variable the lane went through m0 --
+// three scalar moves per step and 64 scalar registers of constants, which the decoders then spilled).  The vote comes
+// straight out of a vector compare: v_writelane may not read a scalar register a vector instruction wrote less than four
+// wait states ago -- without the s_nop the YSF decoder ran 2.2 times SLOWER (3.1 -> 7.0 ms), with it 3 % faster than the
+// m0 form (profiles/r03_d_ab_logs.txt); inline asm gets no hazard handling from the compiler.
+#ifndef DH_VIT_IMM_NOP
+#define DH_VIT_IMM_NOP "s_nop 3\n\t"
+#endif
+template <bool NXDN, bool RAGGED, int C>
+__device__ __forceinline__ void dh_vitb_step(uint32_t& m, uint32_t h0, uint32_t h1, int src0, int src1, uint32_t i, int blk, int steps, int mysize,
+                                             uint32_t& dlo, uint32_t& dhi) {
+    constexpr int q = C & 3;
+    const int pos = blk * 64 + C;
+    if (pos < steps) {
+        const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
+        const uint32_t m0 = (a + ((h0 >> (8 * q)) & 0xFFu)) & 0xFFu;
+        const uint32_t m1 = (b + ((h1 >> (8 * q)) & 0xFFu)) & 0xFFu;
+        bool take1 = m1 < m0;
+        if (NXDN && C < 4) take1 = take1 && (blk > 0 || (i & ((0xFu << C) & 0xFu)) == 0u);
+        if (RAGGED) {
+            const bool active = pos < mysize;
+            take1 = take1 && active;
+            if (active) m = take1 ? m1 : m0;
+        } else if (NXDN && C < 4) {
+            m = take1 ? m1 : m0;
+        } else {
+            m = m1 < m0 ? m1 : m0;
+        }
+        const uint64_t dec = __builtin_amdgcn_ballot_w64(take1);
+        asm(DH_VIT_IMM_NOP "v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(dlo), "+v"(dhi) : "s"((uint32_t) dec), "s"((uint32_t) (dec >> 32)), "n"(C));
+    }
+}
 // gfx950 forward pass: path metrics stay in registers, the two predecessor metrics come through ds_bpermute
 // (__shfl), decisions are wave votes; no LDS traffic or barrier inside the step loop.  Per step and lane: two byte
 // adds (SDWA: uint8 wrap for free, like the reference's uint8 metrics), a compare, a min, two v_writelane; the branch
@@ -977,42 +1010,18 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
     for (int blk = 0; blk * 64 < steps; blk++) {
         // decisions of 64 steps collect in one register pair, step (64 blk + c) in lane c, written with v_writelane
         uint32_t dlo = 0, dhi = 0;
-#pragma unroll
-        for (int wq = 0; wq < 16; wq++) {
-            if (blk * 64 + wq * 4 < steps) {
-                const uint32_t w = inw[blk * 16 + wq];
-                const uint32_t h0 = __builtin_amdgcn_perm(tab0, tab0, w), h1 = __builtin_amdgcn_perm(tab1, tab1, w);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int c = wq * 4 + q, pos = blk * 64 + c;
-                    if (pos < steps) {
-                        const uint32_t a = (uint32_t) __shfl((int) m, src0), b = (uint32_t) __shfl((int) m, src1);
-                        const uint32_t m0 = (a + ((h0 >> (8 * q)) & 0xFFu)) & 0xFFu;
-                        const uint32_t m1 = (b + ((h1 >> (8 * q)) & 0xFFu)) & 0xFFu;
-                        bool take1 = m1 < m0;
-                        if (NXDN && c < 4) {
-                            // for the first four steps a state that overlaps the shifting `blocked` mask only looks
-                            // at its k = 0 predecessor
-                            take1 = take1 && (blk > 0 || ((uint32_t) i & ((0xFu << c) & 0xFu)) == 0u);
-                        }
-                        if (RAGGED) {
-                            const bool active = pos < mysize;
-                            take1 = take1 && active;
-                            if (active) m = take1 ? m1 : m0;
-                        } else if (NXDN && c < 4) {
-                            m = take1 ? m1 : m0;
-                        } else {
-                            m = m1 < m0 ? m1 : m0;
-                        }
-                        const uint64_t dec = __builtin_amdgcn_ballot_w64(take1);
-                        const uint32_t slo = (uint32_t) dec, shi = (uint32_t) (dec >> 32), sc = (uint32_t) c;
-                        uint32_t keep;
-                        asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
-                            : "+v"(dlo), "+v"(dhi), "=&s"(keep) : "s"(slo), "s"(shi), "s"(sc));
-                    }
-                }
-            }
+#define DH_VITB_WORD(WQ) \
+        if (blk * 64 + (WQ) * 4 < steps) { \
+            const uint32_t w = inw[blk * 16 + (WQ)]; \
+            const uint32_t h0 = __builtin_amdgcn_perm(tab0, tab0, w), h1 = __builtin_amdgcn_perm(tab1, tab1, w); \
+            dh_vitb_step<NXDN, RAGGED, (WQ) * 4 + 0>(m, h0, h1, src0, src1, (uint32_t) i, blk, steps, mysize, dlo, dhi); \
+            dh_vitb_step<NXDN, RAGGED, (WQ) * 4 + 1>(m, h0, h1, src0, src1, (uint32_t) i, blk, steps, mysize, dlo, dhi); \
+            dh_vitb_step<NXDN, RAGGED, (WQ) * 4 + 2>(m, h0, h1, src0, src1, (uint32_t) i, blk, steps, mysize, dlo, dhi); \
+            dh_vitb_step<NXDN, RAGGED, (WQ) * 4 + 3>(m, h0, h1, src0, src1, (uint32_t) i, blk, steps, mysize, dlo, dhi); \
         }
+        DH_VITB_WORD(0) DH_VITB_WORD(1) DH_VITB_WORD(2) DH_VITB_WORD(3) DH_VITB_WORD(4) DH_VITB_WORD(5) DH_VITB_WORD(6) DH_VITB_WORD(7)
+        DH_VITB_WORD(8) DH_VITB_WORD(9) DH_VITB_WORD(10) DH_VITB_WORD(11) DH_VITB_WORD(12) DH_VITB_WORD(13) DH_VITB_WORD(14) DH_VITB_WORD(15)
+#undef DH_VITB_WORD
         S.vit_dec[blk * 64 + lane] = (uint64_t) dhi << 32 | dlo;
     }
     S.vit_metric[0][lane] = m;
