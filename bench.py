@@ -70,20 +70,37 @@ WORKLOADS = {
 UNITS = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}     # bursts / frames per step: ~3.96-4 s
 
 
+def _profile_config(pdir, name, workload):
+    """(channels, samples per channel) the PMC passes of profiles/<name> ran on: the `## config:` line tools/profile_gpu.sh
+    writes into the summary, else the bench line captured under the tracer beside it (<prefix>_bench_<workload>_under_trace.json)."""
+    for line in open(os.path.join(pdir, name)):
+        if line.startswith("## config:"):
+            kv = dict(t.split("=", 1) for t in line.split()[2:] if "=" in t)
+            return int(kv["channels_per_gpu"]), int(kv["samples_per_channel"])
+    beside = os.path.join(pdir, name.replace("_%s_pmc.txt" % workload, "_bench_%s_under_trace.json" % workload))
+    try:
+        cfg = json.loads(open(beside).read().strip().splitlines()[-1])["config"]
+        return int(cfg["channels_per_gpu"]), int(cfg["samples_per_channel_per_step"])
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def profiled_counters(workload, channels, T, part0=False):
     """Counters of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot collect counters itself):
     HBM bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE (KiB, per-dispatch average; MI355X_MICROARCH.md), and the share of
-    the SIMDs' cycles on which a vector instruction issued.  Only for the configuration those passes were run on
-    (tools/profile_gpu.sh: 16 384 channels, 4 096 for the RRC-only configs); newest round first.
+    the SIMDs' cycles on which a vector instruction issued.  The passes name the configuration they ran on (_profile_config);
+    per-launch byte and instruction counts are proportional to channels x samples and are SCALED to this run's -- a summary
+    that does not say what it ran on is not used.  Newest round first.
     part0: the push goes out as two launches; take the lines of the first one (kernel template argument PART = 0)."""
-    want_B = 4096 if workload.startswith("rrc_gfsk") else 16384
-    if channels != want_B:
-        return {}
     pdir = os.path.join(ROOT, "profiles")
     kern = "k_rrc_tile" if workload.startswith("rrc_gfsk") else "k_chain"
     want = lambda line: kern in line and (not part0 or ", 10, 0>" in line)
     names = sorted((f for f in os.listdir(pdir) if f.endswith("_%s_pmc.txt" % workload) or (workload == "dmr_full" and f.endswith("_chain_pmc.txt"))), reverse=True)
     for name in names:
+        ran = _profile_config(pdir, name, workload)
+        if not ran:
+            continue
+        scale = (channels * float(T)) / (ran[0] * float(ran[1]))
         c = {}
         for line in open(os.path.join(pdir, name)):
             if want(line) and "avg=" in line:
@@ -91,8 +108,9 @@ def profiled_counters(workload, channels, T, part0=False):
                     if " %s " % key in line and key not in c:
                         c[key] = float(line.split("avg=")[1].split()[0])
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            out = {"traffic": c["FETCH_SIZE"] * 2.0 * 1024.0 + c["WRITE_SIZE"] * 1024.0,
-                   "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload)" % name}
+            out = {"traffic": (c["FETCH_SIZE"] * 2.0 * 1024.0 + c["WRITE_SIZE"] * 1024.0) * scale,
+                   "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this workload at %d channels x %d samples%s)"
+                                     % (name, ran[0], ran[1], "" if scale == 1.0 else ", scaled x%.4g to this run's size" % scale)}
             if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
                 out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
@@ -100,7 +118,7 @@ def profiled_counters(workload, channels, T, part0=False):
                 out["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
             for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA"):
                 if k in c:
-                    out[k.lower() + "_per_launch"] = c[k]
+                    out[k.lower() + "_per_launch"] = c[k] * scale
             return out
     return {}
 
@@ -108,23 +126,33 @@ def profiled_counters(workload, channels, T, part0=False):
 _COPY_GBS = {}
 
 
-def copy_ceiling(torch, device):
-    """What a plain streaming kernel reaches on this lease: a 2 GiB device-to-device copy (16 bytes per lane), read + write
-    bytes over its duration -- the achievable HBM ceiling SURVEY.md section 8(d) asks for beside the 8 TB/s of the data sheet."""
+def copy_ceiling(torch, device, ctx):
+    """What a plain streaming kernel reaches on this lease: the library's own copy kernel (dh_debug_copy: 16 bytes per lane,
+    non-temporal loads and stores) over 2 GiB, read + write bytes over its duration -- the achievable HBM ceiling SURVEY.md
+    section 8(d) asks for beside the 8 TB/s of the data sheet.  torch's copy_ on the same buffers is timed beside it; the
+    larger of the two is the ceiling (a ceiling below what some kernel reaches is not one)."""
     key = str(device)
     if key not in _COPY_GBS:
         n = 1 << 29                                  # floats: 2 GiB in, 2 GiB out
         a = torch.empty(n, dtype=torch.float32, device=device).normal_()
         b = torch.empty_like(a)
-        for _ in range(2):
-            b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            b.copy_(a)
-        e1.record()
-        e1.synchronize()
-        _COPY_GBS[key] = 5 * 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        stream = ctx.mem.stream()
+
+        def own():
+            assert ctx.lib.dh_debug_copy(ctx.mem.ptr(a), ctx.mem.ptr(b), n * 4, stream) == 0
+        rates = {}
+        for name, fn in (("dh_debug_copy", own), ("torch.Tensor.copy_", lambda: b.copy_(a))):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            e1.synchronize()
+            rates[name] = 5 * 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        assert bool((a[:: 4097] == b[:: 4097]).all())
+        _COPY_GBS[key] = (max(rates.values()), rates)
         del a, b
         torch.cuda.empty_cache()
     return _COPY_GBS[key]
@@ -392,7 +420,7 @@ class Job:
         mean = lambda a: float(np.mean(a)) if len(a) else None
         f16 = dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "wide" and kw["sps"] == 10
         bounded = f16 or (dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "narrow")
-        ceiling = copy_ceiling(self.torch, p["x"].device)
+        ceiling, ceiling_rates = copy_ceiling(self.torch, p["x"].device, p["eng"].ctx)
         if f16:
             what = ("vector instruction issue: the 81-tap FIR runs as a split-f16 product on the matrix cores (36 v_mfma_f32_16x16x32_f16 per 1024 "
                     "outputs, error radius carried, undecided comparisons re-evaluated with the reference's rounded arithmetic: bit-exact output); "
@@ -409,11 +437,73 @@ class Job:
                 "launch_group": group,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "peak_achievable": ceiling, "frac_of_achievable": achieved / ceiling,
-                "peak_achievable_source": "2 GiB device-to-device copy timed on this lease (read + write bytes)",
+                "peak_achievable_source": "2 GiB device-to-device copy timed on this lease (read + write bytes): the larger of the library's own "
+                                          "16-byte-per-lane non-temporal copy kernel (dh_debug_copy) and torch.Tensor.copy_",
+                "peak_achievable_rates": ceiling_rates,
                 "traffic": pc.get("traffic"), "traffic_source": pc.get("traffic_source"),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                 "co_limit": co}, \
                {"rrc": mean(rrc_ms), "slicer": mean(slicer_ms), "decoder": mean(dec_ms)}
+
+    def verify_timed(self, nv, pushes):
+        """What the TIMED engines produced in their last push -- the engines of Job.timed themselves, with whatever launch
+        path they took (tail split, overlapped pushes, two streams) -- for nv channels spread over every part, against the
+        oracle: the same rows as one stream of `pushes` identical pushes through the oracle, and of pushes - 1; what the
+        longer run has beyond the shorter one is the last push's output (dibits, decoder bytes, events, filtered floats).
+        Outside any timed region."""
+        import numpy as np
+        from oracle import oracle as O
+        if any("iq" in p for p in self.parts):
+            return None, None                       # (the front-end's state makes every push's floats different: Job.verify replays those)
+        ok, frame_bytes, worst, checked = True, 0, 0.0, 0
+        for p in self.parts:
+            kw, T, eng = p["kw"], p["T"], p["eng"]
+            n = min(nv, p["B"])
+            pick = [int(round(v)) for v in np.linspace(0, p["B"] - 1, n)]
+            xs = p["x"][self.torch.tensor(pick, device=p["x"].device)].cpu().numpy()
+            okw = oracle_kw(p["proto"])
+            if kw["proto"] == "none":
+                okw = dict(okw, proto=0)
+            threads = min(n, effective_cores()[1])
+            keep = bool(kw.get("keep_filtered"))
+            full = O.chain(np.tile(xs, (1, pushes)), threads=threads, keep_filtered=keep, **okw)
+            pre = O.chain(np.tile(xs, (1, pushes - 1)), threads=threads, **okw) if pushes > 1 else None
+            lo = (lambda key, b: int(pre[key][b])) if pre is not None else (lambda key, b: 0)
+            gs, gsc = eng.read_rows("symbols", pick)
+            if kw["proto"] != "none":
+                gf, gfc = eng.read_rows("frames", pick)
+                ge, gec = eng.read_rows("events", pick)
+            for j in range(n):
+                want = full["syms"][j, lo("sym_count", j):full["sym_count"][j]]
+                same = gsc[j] == len(want) and gs[j, :gsc[j]].tobytes() == want.tobytes()
+                if kw.get("fast_fir"):
+                    same = True                      # dibits are not guaranteed with the FMA FIR; the floats are checked below
+                ok &= bool(same)
+                if kw["proto"] != "none":
+                    wf = full["out"][j, lo("out_count", j):full["out_count"][j]]
+                    we = full["events"][j, lo("event_count", j):full["event_count"][j]]
+                    ok &= bool(gfc[j] == len(wf) and gf[j, :gfc[j]].tobytes() == wf.tobytes())
+                    if not kw.get("fast_fir"):
+                        # (event positions count from the start of the stream on both sides)
+                        ok &= bool(gec[j] == len(we) and ge[j, :gec[j]].tobytes() == we.tobytes())
+                    frame_bytes += int(gfc[j])
+            if keep:
+                y = eng.read_rows("filtered", pick)[0][:, :T]
+                r = full["filtered"][:, (pushes - 1) * T:]
+                if kw.get("fast_fir"):               # BASELINE.md section 4: 1e-6 relative to max(|ref|, rms(ref))
+                    rms = np.sqrt(np.mean(r.astype(np.float64) ** 2)) + 1e-30
+                    err = float(np.max(np.abs(y.astype(np.float64) - r) / np.maximum(np.abs(r), rms)))
+                    worst = max(worst, err)
+                    ok &= err <= 1e-6
+                else:
+                    ok &= bool((y.view(np.uint32) == r.view(np.uint32)).all())
+            checked += n
+        out = {"what": "the timed engines' own last push (push %d of %d identical pushes since reset) against the oracle run over the same stream" % (pushes, pushes),
+               "channels": checked, "sampling": "evenly spread over the batch", "pushes": pushes,
+               "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir"), "frame_bytes": frame_bytes}
+        if self.kw.get("fast_fir"):
+            out.update({"within_1e-6_vs_oracle": bool(ok), "max_rel_err": worst})
+        return bool(ok), out
 
     def verify(self, ctx, nv, reps=2):
         """Replay the first nv channels of every part from reset on a small engine and on the oracle (outside any timed
@@ -475,8 +565,11 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
     """The remaining single-GPU BASELINE configs on the same lease (each its own engines, inputs resident, same timing
     method as the headline)."""
     out = []
+    # ("mixed", (4096, 4096)) is one GPU's share of BASELINE configs[4] (65 536 channels over 8 GPUs), ("dmr_full", 8192) its
+    # share of the north-star target (65 536 DMR channels over 8 GPUs)
     for workload, channels, overlap, streams in (("rrc_gfsk", 4096, False, 1), ("rrc_gfsk_fast", 4096, False, 1), ("ysf_full", 16384, False, 1),
                                                  ("mixed", (8192, 8192), False, 1), ("mixed", (8192, 8192), False, 2),
+                                                 ("mixed", (4096, 4096), False, 1), ("mixed", (4096, 4096), False, 2), ("dmr_full", 8192, False, 1),
                                                  ("dmr_full", 16384, True, 1), ("ysf_full", 16384, True, 1)):
         t_start = time.perf_counter()
         job = Job(torch, ctx, device, workload, channels, rank=0, overlap=overlap, streams=streams)
@@ -491,8 +584,8 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
                  "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "traffic": roof["traffic"], "traffic_source": roof["traffic_source"],
                  "stage_ms": stage}
         if verify:
-            ok, entry["verified"] = job.verify(ctx, min(verify, 4))
-            assert ok, "GPU output differs from the oracle (%s)" % workload
+            ok, entry["verified"] = job.verify_timed(verify, steps + warmup)
+            assert ok, "GPU output of the timed engines differs from the oracle (%s)" % entry["workload"]
         job.close()
         del job
         torch.cuda.empty_cache()
@@ -553,9 +646,11 @@ def main():
     roof, stage = job.roofline(args.split_stages, step_ms=dt / args.steps * 1e3)
 
     verified = None
-    if args.verify and not (job.kw["proto"] == "none" and not job.kw.get("keep_filtered")):
-        ok, verified = job.verify(ctx, args.verify)
-        assert ok, "GPU output differs from the oracle"
+    if args.verify:
+        ok, verified = job.verify_timed(args.verify, args.steps + args.warmup)
+        if ok is None and not (job.kw["proto"] == "none" and not job.kw.get("keep_filtered")):
+            ok, verified = job.verify(ctx, args.verify)          # front-end workloads: a replay on a fresh small engine
+        assert ok is not False, "GPU output differs from the oracle"
 
     if rank == 0:
         rate = samples_all / dt_max

@@ -54,6 +54,7 @@ def declare(L, lenient=False):
         "dh_debug_div_const": [vp, vp, sz, C.c_uint, vp],
         "dh_debug_mfma_f16": [vp, vp, vp, vp, sz, vp],
         "dh_debug_f16_split": [vp, vp, vp, sz, C.c_float, vp],
+        "dh_debug_copy": [vp, vp, sz, vp],
         "dh_engine_create": [C.POINTER(EngineConfig), C.POINTER(vp)],
         "dh_engine_reset": [vp], "dh_engine_set_slot_filter": [vp, u32],
         "dh_engine_reset_channel": [vp, u32], "dh_engine_set_slot_filter_channel": [vp, u32, u32],
@@ -88,7 +89,7 @@ EXPORTED_SYMBOLS = [
     "dh_version", "dh_last_error", "dh_device_count", "dh_device_alloc", "dh_device_free", "dh_copy_to_host",
     "dh_copy_to_device", "dh_hamming_7_4", "dh_hamming_13_9", "dh_hamming_15_11", "dh_hamming_16_11",
     "dh_quadratic_residue", "dh_golay_20_8", "dh_golay_24_12", "dh_bch_31_21", "dh_bptc_196_96", "dh_trellis", "dh_crc16",
-    "dh_whitening", "dh_dvfilter_s16", "dh_frontend_s16", "dh_debug_div_gain", "dh_debug_div_const", "dh_debug_mfma_f16", "dh_debug_f16_split", "dh_engine_create", "dh_engine_destroy", "dh_engine_reset",
+    "dh_whitening", "dh_dvfilter_s16", "dh_frontend_s16", "dh_debug_div_gain", "dh_debug_div_const", "dh_debug_mfma_f16", "dh_debug_f16_split", "dh_debug_copy", "dh_engine_create", "dh_engine_destroy", "dh_engine_reset",
     "dh_engine_set_slot_filter", "dh_engine_reset_channel", "dh_engine_set_slot_filter_channel", "dh_engine_push", "dh_engine_push_host", "dh_engine_push_ragged", "dh_engine_push_host_ragged", "dh_engine_push_symbols",
     "dh_engine_filtered", "dh_engine_symbols", "dh_engine_frames", "dh_engine_events", "dh_engine_read_symbols",
     "dh_engine_read_frames", "dh_engine_read_events", "dh_engine_read_filtered", "dh_engine_sync",

@@ -350,6 +350,32 @@ class Engine:
         rows, _ = self._fetch(self.ctx.lib.dh_engine_filtered, np.float32, with_counts=False)
         return rows
 
+    def read_rows(self, what, channels):
+        """The current push's rows of the given channels only: what = "symbols" | "frames" | "events" -> (rows [len(channels)][stride],
+        counts [len(channels)]); "filtered" -> (rows, None).  For looking at a few channels of a large engine (bench.py checks the
+        engine it has just timed) without copying every row to the host."""
+        lib = self.ctx.lib
+        getter, dt = {"symbols": (lib.dh_engine_symbols, np.dtype(np.uint8)), "frames": (lib.dh_engine_frames, np.dtype(np.uint8)),
+                      "events": (lib.dh_engine_events, EVENT_DTYPE), "filtered": (lib.dh_engine_filtered, np.dtype(np.float32))}[what]
+        p, stride, cnt = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        if what == "filtered":
+            _check(getter(self._h, C.byref(p), C.byref(stride)), getter.__name__, lib)
+        else:
+            _check(getter(self._h, C.byref(p), C.byref(stride), C.byref(cnt)), getter.__name__, lib)
+        self.sync()
+        channels = [int(c) for c in channels]
+        rows = np.empty((len(channels), stride.value), dt)
+        row_bytes = stride.value * dt.itemsize
+        for j, b in enumerate(channels):
+            if not 0 <= b < self.B:
+                raise ValueError("Engine.read_rows: channel %d of %d" % (b, self.B))
+            _check(lib.dh_copy_to_host(rows[j].ctypes.data_as(C.c_void_p), C.c_void_p(p.value + b * row_bytes), row_bytes), "dh_copy_to_host", lib)
+        if what == "filtered":
+            return rows, None
+        counts = np.empty(self.B, np.uint32)
+        _check(lib.dh_copy_to_host(counts.ctypes.data_as(C.c_void_p), cnt, counts.nbytes), "dh_copy_to_host", lib)
+        return rows, counts[channels]
+
     def device_views(self):
         """Raw device pointers of the output buffers (for zero-copy consumers)."""
         lib = self.ctx.lib

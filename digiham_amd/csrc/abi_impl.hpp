@@ -90,6 +90,11 @@ int dh_debug_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, fl
     return dh_be_f16_split(in, h1, h2, n, scale, s);
 }
 
+int dh_debug_copy(const void* src, void* dst, size_t n_bytes, void* s) {
+    if (((!src || !dst) && n_bytes) || (n_bytes & 15u) || (((uintptr_t) src | (uintptr_t) dst) & 15u)) return DH_EINVAL;
+    return dh_be_copy_kernel(src, dst, n_bytes, s);
+}
+
 int dh_engine_create(const dh_engine_config* cfg, dh_engine** out) {
     if (!cfg || !out) return DH_EINVAL;
     *out = nullptr;

@@ -50,7 +50,7 @@ enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED
        DH_ST_BLOCK_FLAGS = 11,       // bit 0: the current block's start is known, bit 1: the previous block's
        DH_ST_E_CUR = 12, DH_ST_E_PREV = 13, DH_ST_E_COUNT = 14, DH_ST_E_BLOCK = 15,          // error radii of the ring entries (floats), symbols in the current bucket
        DH_ST_UNCERTAIN = 16, DH_ST_EXACT_RUNS = 17, DH_ST_EXACT_BLOCKS = 18,                    // statistics: symbols / runs / timing blocks decided by exact arithmetic
-       DH_ST_PART = 19,              // tail split (k_chain): epoch of the last push whose first part has been written back | XCC id << 28
+       DH_ST_PART = 19,              // tail split (k_chain): epoch of the last split push (24 bits) | parts written back << 24 | a later part gave up << 26 | XCC id << 28
        DH_ST_DIAG = 20 };            // 20..31: diagnostic builds (phase clocks 20..27, wave timeline 28..31)
 #define DH_ST_VOL DH_STATE_HDR
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
@@ -80,6 +80,11 @@ struct DhDspParams {
     // k * split_pad + channel takes the samples [0, split_n0), [split_n0, split_n1 or the end), [split_n1, end) of the
     // channel's row for k = 0, 1, 2.  split_n0 = 0: one workgroup per channel; split_n1 = 0: two.
     uint32_t split_n0, split_n1, split_pad, part_epoch;
+    // split_fixup = 1: the launch BEHIND a split launch, one workgroup per channel -- a channel whose later parts did not get
+    // their hand-over (flag never came, or came from another XCD) is finished here, unsplit, from where its last completed part
+    // stopped; every other workgroup leaves at once.  split_force_fail = k > 0 (tests: DH_TAIL_SPLIT_FORCE_FAIL): the later parts
+    // of the channels with ch % k == 1 give up without looking.
+    uint32_t split_fixup, split_force_fail;
 };
 
 DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }

@@ -87,29 +87,54 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     // workgroups of a channel run on the same XCD (workgroup i goes to XCD i mod 8, split_pad is a multiple of 8), so a
     // part's stores only have to reach that XCD's L2 (s_waitcnt, no write-back) and the next part only has to drop its
     // CU's L1 / scalar cache; the flag word carries the epoch of the push, the number of parts written back and the XCC
-    // id, and a part that finds another XCC id, or no flag at all, reports an error instead of reading stale state.
+    // id.  None of this is promised by HIP: HipBackend::open probes the placement once per device and switches the split off
+    // where it does not hold, and a part that finds another XCC id, or no flag within its patience, touches nothing and
+    // leaves -- the fix-up launch that follows every split launch (split_fixup, below) then finishes that channel's row.
     uint32_t bid = blockIdx.x, part = 0, sym_base = 0, part_lo = 0, part_hi = 0xFFFFFFFFu;
     const uint32_t last_part = P.split_n0 ? (P.split_n1 ? 2u : 1u) : 0u;
-    if (P.split_n0) {
+    if (P.split_n0 && !P.split_fixup) {
         while (part < last_part && bid >= P.split_pad) { part++; bid -= P.split_pad; }
         if (bid >= P.n_channels) return;                // padding between the parts of the grid
         part_lo = part == 0 ? 0u : part == 1 ? P.split_n0 : P.split_n1;
         part_hi = part == 0 ? P.split_n0 : (part == 1 && P.split_n1) ? P.split_n1 : 0xFFFFFFFFu;
     }
     const uint32_t ch = bid + P.ch_base;
-    // flag word: epoch of the push (24 bits) | parts written back << 24 | XCC id << 28
+    // flag word: epoch of the push (24 bits) | parts written back << 24 | a later part gave up << 26 | XCC id << 28
     uint32_t* const part_flag = reinterpret_cast<uint32_t*>(P.state) + (size_t) ch * P.state_stride + DH_ST_PART;
-    if (part) {
+    if (P.split_n0 && P.split_fixup) {
+        // The launch behind a split launch (HipBackend::go_chain), one workgroup per channel.  The kernel boundary in front of
+        // it has made everything the split launch stored visible; a channel whose flag word says that all parts were written
+        // back -- every channel, unless a hand-over failed -- is left alone.  Otherwise the rest of the row is done here in
+        // one piece, starting behind the last part that was completed.
+        const uint32_t v = dh_uniform(__hip_atomic_load(part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const uint32_t done = (v & 0x00FFFFFFu) == P.part_epoch ? ((v >> 24) & 3u) : 0u;
+        if (done > last_part) return;
+        part = done;
+        part_lo = part == 0 ? 0u : part == 1 ? P.split_n0 : P.split_n1;
+        if (part) sym_base = dh_uniform(__hip_atomic_load(P.sym_count + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else if (part) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;      // HW_REG_XCC_ID
         bool ok = false;
-        for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+        const bool forced = P.split_force_fail && ch % P.split_force_fail == 1u;     // (tests: this hand-over "fails")
+        for (uint32_t spin = 0; spin < (1u << 16) && !forced; spin++) {                 // (a first part takes ~1.5 ms; 2^16 x ~2 us)
             const uint32_t v = dh_uniform(__hip_atomic_load(part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if ((v & 0x00FFFFFFu) == P.part_epoch && ((v >> 24) & 3u) >= part) { ok = (v >> 28) == xcc; break; }
+            if ((v & 0x00FFFFFFu) == P.part_epoch) {
+                if (v & (1u << 26)) break;                                               // the part in front of this one gave up
+                if (((v >> 24) & 3u) >= part) { ok = (v >> 28) == xcc; break; }
+            }
             __builtin_amdgcn_s_sleep(64);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // buffer_inv: this CU's L1 holds nothing older than the flag
         __builtin_amdgcn_s_dcache_inv();
-        if (!ok) { if (threadIdx.x == 0 && P.overflow) P.overflow[1] = 1u; return; }      // (never seen; the push then reports DH_EDEVICE)
+        if (!ok) {
+            // No hand-over (never seen on an MI355X in SPX mode, where the probe of HipBackend::open holds): nothing of this
+            // channel has been touched by this workgroup, the fix-up launch behind this one finishes the row.
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_or(part_flag, 1u << 26, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.overflow) __hip_atomic_fetch_add(P.overflow + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a statistic: dh_engine_debug_header(202))
+            }
+            return;
+        }
         sym_base = dh_uniform(__hip_atomic_load(P.sym_count + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     {
@@ -136,8 +161,10 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     // (which part this is, and its flag word, worked out again: nothing of the hand-over stays live through the two halves)
     uint32_t part_end = 0, bid_end = blockIdx.x;
     DH_OPAQUE_SGPR(bid_end);
-    while (P.split_n0 && part_end < (P.split_n1 ? 2u : 1u) && bid_end >= P.split_pad) { part_end++; bid_end -= P.split_pad; }
-    if (P.split_n0 && part_end < (P.split_n1 ? 2u : 1u)) {
+    const uint32_t last_end = P.split_n0 ? (P.split_n1 ? 2u : 1u) : 0u;
+    if (P.split_n0 && P.split_fixup) part_end = last_end;                                 // the fix-up launch finishes the row
+    else while (P.split_n0 && part_end < last_end && bid_end >= P.split_pad) { part_end++; bid_end -= P.split_pad; }
+    if (P.split_n0 && (part_end < last_end || P.split_fixup)) {
         uint32_t* const flag_end = reinterpret_cast<uint32_t*>(P.state) + (size_t) (bid_end + P.ch_base) * P.state_stride + DH_ST_PART;
         // everything this workgroup stored is in the XCD's L2 before the flag is
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -195,6 +222,11 @@ __global__ __launch_bounds__(DH_WAVE) void k_pocsag(const DhDecParams P) {
 __global__ __launch_bounds__(DH_WAVE, DH_DSTAR_LB) void k_dstar(const DhDecParams P) {
     __shared__ DhDecShared S;
     dh_dstar_channel(P, blockIdx.x, S);
+}
+
+// which XCD workgroup i of a launch runs on (HipBackend::tail_split_probe)
+__global__ __launch_bounds__(DH_WAVE) void k_xcc_probe(uint32_t* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;       // HW_REG_XCC_ID
 }
 
 __global__ void k_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
@@ -307,6 +339,8 @@ __global__ __launch_bounds__(64) void k_fe_dcblock(const int16_t* in, size_t in_
 #define DH_FE_TS 128
 #endif
 #define DH_FE_SPT (DH_FE_CH * DH_FE_TS / 256)          // samples a thread converts per tile (a multiple of 4)
+// (four dwords from a row that is only promised to be 4-byte aligned: the plain vector type would tell the compiler 16)
+typedef uint32_t dh_u4w __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(320) void k_fe_fused(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // five wavefronts: the first runs the recurrence of tile k while the other four convert tile k + 1 into the second buffer
@@ -331,7 +365,7 @@ __global__ __launch_bounds__(320) void k_fe_fused(const int16_t* in, size_t in_s
             uint32_t w[DH_FE_SPT + 1];                           // the pair before the first sample, then this thread's pairs
             const uint32_t* p32 = reinterpret_cast<const uint32_t*>(row + 2 * t);
 #pragma unroll
-            for (int j = 0; j < DH_FE_SPT / 4; j++) { const dh_u4 v = *reinterpret_cast<const dh_u4*>(p32 + 4 * j); w[1 + 4 * j] = v[0]; w[2 + 4 * j] = v[1]; w[3 + 4 * j] = v[2]; w[4 + 4 * j] = v[3]; }
+            for (int j = 0; j < DH_FE_SPT / 4; j++) { const dh_u4w v = *reinterpret_cast<const dh_u4w*>(p32 + 4 * j); w[1 + 4 * j] = v[0]; w[2 + 4 * j] = v[1]; w[3 + 4 * j] = v[2]; w[4 + 4 * j] = v[3]; }
             w[0] = t ? p32[-1] : (((uint32_t) (uint16_t) (int16_t) qp0) << 16) | (uint16_t) (int16_t) ip0;
 #pragma unroll
             for (int j = 0; j < DH_FE_SPT; j++) {
@@ -343,7 +377,7 @@ __global__ __launch_bounds__(320) void k_fe_fused(const int16_t* in, size_t in_s
             const uint32_t* p32 = reinterpret_cast<const uint32_t*>(row + t);           // eight samples per 16-byte load
 #pragma unroll
             for (int j = 0; j < DH_FE_SPT / 8; j++) {
-                const dh_u4 v = *reinterpret_cast<const dh_u4*>(p32 + 4 * j);
+                const dh_u4w v = *reinterpret_cast<const dh_u4w*>(p32 + 4 * j);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     tile[c][s0 + 8 * j + 2 * k] = (float) (int16_t) (v[k] & 0xFFFFu) * 0.000030517578125f;
@@ -440,6 +474,20 @@ __global__ void k_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t 
 #endif
 }
 
+// dh_debug_copy: the streaming ceiling of the lease (16 bytes per lane, non-temporal both ways, four pieces in flight per lane)
+typedef uint32_t dh_u4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const dh_u4s* __restrict__ src, dh_u4s* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const dh_u4s a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const dh_u4s c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 inline unsigned grid_for(size_t n, unsigned block) {
     const size_t g = (n + block - 1) / block;
     return (unsigned) (g < 1 ? 1 : (g > 8192 ? 8192 : g));      // 256 CUs x 32 resident workgroups, grid-stride beyond
@@ -492,11 +540,15 @@ struct HipBackend {
         if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) return DH_ENODEV;
         if (dev < 0 || dev >= count) return DH_EINVAL;
         device = dev; stream = (hipStream_t) s;
+        if (!tail_split_probe()) tail_split_pct = 0;              // workgroup i does not run on XCD i mod 8 here (another part, a partitioned one): one workgroup per channel
+        if (const char* e = std::getenv("DH_TAIL_SPLIT_FORCE_FAIL")) tail_split_force_fail = (uint32_t) std::strtoul(e, nullptr, 10);     // tests: see DhDspParams
         if (const char* e = std::getenv("DH_TAIL_SPLIT")) {       // "80" or "75,93" (percent of a push where the second / third workgroup of a channel starts), "0" = off
             char* end = nullptr;
             const long v = std::strtol(e, &end, 10), w = end && *end == ',' ? std::strtol(end + 1, nullptr, 10) : 0;
-            tail_split_pct = v > 0 && v < 100 ? (uint32_t) v : 0u;
-            tail_split_pct2 = tail_split_pct && w > v && w < 100 ? (uint32_t) w : 0u;
+            if (tail_split_pct) {                   // (the probe's verdict stands: the environment can only move the split point, or switch it off)
+                tail_split_pct = v > 0 && v < 100 ? (uint32_t) v : 0u;
+                tail_split_pct2 = tail_split_pct && w > v && w < 100 ? (uint32_t) w : 0u;
+            }
         }
         return DH_OK;
     }
@@ -524,7 +576,33 @@ struct HipBackend {
     bool overlap_pushes = false;
     // tail split of the chain launches (go_chain): share of a push, in percent, that the first workgroup of a channel
     // takes; 0 = off.  DH_TAIL_SPLIT in the environment overrides it when the engine is created (A/B runs).
-    uint32_t tail_split_pct = DH_TAIL_SPLIT_PCT, tail_split_pct2 = DH_TAIL_SPLIT_PCT2, part_epoch = 0;
+    uint32_t tail_split_pct = DH_TAIL_SPLIT_PCT, tail_split_pct2 = DH_TAIL_SPLIT_PCT2, part_epoch = 0, tail_split_force_fail = 0;
+    // What the tail split's cheap hand-over rests on, checked once per device and process: the part is a gfx950 and the
+    // workgroups of a launch land on XCD (index mod 8) -- a probe launch of 4 096 workgroups records HW_REG_XCC_ID per index.
+    // (Dispatch in index order cannot be probed; a hand-over that does not come is caught at run time, see k_chain.)
+    bool tail_split_probe() {
+        static std::mutex m; static int verdict[64] = { 0 };         // 0 unknown, 1 holds, -1 does not
+        if (device < 0 || device >= 64) return false;
+        std::lock_guard<std::mutex> lock(m);
+        if (verdict[device]) return verdict[device] > 0;
+        verdict[device] = -1;
+        Scope on_device(device);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { (void) hipGetLastError(); return false; }
+        constexpr uint32_t N = 4096;
+        uint32_t* d = nullptr; std::vector<uint32_t> h(N, 0xFFu);
+        if (hipMalloc((void**) &d, sizeof(uint32_t) * N) != hipSuccess) { (void) hipGetLastError(); return false; }
+        hipLaunchKernelGGL(k_xcc_probe, dim3(N), dim3(DH_WAVE), 0, stream, d);
+        const bool ran = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess &&
+                         hipMemcpy(h.data(), d, sizeof(uint32_t) * N, hipMemcpyDeviceToHost) == hipSuccess;
+        (void) hipFree(d);
+        if (!ran) { (void) hipGetLastError(); return false; }
+        bool ok = true;
+        for (uint32_t i = 0; i < N && ok; i++) ok = h[i] < 8u && h[i] == h[i & 7u];
+        for (uint32_t i = 0; i < 8 && ok; i++) for (uint32_t j = 0; j < i; j++) ok = ok && h[i] != h[j];      // eight XCDs, each index class its own
+        verdict[device] = ok ? 1 : -1;
+        return ok;
+    }
     hipStream_t side = nullptr, side_lo = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_lo = nullptr;
     bool side_failed = false, join_pending = false;
@@ -566,6 +644,9 @@ struct HipBackend {
     int upload(void* dst, const void* src, size_t bytes) {
         // pageable source: hipMemcpyAsync stages it before returning, so the caller may free `src`
         return hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ms()), "hipMemcpyAsync(H2D)");
+    }
+    int copy_device(void* dst, const void* src, size_t bytes) {
+        return hip_fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ms()), "hipMemcpyAsync(D2D)");
     }
     int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
         if (!width || !rows) return 0;
@@ -696,8 +777,15 @@ struct HipBackend {
                 Q.split_pad = (P.n_channels + 7u) & ~7u;
                 part_epoch = (part_epoch % 0x00FFFFFEu) + 1u;
                 Q.part_epoch = part_epoch;
+                Q.split_force_fail = tail_split_force_fail;
                 hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 0>), dim3((Q.split_n1 ? 2u : 1u) * Q.split_pad + P.n_channels), dim3(DH_WAVE), lds, ms(), Q, D);
-                return launched("k_chain");
+                if (launched("k_chain")) return -1;
+                // The fix-up launch (PART 1 only names it for profilers): one workgroup per channel looks at the channel's flag
+                // word and leaves -- a few microseconds for the whole grid -- unless a hand-over of the launch above failed, in
+                // which case it finishes that row unsplit.  Stream order makes it see everything the split launch stored.
+                Q.split_fixup = 1u;
+                hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 1>), dim3(P.n_channels), dim3(DH_WAVE), lds, ms(), Q, D);
+                return launched("k_chain (fix-up)");
             }
         }
         hipLaunchKernelGGL((k_chain<NZ, FAST, PROTO, SPS, 0>), dim3(P.n_channels), dim3(DH_WAVE), lds, ms(), P, D);
@@ -877,6 +965,15 @@ static int dh_be_mfma_f16(const uint16_t* a, const uint16_t* b, const float* c, 
 static int dh_be_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, float scale, void* stream) {
     if (!n) return DH_OK;
     hipLaunchKernelGGL(k_f16_split, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t) stream, in, h1, h2, n, scale);
+    HIP_TRY(hipGetLastError());
+    return DH_OK;
+}
+
+static int dh_be_copy_kernel(const void* src, void* dst, size_t n_bytes, void* stream) {
+    if (!n_bytes) return DH_OK;
+    const size_t n16 = n_bytes / 16;
+    const unsigned grid = (unsigned) std::min<size_t>((n16 + 255) / 256, 2048);      // 256 CUs x 8 resident workgroups of 256
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, (hipStream_t) stream, (const dh_u4s*) src, (dh_u4s*) dst, n16);
     HIP_TRY(hipGetLastError());
     return DH_OK;
 }

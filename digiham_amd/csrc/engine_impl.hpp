@@ -84,6 +84,7 @@ inline void fill_taps(int rrc, float* half, double* gain) {
 //   void* alloc(size_t bytes); void free(void*);
 //   int zero(void* p, size_t bytes);                       // async on the engine stream
 //   int upload(void* dst, const void* src, size_t bytes);  // host -> device, async
+//   int copy_device(void* dst, const void* src, size_t bytes);  // device -> device, async on the engine stream
 //   int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);  // synchronous
 //   int launch_chain(const DhDspParams&, const DhDecParams&, uint32_t nz, bool fast, int proto);   // 1 = unavailable
 //   int upload2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
@@ -115,6 +116,7 @@ struct Engine {
     float* filtered = nullptr; float* rrc_hist = nullptr;
     float* staging = nullptr;            // push_host staging [B][max_samples]
     uint32_t* staging_counts = nullptr;  // ... and the per-channel counts of a ragged host push
+    uint32_t* counts_copy = nullptr;     // the counts of the last ragged push of an engine that keeps its filtered samples
     const uint32_t* last_counts = nullptr;       // per-channel sample counts of the last push (device), or null
     DhFecTables* tables = nullptr;
     uint32_t* zero_counts = nullptr;
@@ -178,7 +180,7 @@ struct Engine {
 
     void destroy() {
         void* ptrs[] = { dsp_state, syms, sym_count, sym_carry, dec_state, frames, frame_count, events, ev_count,
-                         overflow, filtered, rrc_hist, staging, staging_counts, tables, custom_taps, tapfrag };
+                         overflow, filtered, rrc_hist, staging, staging_counts, counts_copy, tables, custom_taps, tapfrag };
         for (void* p : ptrs) if (p) be.free(p);
     }
 
@@ -237,8 +239,15 @@ struct Engine {
     int push(const float* d_in, size_t stride, size_t n, const uint32_t* d_counts = nullptr) {
         if ((!d_in && n) || n > L.max_samples || stride < n) return DH_EINVAL;
         if (d_counts && L.rrc == DH_RRC_CUSTOM) return DH_EINVAL;          // (the generic FIR takes whole pushes only)
-        last_counts = d_counts;
         if (!L.rrc && !L.demod) return DH_EINVAL;
+        // what dh_engine_read_filtered needs to know later is kept in a buffer of the engine's own: the caller's counts only
+        // have to live as long as the sample rows (until the push has run)
+        last_counts = nullptr;
+        if (d_counts && filtered) {
+            if (!counts_copy) { counts_copy = (uint32_t*) be.alloc(sizeof(uint32_t) * L.B); if (!counts_copy) return DH_ENOMEM; }
+            if (be.copy_device(counts_copy, d_counts, sizeof(uint32_t) * L.B)) return DH_EDEVICE;
+            last_counts = counts_copy;
+        }
         // an empty push is a module call with nothing readable: it runs (zero outputs, state untouched) and never
         // dereferences the sample pointer, which may then be null
         if (!d_in) d_in = reinterpret_cast<const float*>(overflow);
@@ -316,14 +325,17 @@ struct Engine {
     // decoder-only engines: the caller's symbol rows are read in place
     int push_symbols(const uint8_t* d_syms, size_t stride, const uint32_t* d_count) {
         if (!L.proto || L.demod || !d_syms || !d_count) return DH_EINVAL;
+        last_counts = nullptr;
         fill_dec_params(d_syms, stride, d_count);
         return be.launch_decoder(dec, L.proto) ? DH_EDEVICE : DH_OK;
     }
 
     int check_overflow() {
-        uint32_t flag[2] = { 0, 0 };                     // [0] a capacity was hit, [1] a split push's hand-over failed (k_chain)
-        if (be.download(flag, overflow, sizeof(flag))) return DH_EDEVICE;
-        return flag[1] ? DH_EDEVICE : flag[0] ? DH_ECAPACITY : DH_OK;
+        // [0] a capacity was hit.  ([2] counts hand-overs of split launches that did not come -- not an error: the fix-up
+        // launch behind every split launch finished those rows; dh_engine_debug_header(e, 202, ...) reads it.)
+        uint32_t flag = 0;
+        if (be.download(&flag, overflow, sizeof(flag))) return DH_EDEVICE;
+        return flag ? DH_ECAPACITY : DH_OK;
     }
 
     // per-channel header words of the slicer state: timing blocks evaluated / decided by the ordered chain
@@ -336,6 +348,13 @@ struct Engine {
     }
 
     int debug_header(uint32_t word, uint32_t* h_out) {
+        if (word >= 200u) {                                  // 200 + w: word w of the engine's flag block, the same for every channel
+            if (word - 200u >= 16u || !h_out) return DH_EINVAL;
+            uint32_t v = 0;
+            if (be.download(&v, overflow + (word - 200u), sizeof(v))) return DH_EDEVICE;
+            for (uint32_t b = 0; b < L.B; b++) h_out[b] = v;
+            return DH_OK;
+        }
         if (word >= 100u) {                                  // 100 + w: word w of the decoder state
             if (!dec_state || word - 100u >= DH_DEC_STATE_WORDS || !h_out) return DH_EINVAL;
             return be.download2d(h_out, sizeof(uint32_t), dec_state + (word - 100u), sizeof(uint32_t) * DH_DEC_STATE_WORDS, sizeof(uint32_t), L.B) ? DH_EDEVICE : DH_OK;

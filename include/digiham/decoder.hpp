@@ -37,7 +37,8 @@ namespace Digiham {
             void process() override {
                 std::lock_guard<std::mutex> lock(processMutex);
                 if (shared()) {                        // one engine for every decoder instance of the process (shared_engine.hpp)
-                    bank->wantEvents = bank->wantEvents || onEvent || metaCollector;
+                    const bool want = (bool) onEvent || metaCollector != nullptr;
+                    if (want != wantsEvents) { bank->setWantEvents(slot, want); wantsEvents = want; }
                     deliver();
                     if (bank->hasPending(slot)) { bank->settle(slot); deliver(); return; }
                     if (bank->hasOutput(slot)) return;
@@ -95,9 +96,8 @@ namespace Digiham {
                 if (!decided) {
                     decided = true;
                     if (Amd::SharedEngine::enabled()) {
-                        bank = Amd::SharedEngine::forKind(Amd::SharedEngine::DECODER, DH_RRC_NONE, DH_DEMOD_NONE, 0, proto, 0);
-                        slot = bank->attach();
-                        if (proto == DH_PROTO_DMR && slotFilter != 3) bank->setSlotFilter(slot, slotFilter);
+                        bank = Amd::SharedEngine::join(Amd::SharedEngine::DECODER, DH_RRC_NONE, DH_DEMOD_NONE, 0, proto, 0, slot);
+                        if (bank && proto == DH_PROTO_DMR && slotFilter != 3) bank->setSlotFilter(slot, slotFilter);
                     }
                 }
                 return (bool) bank;
@@ -108,15 +108,17 @@ namespace Digiham {
             void deliver() {
                 const size_t n = bank->take(slot, writer->getWritePointer(), writer->writeable());
                 if (n) writer->advance(n);
+                // (always taken, consumer or not: events left in the slot would count as undelivered output for ever)
+                const std::vector<dh_event> evs = bank->takeEvents(slot);
                 if (onEvent || metaCollector) {
-                    for (const dh_event& e : bank->takeEvents(slot)) {
+                    for (const dh_event& e : evs) {
                         if (metaCollector) metaCollector->consume(e);
                         if (onEvent) onEvent(e);
                     }
                     if (metaCollector) metaCollector->flush();
                 }
             }
-            bool decided = false;
+            bool decided = false, wantsEvents = false;
             static constexpr size_t chunk = 16384;
             // a call may emit one voice payload per 144-symbol burst (DMR, 27 bytes), 95 bytes per 480-symbol frame (YSF)
             // or 36 bytes per 192-symbol frame (NXDN); a POCSAG page line can take up to about half a byte per input bit

@@ -48,7 +48,7 @@ namespace Digiham {
                     // (n + sps + 1) / (sps - 1) + 1 <= n / (sps - 1) + 3 symbols
                     size_t n = reader->available();
                     size_t room = writer->writeable();
-                    size_t cap = (room - 3) * (samplesPerSymbol - 1);
+                    size_t cap = room > 3 ? (room - 3) * (samplesPerSymbol - 1) : 0;      // (a call without canProcess(): nothing fits)
                     if (n > cap) n = cap;
                     if (n > chunk) n = chunk;
                     if (n == 0) return;
@@ -65,8 +65,7 @@ namespace Digiham {
                     if (!decided) {
                         decided = true;
                         if (Amd::SharedEngine::enabled()) {
-                            bank = Amd::SharedEngine::forKind(Amd::SharedEngine::SLICER, DH_RRC_NONE, levels, samplesPerSymbol, DH_PROTO_NONE, invert ? DH_FLAG_FSK_INVERT : 0);
-                            slot = bank->attach();
+                            bank = Amd::SharedEngine::join(Amd::SharedEngine::SLICER, DH_RRC_NONE, levels, samplesPerSymbol, DH_PROTO_NONE, invert ? DH_FLAG_FSK_INVERT : 0, slot);
                         }
                     }
                     return (bool) bank;

@@ -69,8 +69,7 @@ namespace Digiham {
                     if (!decided) {
                         decided = true;
                         if (kind != DH_RRC_CUSTOM && Amd::SharedEngine::enabled()) {
-                            bank = Amd::SharedEngine::forKind(Amd::SharedEngine::RRC, kind, DH_DEMOD_NONE, 0, DH_PROTO_NONE, DH_FLAG_KEEP_FILTERED);
-                            slot = bank->attach();
+                            bank = Amd::SharedEngine::join(Amd::SharedEngine::RRC, kind, DH_DEMOD_NONE, 0, DH_PROTO_NONE, DH_FLAG_KEEP_FILTERED, slot);
                         }
                     }
                     return (bool) bank;

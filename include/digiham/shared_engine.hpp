@@ -41,9 +41,14 @@ namespace Digiham {
                 // launches (ticks) of every bank of the process so far: what a test counts
                 static unsigned long ticksTotal() { std::lock_guard<std::mutex> l(registryMutex()); unsigned long t = 0; for (auto& kv : registry()) if (auto p = kv.second.lock()) t += p->ticks; return t; }
 
-                // the bank for this kind of module (created on first use, destroyed with its last instance)
-                static std::shared_ptr<SharedEngine> forKind(Stage stage, int rrc, int demod, unsigned int sps, int proto, unsigned int flags) {
+                // The bank for this kind of module (created on first use, destroyed with its last instance) AND a slot in it, taken
+                // under the registry lock: two threads asking at once cannot both be handed the last free slot of a bank, and a
+                // disable() in between cannot make this construct an engine of capacity 0 (null bank: the caller runs its own
+                // 1-channel engine, as without sharing).
+                static std::shared_ptr<SharedEngine> join(Stage stage, int rrc, int demod, unsigned int sps, int proto, unsigned int flags, int& slot) {
                     std::lock_guard<std::mutex> l(registryMutex());
+                    slot = -1;
+                    if (capacityRef() == 0) return nullptr;
                     const auto key = std::make_tuple((int) stage, rrc, demod, sps, proto, flags);
                     auto& weak = registry()[key];
                     auto bank = weak.lock();
@@ -51,6 +56,7 @@ namespace Digiham {
                         bank.reset(new SharedEngine(stage, rrc, demod, sps, proto, flags, capacityRef()));
                         weak = bank;
                     }
+                    slot = bank->attach();
                     return bank;
                 }
 
@@ -103,10 +109,12 @@ namespace Digiham {
                     std::lock_guard<std::mutex> l(mutex);
                     check(dh_engine_set_slot_filter_channel(engine.get(), (uint32_t) s, filter), "dh_engine_set_slot_filter_channel");
                 }
-                std::atomic<bool> wantEvents { false };          // DECODER banks: fetch the event rows as well (set by any instance with a meta writer)
+                // DECODER banks: fetch this slot's event row as well (an instance with a meta writer or an event callback).  Per slot:
+                // events fetched for an instance that never takes them would make hasOutput() true for ever.
+                void setWantEvents(int s, bool want) { std::lock_guard<std::mutex> l(mutex); slots[s].wantEvents = want; if (!want) slots[s].events.clear(); }
 
             private:
-                struct Slot { bool used = false, dirty = false; uint32_t pending = 0; std::vector<unsigned char> out; std::vector<dh_event> events; };
+                struct Slot { bool used = false, dirty = false, wantEvents = false; uint32_t pending = 0; std::vector<unsigned char> out; std::vector<dh_event> events; };
 
                 SharedEngine(Stage stage, int rrc, int demod, unsigned int sps, int proto, unsigned int flags, unsigned int capacity):
                     stage(stage),
@@ -132,27 +140,32 @@ namespace Digiham {
                         check(dh_engine_push_host_ragged(engine.get(), reinterpret_cast<const float*>(staging.data()), chunk, counts.data(), most), "dh_engine_push_host_ragged");
                     }
                     ticks++;
+                    // The deposits are in the engine now, whatever happens below: a read that throws (DH_ECAPACITY, DH_EDEVICE) must
+                    // not leave rows marked pending, or the next tick would push the same staging rows a second time.
+                    for (unsigned int s = 0; s < B; s++) slots[s].pending = 0;
+                    pendingCount = 0;
                     for (unsigned int s = 0; s < B; s++) {
                         Slot& sl = slots[s];
-                        if (!sl.pending) continue;
+                        const uint32_t pushed = counts[s];
+                        if (!pushed) continue;
                         const size_t w = stage == RRC ? sizeof(float) : 1;
                         const size_t old = sl.out.size();
-                        size_t got = stage == RRC ? sl.pending : stage == SLICER ? sl.pending / 2 + 8 : chunk / 2 + 512;
+                        size_t got = stage == RRC ? pushed : stage == SLICER ? pushed / 2 + 8 : chunk / 2 + 512;
                         sl.out.resize(old + got * w);
-                        if (stage == RRC) check(dh_engine_read_filtered(engine.get(), s, reinterpret_cast<float*>(sl.out.data() + old), &got), "dh_engine_read_filtered");
-                        else if (stage == SLICER) check(dh_engine_read_symbols(engine.get(), s, sl.out.data() + old, &got), "dh_engine_read_symbols");
-                        else check(dh_engine_read_frames(engine.get(), s, sl.out.data() + old, &got), "dh_engine_read_frames");
-                        sl.out.resize(old + got * w);
-                        if (stage == DECODER && wantEvents) {
+                        const int rc = stage == RRC ? dh_engine_read_filtered(engine.get(), s, reinterpret_cast<float*>(sl.out.data() + old), &got)
+                                     : stage == SLICER ? dh_engine_read_symbols(engine.get(), s, sl.out.data() + old, &got)
+                                     : dh_engine_read_frames(engine.get(), s, sl.out.data() + old, &got);
+                        sl.out.resize(old + (rc == DH_OK ? got : 0) * w);
+                        check(rc, stage == RRC ? "dh_engine_read_filtered" : stage == SLICER ? "dh_engine_read_symbols" : "dh_engine_read_frames");
+                        if (stage == DECODER && sl.wantEvents) {
                             const size_t eold = sl.events.size();
                             size_t ne = chunk / 20 + 64;
                             sl.events.resize(eold + ne);
-                            check(dh_engine_read_events(engine.get(), s, sl.events.data() + eold, &ne), "dh_engine_read_events");
-                            sl.events.resize(eold + ne);
+                            const int rce = dh_engine_read_events(engine.get(), s, sl.events.data() + eold, &ne);
+                            sl.events.resize(eold + (rce == DH_OK ? ne : 0));
+                            check(rce, "dh_engine_read_events");
                         }
-                        sl.pending = 0;
                     }
-                    pendingCount = 0;
                 }
 
                 static std::mutex& registryMutex() { static std::mutex m; return m; }

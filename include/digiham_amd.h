@@ -224,7 +224,9 @@ int  dh_engine_timing_read_split(dh_engine* e, float* first_ms, uint32_t* first_
  * error-bounded estimate could not separate the phases and the reference's in-order sums decided. Synchronises. */
 int  dh_engine_timing_stats(dh_engine* e, uint32_t* h_blocks, uint32_t* h_ordered);
 /* Diagnostic: word `word` (0..31) of every channel's slicer state header, or word `word - 100` (0..63) of its
- * decoder state, into h_out[n_channels]. Synchronises. */
+ * decoder state, or word `word - 200` (0..15) of the engine's own flag block (the same value for every channel; 202 =
+ * hand-overs inside split launches that did not come and were finished by the fix-up launch), into h_out[n_channels].
+ * Synchronises. */
 int  dh_engine_debug_header(dh_engine* e, uint32_t word, uint32_t* h_out);
 /* wait for all enqueued work; returns DH_ECAPACITY if any channel overflowed an output buffer */
 int  dh_engine_sync(dh_engine* e);
@@ -275,6 +277,11 @@ int dh_debug_mfma_f16(const uint16_t* d_a, const uint16_t* d_b, const float* d_c
 /* The split of a scaled sample into two halves as the same kernels do it: d_h1[i] = f16(x scale), d_h2[i] =
  * f16((x scale - h1) 2^11), both rounded to nearest even, subnormal halves kept. */
 int dh_debug_f16_split(const float* d_in, uint16_t* d_h1, uint16_t* d_h2, size_t n, float scale, void* stream);
+/* A plain streaming copy of n_bytes (a multiple of 16, both pointers 16-byte aligned): 16 bytes per lane, non-temporal
+ * loads and stores, grid-stride over 2 048 workgroups.  Not part of the path -- bench.py times it on the lease it runs on
+ * as the achievable HBM ceiling (read + write bytes over its duration) that the path's kernels are priced against beside
+ * the 8 TB/s of the data sheet. */
+int dh_debug_copy(const void* d_src, void* d_dst, size_t n_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,9 @@
 // (include/digiham/shared_engine.hpp): the three stages of every channel are connected by ring buffers and driven round-robin by
 // one thread, the way a receiver hosting many channels runs them.  Prints how many launches (ticks) the banks needed and dumps
 // every channel's decoder bytes and metadata lines.
-//   shared_test <n_channels> <in.f32 (rows of equal length)> <samples_per_row> <out_prefix> <feed_chunk> <shared 0|1>
+//   shared_test <n_channels> <in.f32 (rows of equal length)> <samples_per_row> <out_prefix> <feed_chunk> <shared 0|1> [meta_every]
+// meta_every = k > 1: only every k-th decoder gets a meta writer (a bank that mixes instances with and without one).  A driver
+// that still finds work after 200 000 rounds has met a livelock and says so (exit code 4).
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -33,11 +35,12 @@ struct Channel {
     Digiham::Fsk::GfskDemodulator gfsk { 10 };
     Digiham::Dmr::Decoder dec;
     std::string metaPath;
-    Channel(const std::string& metaPath, int slotFilter): metaPath(metaPath) {
+    Channel(const std::string& metaPath, int slotFilter, bool withMeta): metaPath(metaPath) {
         rrc.setReader(&inR); rrc.setWriter(&filtered);
         gfsk.setReader(&filteredR); gfsk.setWriter(&syms);
         dec.setReader(&symsR); dec.setWriter(&out);
-        dec.setMetaWriter(new Digiham::FileMetaWriter(fopen(metaPath.c_str(), "w")));
+        if (withMeta) dec.setMetaWriter(new Digiham::FileMetaWriter(fopen(metaPath.c_str(), "w")));
+        else fclose(fopen(metaPath.c_str(), "w"));
         if (slotFilter != 3) dec.setSlotFilter((unsigned char) slotFilter);
     }
 };
@@ -48,13 +51,14 @@ int main(int argc, char** argv) {
     const size_t T = (size_t) atol(argv[3]), feed = (size_t) atol(argv[5]);
     const std::string prefix = argv[4];
     if (atoi(argv[6])) Digiham::Amd::SharedEngine::enable((unsigned int) N);
+    const int metaEvery = argc > 7 ? atoi(argv[7]) : 1;
     std::vector<float> x((size_t) N * T);
     FILE* f = fopen(argv[2], "rb");
     if (!f || fread(x.data(), sizeof(float), x.size(), f) != x.size()) return 3;
     fclose(f);
     try {
         std::vector<std::unique_ptr<Channel>> ch;
-        for (int i = 0; i < N; i++) ch.emplace_back(new Channel(prefix + "." + std::to_string(i) + ".meta", i % 5 == 4 ? 1 : 3));
+        for (int i = 0; i < N; i++) ch.emplace_back(new Channel(prefix + "." + std::to_string(i) + ".meta", i % 5 == 4 ? 1 : 3, metaEvery <= 1 || i % metaEvery == 0));
         std::vector<size_t> fed(N, 0);
         unsigned long rounds = 0;
         for (;;) {
@@ -70,6 +74,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < N; i++) if (ch[i]->dec.canProcess()) { ch[i]->dec.process(); busy = true; }
             rounds++;
             if (!busy) break;
+            if (rounds > 200000) { fprintf(stderr, "shared_test: still busy after %lu rounds (livelock)\n", rounds); return 4; }
         }
         printf("rounds %lu ticks %lu\n", rounds, Digiham::Amd::SharedEngine::ticksTotal());
         for (int i = 0; i < N; i++) {

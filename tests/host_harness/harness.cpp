@@ -32,6 +32,7 @@ struct HostBackend {
     void free(void* p) { ::free(p); }
     int zero(void* p, size_t bytes) { memset(p, 0, bytes); return 0; }
     int upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+    int copy_device(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
     int download2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
         return upload2d(dst, dpitch, src, spitch, width, rows);
     }
@@ -107,9 +108,17 @@ struct HostBackend {
             std::vector<float> lds(dh_dsp_shared_bytes(P.sps, 80) / sizeof(float));
             DhDspShared S = dh_dsp_carve(lds.data(), P.sps, 80);
             DhDecShared* DS = new DhDecShared;
+            // DH_TAIL_SPLIT_FORCE_FAIL = k: the later parts of the channels with ch % k == 1 "fail" their hand-over, and what the
+            // device's fix-up launch does is done here -- the rest of the row in one piece behind the first part
+            const uint32_t force = getenv("DH_TAIL_SPLIT_FORCE_FAIL") ? (uint32_t) strtoul(getenv("DH_TAIL_SPLIT_FORCE_FAIL"), nullptr, 10) : 0u;
             for (uint32_t ch = 0; ch < P.n_channels; ch++)
                 for (uint32_t part = 0; part < (b1 ? 3u : 2u); part++) {
                     const uint32_t sym_base = part ? P.sym_count[ch] : 0u;
+                    if (force && ch % force == 1u && part) {
+                        dh_rrc_demod_channel<80, false, 10>(P, ch, S, lo[1], 0xFFFFFFFFu, sym_base);
+                        if (proto == DH_PROTO_DMR) dh_dmr_channel(D, ch, *DS, sym_base, true); else dh_ysf_channel(D, ch, *DS, sym_base, true);
+                        break;
+                    }
                     dh_rrc_demod_channel<80, false, 10>(P, ch, S, lo[part], hi[part], sym_base);
                     if (proto == DH_PROTO_DMR) dh_dmr_channel(D, ch, *DS, sym_base, part != 0); else dh_ysf_channel(D, ch, *DS, sym_base, part != 0);
                 }
@@ -201,6 +210,7 @@ static int dh_be_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n
     }
     return 0;
 }
+static int dh_be_copy_kernel(const void* src, void* dst, size_t n_bytes, void*) { __builtin_memcpy(dst, src, n_bytes); return 0; }
 static int dh_be_div_const(const float* in, float* out, size_t n, unsigned divisor, void*) {
     const float d = (float) divisor, r = 1.0f / d;
     for (size_t i = 0; i < n; i++) out[i] = dh_div_const(in[i], d, r);

@@ -40,3 +40,18 @@ def test_effective_cores_respects_affinity():
             assert bench.effective_cores()[1] == 1
         finally:
             os.sched_setaffinity(0, old)
+
+
+def test_profiled_counters_are_scaled_to_the_size_of_the_run():
+    """The committed PMC passes say what they ran on (a `## config:` line, or the bench line under the tracer beside them);
+    bench.py scales their per-launch bytes and instruction counts to the size it reports on -- never a silent assumption
+    (round 3 reported a 16 384-channel pass against a 4 096-channel launch: "4.1 x wasted traffic" that was a unit bug)."""
+    import bench
+    full = bench.profiled_counters("rrc_gfsk", 16384, 190080)
+    quarter = bench.profiled_counters("rrc_gfsk", 4096, 190080)
+    assert full and quarter and "scaled" in quarter["traffic_source"]
+    assert abs(quarter["traffic"] / full["traffic"] - 0.25) < 1e-9
+    alg = 4096 * 190080 * 8.0                       # 4 B in + 4 B out per sample
+    assert 0.9 < quarter["traffic"] / alg < 1.3     # HBM traffic of the materialised-RRC kernel is its algorithmic bytes, give or take
+    dmr = bench.profiled_counters("dmr_full", 16384, 190080)
+    assert dmr and 0.9 < dmr["traffic"] / (16384 * 190080 * 4.108) < 1.3

@@ -127,6 +127,47 @@ int main() {
 
 
 @pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
+def test_shared_bank_mixes_decoders_with_and_without_a_meta_writer(oracle, tmp_path, gpu):
+    """A decoder bank whose instances do not all have a meta writer: events are fetched for the slots that asked for them only,
+    and an instance without a consumer never sees "undelivered output" that nobody will take -- the driver's
+    `while canProcess(): process()` terminates (shared_test exits 4 on a livelock), every channel's bytes are the oracle's,
+    and exactly the instances with a writer have metadata lines."""
+    N = 12
+    exe = str(tmp_path / ("mixed_gpu" if gpu else "mixed_emu"))
+    if gpu:
+        libdir, lib = os.path.join(ROOT, "digiham_amd"), "digiham_amd"
+    else:
+        import hostemu
+        hostemu.build()
+        libdir, lib = os.path.join(ROOT, "tests", "host_harness"), "dh_hostemu"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_cpp", "shared_test.cpp"),
+                    "-o", exe, "-L" + libdir, "-l" + lib, "-Wl,-rpath," + libdir], check=True)
+    chans = []
+    for i in range(N):
+        s = synth.dmr_stream(300 + i % 4, 14, two_slots=(i % 2 == 0))
+        chans.append(synth.impair(synth.shape(s), 300 + i, snr_db=[None, 25, 16][i % 3], dc=0.02 * (i % 5), delay=i % 17, gain=[1, 0.4, 2][i % 3]))
+    T = min(len(c) for c in chans)
+    x = np.stack([c[:T] for c in chans]).astype(np.float32)
+    (tmp_path / "in.f32").write_bytes(x.tobytes())
+    env = dict(os.environ)
+    if gpu:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    prefix = str(tmp_path / "m")
+    r = subprocess.run([exe, str(N), str(tmp_path / "in.f32"), str(T), prefix, "3000", "1", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    rounds, ticks = int(r.stdout.split()[1]), int(r.stdout.split()[3])
+    assert 0 < ticks <= 3 * rounds
+    outs = [open("%s.%d.out" % (prefix, i), "rb").read() for i in range(N)]
+    metas = [open("%s.%d.meta" % (prefix, i), "rb").read() for i in range(N)]
+    for i in range(N):
+        ref = oracle.chain(x[i:i + 1], proto=1, slot_filter=1 if i % 5 == 4 else 3)
+        assert outs[i] == ref["out"][0, :ref["out_count"][0]].tobytes(), i
+        assert (b"protocol:DMR" in metas[i]) == (i % 3 == 0), i
+    assert sum(len(o) for o in outs) > 0
+
+
+@pytest.mark.parametrize("gpu", [False, pytest.param(True, marks=pytest.mark.gpu)])
 def test_64_module_triples_share_one_launch_per_stage_and_round(oracle, tmp_path, gpu):
     """Digiham::Amd::SharedEngine (include/digiham/shared_engine.hpp): 64 x (WideRrcFilter | GfskDemodulator | Dmr::Decoder) in
     one process, fed raggedly, driven round-robin.  Every channel's decoder bytes and metadata lines are those of its own

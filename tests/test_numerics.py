@@ -208,3 +208,23 @@ def test_f16_fir_error_radius_covers_a_brute_force_comparison(ctx):
         worst = max(worst, err.max())
     assert worst <= 1.0, worst
     assert worst <= 0.25, "the filtered samples sit much closer to the reference's than the radius: %g of it" % worst
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_rrc_tables_equal_the_references(oracle, narrow):
+    """The two mkshape tables exist ONCE in this repository (digiham_amd/csrc/rrc_taps.h; the oracle includes that header),
+    so no parity test can notice a typo in them.  tests/golden/rrc_taps_ref_hashes.json holds the SHA-256 of the numbers in the
+    reference's own src/rrc_filter/rrc_filter.cpp:36-115 (made by tests/golden/make_golden_taps.py in the development
+    container); the expanded tables -- dh_rrc_expand_taps() as compiled into the oracle, and what the Python side parses for
+    the tests -- and the two gains must hash to the same."""
+    import hashlib
+    import json
+    import os
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rrc_taps_ref_hashes.json")))["narrow" if narrow else "wide"]
+    taps, gain = oracle.rrc_taps(narrow)
+    assert taps.dtype == np.float32 and taps.size == want["taps"] == want["nzeros"] + 1
+    assert hashlib.sha256(taps.astype("<f4").tobytes()).hexdigest() == want["taps_float32_sha256"]
+    assert np.float64(gain).tobytes().hex() == want["gain_float64_hex"]
+    parsed = _taps.narrow() if narrow else _taps.wide()
+    assert hashlib.sha256(parsed.astype("<f4").tobytes()).hexdigest() == want["taps_float32_sha256"]
+    assert np.float64(_taps.NARROW_GAIN if narrow else _taps.WIDE_GAIN).tobytes().hex() == want["gain_float64_hex"]

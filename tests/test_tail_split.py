@@ -24,11 +24,14 @@ def _collect(eng, B, acc):
 
 
 @pytest.mark.parametrize("proto,oproto", [("dmr", 1), ("ysf", 2)])
-@pytest.mark.parametrize("pct", ["1", "37", "75", "99", "40,90", "80,81"])
+@pytest.mark.parametrize("pct", ["1", "37", "75", "99", "40,90", "80,81", "75:fail", "40,90:fail"])
 def test_split_pushes_on_the_wave_emulation(emu_ctx, oracle, monkeypatch, proto, oproto, pct):
     x = make_channels(proto, [31, 32, 33, 34], 10)
     B, n = x.shape
     ref = oracle.chain(x, proto=oproto)
+    if pct.endswith(":fail"):                   # channels 1 and 3 lose their hand-over: the rest of the row in one piece (the fix-up launch's arithmetic)
+        pct = pct[:-5]
+        monkeypatch.setenv("DH_TAIL_SPLIT_FORCE_FAIL", "2")
     monkeypatch.setenv("DH_TAIL_SPLIT", str(pct))
     cap = 20000
     eng = api.Engine(B, cap, proto=proto, ctx=emu_ctx)
@@ -73,8 +76,14 @@ def test_split_launch_equals_whole_launch_and_oracle(gpu_ctx, oracle, monkeypatc
     cnt_u = np.array([n1, n1, 0, 1, n1 * 3 // 4 - 1, n1 * 3 // 4, n1 * 3 // 4 + 1, n1 // 2, n1 - 777, n1 - 1, n1, 12345, n1, n1 * 9 // 10, n1, n1], np.uint32)
     counts = np.tile(cnt_u, reps)[:B].copy()
     results = {}
-    for pct in ("0", "80", "50", "70,92"):
-        monkeypatch.setenv("DH_TAIL_SPLIT", str(pct))
+    for pct in ("0", "80", "50", "70,92", "80:fail", "70,92:fail"):
+        # ":fail" -- the later parts of every third channel give up as if their hand-over had not come (DH_TAIL_SPLIT_FORCE_FAIL):
+        # the fix-up launch behind the split launch finishes those rows, and nothing is reported
+        monkeypatch.setenv("DH_TAIL_SPLIT", pct.split(":")[0])
+        if pct.endswith(":fail"):
+            monkeypatch.setenv("DH_TAIL_SPLIT_FORCE_FAIL", "3")
+        else:
+            monkeypatch.delenv("DH_TAIL_SPLIT_FORCE_FAIL", raising=False)
         eng = api.Engine(B, T, proto=proto, ctx=gpu_ctx, **kw)
         acc = [[[] for _ in range(B)] for _ in range(3)]
         eng.push(x, n=n1, counts=torch.from_numpy(counts).to(x.device))
@@ -94,11 +103,13 @@ def test_split_launch_equals_whole_launch_and_oracle(gpu_ctx, oracle, monkeypatc
             tail[u::U, :l0] = rest[u::U, f0:f0 + l0]
         eng.push(tail, n=int(last.max()), counts=torch.from_numpy(last).to(x.device))
         _collect(eng, B, acc)
+        gave_up = int(eng.debug_header(202)[0])                 # hand-overs that did not come (finished by the fix-up launch)
+        assert (gave_up > 0) == pct.endswith(":fail"), (pct, gave_up)
         eng.close()
         results[pct] = [[hashlib.sha256(np.concatenate(acc[k][b]).tobytes()).hexdigest() for b in range(B)] for k in range(3)]
         if pct == "0":
             whole = [[np.concatenate(acc[k][b]) for b in range(U)] for k in range(3)]
-    for pct in ("80", "50", "70,92"):
+    for pct in ("80", "50", "70,92", "80:fail", "70,92:fail"):
         assert results[pct] == results["0"], pct
     assert all(results["0"][k][b] == results["0"][k][b % U] for k in range(3) for b in range(B))
     ref = oracle.chain(base.cpu().numpy(), proto=oproto, threads=8, **okw)
@@ -108,3 +119,50 @@ def test_split_launch_equals_whole_launch_and_oracle(gpu_ctx, oracle, monkeypatc
         assert len(gf) == ref["out_count"][b] and (gf == ref["out"][b, :len(gf)]).all(), b
         assert ge.tobytes() == ref["events"][b, :ref["event_count"][b]].tobytes(), b
     assert sum(len(whole[1][b]) for b in range(U)) > 0
+
+
+@pytest.mark.gpu
+def test_two_split_engines_on_two_streams(gpu_ctx, oracle, monkeypatch):
+    """What `bench.py --workload mixed --streams 2` times: an 8 192-channel DMR and an 8 192-channel YSF engine on their own HIP
+    streams, pushes long enough for the tail split (>= 65 536 samples) on BOTH, three pushes queued back to back before
+    anything is read.  Same bytes as the unsplit engines, every channel; the distinct signals against the oracle."""
+    import torch
+    from digiham_amd import synth_torch
+    U, B = 32, 8192
+    dev = gpu_ctx.mem.device
+    hashes = {}
+    for pct in ("0", "80"):
+        monkeypatch.setenv("DH_TAIL_SPLIT", pct)
+        parts = []
+        for proto, units, seed in (("dmr", 50, 515), ("ysf", 15, 616)):
+            base, info = synth_torch.make_batch(torch, dev, proto, U, units, U=U, seed=seed)
+            assert info["samples_per_channel"] >= 65536
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):                      # the engine captures the current stream
+                eng = api.Engine(B, info["samples_per_channel"], proto=proto, ctx=gpu_ctx)
+            parts.append({"proto": proto, "base": base, "x": base.repeat(B // U, 1).contiguous(), "eng": eng, "outs": []})
+        torch.cuda.synchronize()
+        for _ in range(2):
+            for p in parts:
+                p["eng"].push(p["x"])
+            for p in parts:
+                p["eng"].push(p["x"])                           # a second push of each queued behind the first, both streams busy
+            for p in parts:
+                p["outs"].append(tuple(a.copy() for pair in (p["eng"].symbols(), p["eng"].frames(), p["eng"].events()) for a in pair))
+        for p in parts:
+            assert int(p["eng"].debug_header(202)[0]) == 0      # every hand-over came
+            p["eng"].close()
+            hashes[(pct, p["proto"])] = [[hashlib.sha256(o[2 * k][b, :o[2 * k + 1][b]].tobytes()).hexdigest() for b in range(B)] for o in p["outs"] for k in range(3)]
+            if pct == "80":
+                # pushes 2 and 4 of the stream were read: compare them with the oracle's stream of four
+                ref = oracle.chain(np.tile(p["base"].cpu().numpy(), (1, 4)), proto={"dmr": 1, "ysf": 2}[p["proto"]], threads=8)
+                pre = [oracle.chain(np.tile(p["base"].cpu().numpy(), (1, k)), proto={"dmr": 1, "ysf": 2}[p["proto"]], threads=8) for k in (1, 2, 3)]
+                for b in range(U):
+                    for o, lo, hi in ((p["outs"][0], pre[0], pre[1]), (p["outs"][1], pre[2], ref)):
+                        for k, (rows, cnt) in enumerate((("syms", "sym_count"), ("out", "out_count"), ("events", "event_count"))):
+                            got = o[2 * k][b, :o[2 * k + 1][b]]
+                            want = hi[rows][b, lo[cnt][b]:hi[cnt][b]]
+                            assert got.tobytes() == want.tobytes(), (p["proto"], b, rows)
+                assert sum(int(o[3].sum()) for o in p["outs"]) > 0
+    for proto in ("dmr", "ysf"):
+        assert hashes[("80", proto)] == hashes[("0", proto)], proto
