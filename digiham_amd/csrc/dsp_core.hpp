@@ -87,7 +87,10 @@ struct DhDspParams {
     uint32_t split_fixup, split_force_fail;
 };
 
-DH_HD uint32_t dh_state_words(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }
+// (behind the tail: the per-phase partial sums of the ring-less kernels, see DH_RINGLESS)
+#define DH_PART_WORDS(sps) ((2u * (sps) + 4u + 3u) & ~3u)
+DH_HD uint32_t dh_state_part_offset(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }
+DH_HD uint32_t dh_state_words(uint32_t sps) { return dh_state_part_offset(sps) + DH_PART_WORDS(sps); }
 
 // LDS block of one wavefront.  `xf` holds the raw-sample window during the FIR (padded one word
 // per 16 so that the per-lane sliding windows, 16 words apart, hit 32 different banks) and is then
@@ -120,6 +123,7 @@ struct DhDspShared {
     uint32_t* clk;                                     // DH_PHASE_CLOCKS builds only
     float* tapsf;                                      // FIR taps (first half + centre; the wide filter: all of them, see above)
     float* var_rb;
+    float* part;                                       // ring-less kernels: per-phase sums of the current variance block, [sps] sum x then [sps] sum x^2
     float* bound;                                      // bookkeeping of the error-bounded kernels (DhBoundState, 16 words)
 };
 
@@ -140,10 +144,20 @@ DH_HD uint32_t dh_dsp_xf_words(uint32_t nz) {
 #else
 #define DH_RING_WORDS(sps) (DH_VARIANCE_SYMBOLS * (sps))
 #endif
-DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz) {
-    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + DH_RING_WORDS(sps) + dh_dsp_xf_words(nz));
+// Ring-less kernels (DH_RINGLESS; the split-f16 kernels of the DMR / YSF and NXDN48 pipes).  The variance ring -- the last hundred
+// symbols' samples, 4 000 bytes of LDS at sps 10 and 8 000 at sps 20 -- only feeds the per-phase variance estimate at the end of a
+// block.  These kernels add up sum x and sum x^2 per phase while the run's filtered samples are still in the window block (P3)
+// and carry 2 sps floats instead: 6.3 KB of LDS per wavefront, which no longer limits how many wavefronts a CU holds.  The rare
+// blocks the estimate cannot decide recompute their samples from the raw history anyway (exactly); they use the ring's place in
+// the channel's state block in HBM as their scratch.
+#ifndef DH_RINGLESS
+#define DH_RINGLESS 0                        // (measured, round 4: the sums cost the window phase more than the ring cost P3 + P6 -- DMR chain +4 % -- and a 96-register
+#endif                                       //  budget for a fifth wavefront per SIMD spills across the FIR: off; tools/build_variant.sh <name> -DDH_RINGLESS=1 builds it)
+DH_HD bool dh_is_ringless(uint32_t nz, uint32_t sps_template, bool fast);
+DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz, bool ringless = false) {
+    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + (ringless ? DH_PART_WORDS(sps) : DH_RING_WORDS(sps)) + dh_dsp_xf_words(nz));
 }
-DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {          // base: 16-byte aligned
+DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0, bool ringless = false) {          // base: 16-byte aligned
     float* f = reinterpret_cast<float*>(base);
     DhDspShared S;
     S.vol_old = f; S.vol_new = f + 128;
@@ -157,7 +171,8 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {     
         S.stats = reinterpret_cast<uint32_t*>(f + 256 + 124); S.clk = reinterpret_cast<uint32_t*>(f + 384);
     }
     S.var_rb = f + dh_lds_fixed_words(nz);
-    S.xf = S.var_rb + DH_RING_WORDS(sps);
+    S.part = S.var_rb;                                 // (ring-less: the sums sit where the ring would start, and var_rb is pointed at scratch in HBM by the kernel body)
+    S.xf = S.var_rb + (ringless ? DH_PART_WORDS(sps) : DH_RING_WORDS(sps));
     S.mn = S.xf; S.mx = S.xf + DH_SCAN_N;
     S.variance = reinterpret_cast<double*>(S.xf + 2 * DH_SCAN_N);
     S.sum = S.xf + DH_FTILE + 4;
@@ -260,6 +275,19 @@ DH_HD float dh_div_const(float x, float d, float r) {
     return __builtin_fmaf(rem, r, q0);
 }
 
+// the same for a pair of operands (device: v_pk_mul_f32 + two v_pk_fma_f32 for both; one range test on the larger of the two words)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+typedef float dh_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dh_f2v dh_div_const2(dh_f2v x, float d, float r) {
+    const uint32_t ta = (__float_as_uint(x.x) << 1) - 2u * 0x0D800000u, tb = (__float_as_uint(x.y) << 1) - 2u * 0x0D800000u;
+    if (__builtin_expect((ta > tb ? ta : tb) > 2u * (0x71800000u - 0x0D800000u), 0)) { dh_f2v q; q.x = dh_div_const(x.x, d, r); q.y = dh_div_const(x.y, d, r); return q; }
+    const dh_f2v rr = { r, r }, dd = { -d, -d };
+    const dh_f2v q0 = x * rr;
+    const dh_f2v rem = __builtin_elementwise_fma(q0, dd, x);
+    return __builtin_elementwise_fma(rem, rr, q0);
+}
+#endif
+
 // loop-invariant wave-uniform values that should live in VGPRs rather than compete for the 102 SGPRs
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 #define DH_TO_VGPR(x) asm volatile("" : "+v"(x))
@@ -323,6 +351,18 @@ __device__ __forceinline__ dh_f2 dh_f2_fma(dh_f2 a, dh_f2 b, dh_f2 c) { return _
 inline dh_f2 dh_f2_add(dh_f2 a, dh_f2 b) { return dh_f2_make(a.x + b.x, a.y + b.y); }
 inline dh_f2 dh_f2_sub(dh_f2 a, dh_f2 b) { return dh_f2_make(a.x - b.x, a.y - b.y); }
 inline dh_f2 dh_f2_fma(dh_f2 a, dh_f2 b, dh_f2 c) { return dh_f2_make(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)); }
+#endif
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ dh_f2 dh_f2_scale(dh_f2 a, float s) { const dh_f2 ss = { s, s }; return a * ss; }
+// min(|a|, |b|, |c|) in one instruction; a NaN operand is skipped (v_min3_f32), so callers that must notice a NaN distance make
+// sure ALL THREE are NaN then (they are: every distance of a symbol hangs on the same average and extremes) -- see P5
+__device__ __forceinline__ float dh_min3_abs(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+inline dh_f2 dh_f2_scale(dh_f2 a, float s) { return dh_f2_make(a.x * s, a.y * s); }
+inline float dh_min3_abs(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
+#endif
+#if !(DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__))
+inline dh_f2 dh_div_const2(dh_f2 x, float d, float r) { return dh_f2_make(dh_div_const(x.x, d, r), dh_div_const(x.y, d, r)); }
 #endif
 #define DH_FIR_H (DH_FIR_L / 2)
 #define DH_XLOFF(e) ((e) + ((e) >> 4))                 // dword offset of window element e from the lane's base
@@ -640,6 +680,12 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #ifndef DH_FIR_F16
 #define DH_FIR_F16 1
 #endif
+#ifndef DH_P3_PAIRED
+#define DH_P3_PAIRED 1                       // sps-10 kernels: the window phase takes two symbols per lane (packed adds), one pass per run
+#endif
+#ifndef DH_P5_PAIRED
+#define DH_P5_PAIRED 1                       // ... and so does the slicing phase
+#endif
 #ifndef DH_EXACT_STAGED
 #define DH_EXACT_STAGED 1                    // the exact re-evaluations of the sps-10 kernels stage their raw samples through LDS, like the generic-sps ones
 #endif
@@ -736,6 +782,11 @@ typedef _Float16 dh_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 dh_h4 __attribute__((ext_vector_type(4)));
 typedef uint32_t dh_u4 __attribute__((ext_vector_type(4)));
 // four samples -> four halves of h1 and of h2 (scale = 2^-k as a float)
+typedef _Float16 dh_h2 __attribute__((ext_vector_type(2)));
+// (Round 4 tried the second half as ONE fused operation per sample, h2 = f16(fma(x, 2^11 scale, -2^11 h1)) with v_fma_mixlo / mixhi_f16
+// reading 2^11 h1 as a half: bit-identical, two and a half instructions per sample instead of three and a half -- and no faster,
+// because v_fma_mix* issues at 8.2 cycles per wavefront against 4.2 for the conversions and packed operations it replaces
+// (tools/microbench/valu_rate.hip).  Dropped.)
 __device__ __forceinline__ void dh_f16_split4(const dh_f4& v, float scale, dh_h4& h1, dh_h4& h2) {
     const float x[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -839,7 +890,22 @@ template <int OFF_WORDS> __device__ __forceinline__ void dh_lds_store4_at(float*
                  :: "v"(addr), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"(4 * OFF_WORDS), "n"(4 * OFF_WORDS + 4), "n"(4 * OFF_WORDS + 8), "n"(4 * OFF_WORDS + 12) : "memory");
 }
 __device__ __forceinline__ void dh_lds_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// ten floats into one column of the transposed variance ring (row i is DH_VARIANCE_SYMBOLS words further; K = column offset):
+// ten ds_write_b32 with immediate offsets from one address, no vector arithmetic (see dh_lds_store4_at)
+template <int K> __device__ __forceinline__ void dh_lds_store_row10(float* base, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, float a9) {
+    const uint32_t addr = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) base;
+    asm volatile("ds_write_b32 %0, %1 offset:%11\n\tds_write_b32 %0, %2 offset:%12\n\tds_write_b32 %0, %3 offset:%13\n\tds_write_b32 %0, %4 offset:%14\n\t"
+                 "ds_write_b32 %0, %5 offset:%15\n\tds_write_b32 %0, %6 offset:%16\n\tds_write_b32 %0, %7 offset:%17\n\tds_write_b32 %0, %8 offset:%18\n\t"
+                 "ds_write_b32 %0, %9 offset:%19\n\tds_write_b32 %0, %10 offset:%20"
+                 :: "v"(addr), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(a8), "v"(a9),
+                    "n"(4 * K), "n"(4 * (K + 100)), "n"(4 * (K + 200)), "n"(4 * (K + 300)), "n"(4 * (K + 400)), "n"(4 * (K + 500)), "n"(4 * (K + 600)),
+                    "n"(4 * (K + 700)), "n"(4 * (K + 800)), "n"(4 * (K + 900)) : "memory");
+}
 #else
+template <int K> inline void dh_lds_store_row10(float* base, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, float a9) {
+    const float a[10] = { a0, a1, a2, a3, a4, a5, a6, a7, a8, a9 };
+    for (int i = 0; i < 10; i++) base[i * 100 + K] = a[i];
+}
 template <int OFF_WORDS> inline void dh_lds_store4_at(float* base, const dh_f4& v) { dh_store4(base + OFF_WORDS, v); }
 inline void dh_lds_stores_done() {}
 #endif
@@ -994,6 +1060,12 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 template <int NZ, bool FAST, int SPS> struct DhIsBounded {
     static constexpr bool value = DH_BOUNDED_FIR && !FAST && ((NZ == 80 && SPS == 10) || (DH_BOUNDED_NARROW && NZ == 160 && SPS != 10));
 };
+template <int NZ, bool FAST, int SPS> struct DhIsRingless {
+    static constexpr bool value = DH_RINGLESS && DH_FIR_F16 && DhIsBounded<NZ, FAST, SPS>::value && ((NZ == 80 && SPS == 10) || (NZ == 160 && SPS == 20));
+};
+DH_HD bool dh_is_ringless(uint32_t nz, uint32_t sps_template, bool fast) {
+    return DH_RINGLESS && DH_FIR_F16 && DH_BOUNDED_FIR && !fast && ((nz == 80u && sps_template == 10u) || (DH_BOUNDED_NARROW && nz == 160u && sps_template == 20u));
+}
 // Diagnostic builds only (tools/phase_budget.sh): -DDH_STOP_AFTER=n leaves out the phases after Pn of every run (the
 // results are then wrong; the instruction counters of such builds, subtracted from each other, give the per-phase budget)
 #ifndef DH_STOP_AFTER
@@ -1348,6 +1420,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
+    constexpr bool RINGLESS = DhIsRingless<NZ, FAST, SPS>::value;                                     // no variance ring in LDS: per-phase sums instead (see DH_RINGLESS)
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -1383,8 +1456,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             S.vol_old[j] = j < DH_VOLUME_RB_SIZE ? st[DH_ST_VOL + j] : 0.0f;
             S.vol_new[j] = 0.0f;
         }
-        for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) S.var_rb[j] = st[DH_ST_VAR + j];
+        if (!RINGLESS) { for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) S.var_rb[j] = st[DH_ST_VAR + j]; }
+        else { for (uint32_t j = lane; j < 2u * sps; j += DH_WAVE) S.part[j] = st[dh_state_part_offset(sps) + j]; }
     }
+    if (RINGLESS) S.var_rb = st + DH_ST_VAR;            // the rare exact recomputations of a block use the ring's place in the state block as scratch
     DH_BARRIER();
 
     // FIR taps are parked in LDS and pulled into VGPRs at the start of every FIR pass (see P2): their live range
@@ -1500,7 +1575,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     dh_u4 tapfrag_regs[2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80)];
 #define DH_TAPFRAG_LOAD() do { if constexpr (MF16) { const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(P.tapfrag) + dh_fresh_lane_id_(); \
         _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
+#ifndef DH_TAPFRAG_LATE
+#define DH_TAPFRAG_LATE 0                    // 1: the fragments are requested at the start of every FIR pass instead of one iteration ahead (24 registers less across the loop's back edge; their L1 / L2 latency is then exposed)
+#endif
+#if !DH_TAPFRAG_LATE
     DH_TAPFRAG_LOAD();
+#endif
     // Every path through P2 must leave these loads landed, also the rare ones that never look at the fragments: otherwise the
     // compiler's wait-count bookkeeping still sees them in flight further down, and the first instruction that reuses one of
     // their registers -- in the slicing phase -- gets an s_waitcnt vmcnt(0), which also waits for the NEXT window's loads,
@@ -1542,7 +1622,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         const uint32_t last_start = p + (m - 1) * sps + (m > 1 ? (uint32_t) step_off : 0u);
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
-        if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags |= 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
+        // (bits 2.. of blk_flags, ring-less kernels: 4 = some run of the current block had a non-zero window, bits 8..15 = runs the block has been cut into)
+        if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags = (BS->blk_flags & 3u) | 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
         bool use_exact = BOUNDED && P.exact_mode == 2;  // this run through the exact FIR (odd samples, odd staging path)
         DH_LANE_ARRAY(float, xmax_lane, 1);
         float e_run = 0.0f;                             // error radius of this run's filtered samples (0: exact)
@@ -1712,6 +1793,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
 #endif
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
+#if DH_TAPFRAG_LATE
+            DH_TAPFRAG_LOAD();
+#endif
             // (taps from the LDS copy into vector registers: as scalar operands they free 40 VGPRs but cost this kernel 5 %,
             // see DhFirBatch)
             constexpr bool MFMA = DH_MFMA_FIR && NZ > 0 && NZ <= 80 && (BOUNDED || FAST) && !MF16;      // the fused FIR as f32 MFMAs (dh_fir_mfma)
@@ -1832,7 +1916,59 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #define DH_FB(n) fbuf[n]
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
+#if DH_P3_PAIRED
+        // sps 10: TWO symbols per lane, the whole run in one pass of straight-line code.  A lane's symbols q and q + 24 both lie
+        // behind the pending timing step, so their samples sit at compile-time offsets (i and 240 + i words) from ONE per-lane
+        // base and a single ds_read2_b32 delivers sample i of both as a register pair:
+        //   lanes 0..23: q = lane + 1 (and q + 24);  lanes 24..47: q = lane + 25 (and q + 24);  lanes 48..50: q = lane + 49 alone (as
+        //   the second of a pair whose first is not theirs: every read stays inside the window block);  lane 51: symbol 0, the only
+        //   one in front of the step.
+        // The two symbols of a lane share every addition (v_pk_add_f32 on the pair: each symbol's sums still run in sample order,
+        // as the reference's do) and the division; loads and stores carry their offsets as immediates, so the phase costs ~35
+        // vector instructions instead of the ~85 of two passes of one symbol per lane.  Lanes beyond the run read words of the
+        // window block that nothing will look at (possibly halves of the staged arrays) and store nothing.
+        if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+            const uint32_t l = (uint32_t) lane;
+            const uint32_t qa = l < 51u ? l + 1u + (l >= 24u ? 24u : 0u) : 0u, qb = qa + 24u;
+            const bool va = (l < 48u || l == 51u) && qa < m, vb = l < 51u && qb < m;
+            const float* src = fbuf + (l < 51u ? (int32_t) (qa * 10u) + step_off : 0);
+            dh_f2 v[10];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            {
+                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
+                v[0] = dh_lds_read2<0, 240>(a); v[1] = dh_lds_read2<1, 241>(a); v[2] = dh_lds_read2<2, 242>(a); v[3] = dh_lds_read2<3, 243>(a);
+                v[4] = dh_lds_read2<4, 244>(a); v[5] = dh_lds_read2<5, 245>(a); v[6] = dh_lds_read2<6, 246>(a); v[7] = dh_lds_read2<7, 247>(a);
+                v[8] = dh_lds_read2<8, 248>(a); v[9] = dh_lds_read2<9, 249>(a);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]) :: "memory");
+            }
+#else
+            for (int i = 0; i < 10; i++) v[i] = dh_f2_make(src[i], src[240 + i]);
+#endif
+            dh_f2 vol = v[0];
+#pragma unroll
+            for (int i = 1; i < 10; i++) vol = dh_f2_add(vol, v[i]);
+            const dh_f2 mid = dh_f2_add(dh_f2_add(dh_f2_add(v[3], v[4]), v[5]), v[6]);          // samples ev_lo .. ev_hi - 1 = 3 .. 6
+            const dh_f2 volume = dh_div_const2(vol, 10.0f, sps_rcp);
+            const uint32_t ka = k0 + qa;
+            float* ring = S.var_rb + ka;
+            if (va) {
+#ifndef DH_NO_RING
+                if (!RINGLESS) dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);      // transposed ring: phase-major
+#endif
+                S.sum[qa] = mid.x; S.vol_new[ka] = volume.x;
+            }
+            if (vb) {
+#ifndef DH_NO_RING
+                if (!RINGLESS) dh_lds_store_row10<24>(ring, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y);
+#endif
+                S.sum[qb] = mid.y; S.vol_new[ka + 24u] = volume.y;
+            }
+            dh_lds_stores_done();
+        }
+        if (SPS != 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+#else
         if (DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+#endif
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
@@ -1848,7 +1984,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         if (i >= ev_lo && i < ev_hi) sum += value[i];
                         volume_sum += value[i];
 #ifndef DH_NO_RING
-                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
+                        if (!RINGLESS) S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
 #endif
                     }
                 } else {
@@ -1863,7 +1999,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                             if (i + j >= ev_lo && i + j < ev_hi) sum += value[j];
                             volume_sum += value[j];
 #ifndef DH_NO_RING
-                            S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
+                            if (!RINGLESS) S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
 #endif
                         }
                     }
@@ -1872,12 +2008,66 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         if (i >= ev_lo && i < ev_hi) sum += value;
                         volume_sum += value;
 #ifndef DH_NO_RING
-                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
+                        if (!RINGLESS) S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
 #endif
                     }
                 }
                 S.sum[q] = sum;
                 S.vol_new[k] = dh_div_const(volume_sum, (float) sps, sps_rcp);
+            }
+        }
+        // ---- P3b (ring-less kernels): this run's share of the per-phase sums behind the timing estimate of P6, taken while the
+        // filtered samples are still in the window block.  Lane G i + g adds up phase i (sample i of every symbol) over the g-th
+        // chunk of the run's symbols -- two interleaved chains, the squares by FMA -- the G lanes of a phase meet through a DPP
+        // quad permute, and the first of them folds the result into the block's sums (S.part).  Same phase as the windows above:
+        // both only read the filtered samples.
+        if constexpr (RINGLESS) {
+            constexpr uint32_t G = SPS == 10 ? 4u : 2u, FULL = SPS == 10 ? 100u : 51u, C = (FULL + G - 1u) / G, NL = G * (uint32_t) SPS;
+            static_assert(NL <= DH_WAVE && G * C >= FULL && (G * C - 1u) * SPS + SPS + 1u <= DH_FTILE + 64u, "one lane per phase and chunk; every read stays inside the window block");
+            const bool full_run = m == FULL;
+            DH_LANE_ARRAY(float, psx, 1); DH_LANE_ARRAY(float, psq, 1);
+            if (DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+                const uint32_t l = (uint32_t) lane < NL ? (uint32_t) lane : 0u;          // (lanes beyond the set repeat lane 0's reads and are not looked at)
+                const uint32_t i = l / G, g = l - G * i;
+                const float* col = fbuf + i;
+                const float* src = col + (int32_t) (g * C * (uint32_t) SPS) + step_off;
+                float s0 = 0.0f, s1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+                for (uint32_t j = 0; j < C; j++) {
+                    float x = src[j * (uint32_t) SPS];
+                    if (j == 0) x = g == 0u ? col[0] : x;                               // symbol 0 sits in front of the pending step
+                    if (G * C > FULL && j == C - 1u) x = g * C + j < m ? x : 0.0f;      // (the last chunk's spare slot)
+                    else if (!full_run) x = g * C + j < m ? x : 0.0f;
+                    if (j & 1u) { s1 += x; q1 = __builtin_fmaf(x, x, q1); } else { s0 += x; q0 = __builtin_fmaf(x, x, q0); }
+                }
+                DH_LA(psx, lane)[0] = s0 + s1; DH_LA(psq, lane)[0] = q0 + q1;
+            }
+            if (DH_STOP_AFTER >= 3) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                float sx = psx[0], sq = psq[0];
+                sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0xB1, 0xF, 0xF, true));      // quad_perm:[1,0,3,2]
+                sq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xB1, 0xF, 0xF, true));
+                if (G == 4) {
+                    sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+                    sq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x4E, 0xF, 0xF, true));
+                }
+                const uint32_t l = (uint32_t) dh_fresh_lane_id_();
+                if (l < NL && l % G == 0u) {
+                    const uint32_t i = l / G;
+                    S.part[i] = (k0 == 0u ? 0.0f : S.part[i]) + sx;
+                    S.part[(uint32_t) SPS + i] = (k0 == 0u ? 0.0f : S.part[(uint32_t) SPS + i]) + sq;
+                }
+#else
+                for (uint32_t i = 0; i < (uint32_t) SPS; i++) {
+                    float sx, sq;
+                    if (G == 4) {      // what every lane of the quad holds after the two exchanges: (a0 + a1) + (a2 + a3)
+                        sx = (psx[G * i][0] + psx[G * i + 1][0]) + (psx[G * i + 2][0] + psx[G * i + 3][0]);
+                        sq = (psq[G * i][0] + psq[G * i + 1][0]) + (psq[G * i + 2][0] + psq[G * i + 3][0]);
+                    } else { sx = psx[G * i][0] + psx[G * i + 1][0]; sq = psq[G * i][0] + psq[G * i + 1][0]; }
+                    S.part[i] = (k0 == 0u ? 0.0f : S.part[i]) + sx;
+                    S.part[(uint32_t) SPS + i] = (k0 == 0u ? 0.0f : S.part[(uint32_t) SPS + i]) + sq;
+                }
+#endif
             }
         }
         DH_BARRIER();
@@ -1956,6 +2146,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_COMPILER_FENCE();                            // the bookkeeping in LDS is read here, not carried across the FIR
         float e_blk = 0.0f;
         if (BOUNDED) { e_blk = dh_uniform_f(__builtin_fmaxf(BS->e_blk, e_run)); BS->e_blk = e_blk; }
+        if (RINGLESS) {                                 // one more piece of the current block; did its window hold anything but zeros?
+            const uint32_t f = dh_uniform(BS->blk_flags), pieces = dh_min<uint32_t>(((f >> 8) & 255u) + 1u, 255u);
+            BS->blk_flags = (f & ~0xFF00u) | (pieces << 8) | ((use_exact || e_run > 0.0f) ? 4u : 0u);
+        }
         const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
         const float T = DH_BOUND_T_FACTOR * e_eff;
         uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
@@ -1970,6 +2164,60 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const float T_eff = force_doubt ? __builtin_inff() : T;
         const float inv_width = 1.0f / (float) (ev_hi - ev_lo);                       // (a power of two for sps 10: the product below is the division)
         const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
+#if DH_P5_PAIRED
+        // TWO symbols per lane, q = 2 lane and 2 lane + 1 (a run has at most 100): their AGC extremes, window sums and everything
+        // derived from them are pairs, so centre, average, the two thresholds and the three distances are packed operations for
+        // both symbols -- one pass of ~40 vector instructions instead of two of ~37.  Every operation is the one the one-symbol
+        // form performs (same operands, same order), so the dibits and the doubts are the same.
+        if (DH_STOP_AFTER >= 5) {
+        uint64_t vote_a = 0, vote_b = 0;
+        DH_FOR_LANES_FRESH(lane) {
+            const uint32_t qa = 2u * (uint32_t) lane;
+            const bool va = qa < m, vb = qa + 1u < m;
+            const uint32_t qq = va ? qa : 0u, k = k0 + qq;                            // (lanes beyond the run recompute symbols 0 / 1: in-range reads, no store)
+            const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[k + 1u]), mx = dh_f2_make(S.mx[k], S.mx[k + 1u]);
+            const dh_f2 sumq = dh_f2_make(S.sum[qq], S.sum[qq + 1u]);
+            const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);                // (max + min) / 2.0f: the division by two is exact
+            const dh_f2 average = width_pow2 ? dh_f2_scale(sumq, inv_width) : dh_f2_make(sumq.x / (float) (ev_hi - ev_lo), sumq.y / (float) (ev_hi - ev_lo));
+            const dh_f2 c625 = dh_f2_make(0.625f, 0.625f);
+            const dh_f2 umid = dh_f2_fma(dh_f2_sub(mx, center), c625, center);        // one float FMA each: see the one-symbol form below
+            const dh_f2 lmid = dh_f2_fma(dh_f2_sub(mn, center), c625, center);
+            const bool above_a = average.x > center.x, above_b = average.y > center.y;
+            const uint8_t sym4a = above_a ? (average.x > umid.x ? 1 : 0) : (average.x < lmid.x ? 3 : 2);
+            const uint8_t sym4b = above_b ? (average.y > umid.y ? 1 : 0) : (average.y < lmid.y ? 3 : 2);
+            const uint8_t sym2a = LV == 4 ? (uint8_t) 0 : above_a ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+            const uint8_t sym2b = LV == 4 ? (uint8_t) 0 : above_b ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+            const uint8_t sa = four_levels ? sym4a : sym2a, sb = four_levels ? sym4b : sym2b;
+            bool doubt_a = false, doubt_b = false;
+            if (BOUNDED) {
+                const dh_f2 du = dh_f2_sub(average, umid), dl = dh_f2_sub(average, lmid), dc = dh_f2_sub(average, center);
+                const float da = dh_min3_abs(four_levels ? du.x : DH_FLT_MAX, four_levels ? dl.x : DH_FLT_MAX, dc.x);
+                const float db = dh_min3_abs(four_levels ? du.y : DH_FLT_MAX, four_levels ? dl.y : DH_FLT_MAX, dc.y);
+                doubt_a = va && e_pos && !(da > T_eff);                               // (!(d > T): a NaN distance is a doubt)
+                doubt_b = vb && e_pos && !(db > T_eff);
+            }
+#ifdef DH_IGNORE_DOUBT
+            doubt_a = false; doubt_b = false;
+#endif
+#ifdef DH_P5_NOSTORE
+            if (va && !doubt_a && sa == 77) syms[nsym + qa] = sa;
+            if (vb && !doubt_b && sb == 77) syms[nsym + qa + 1u] = sb;
+#else
+            if (va && !doubt_a) syms[nsym + qa] = sa;
+            if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
+#endif
+            DH_BALLOT_ACC(vote_a, doubt_a, lane);
+            DH_BALLOT_ACC(vote_b, doubt_b, lane);
+        }
+        // symbol q's doubt sits in bit q / 2 of vote_a (even q) or vote_b (odd q): back to one bit per symbol, 64 per word
+        if (DH_UNLIKELY((vote_a | vote_b) != 0)) {
+            for (uint32_t l = 0; l < 50u; l++) {
+                if ((vote_a >> l) & 1ull) unsure[(2u * l) >> 6] |= 1ull << ((2u * l) & 63u);
+                if ((vote_b >> l) & 1ull) unsure[(2u * l + 1u) >> 6] |= 1ull << ((2u * l + 1u) & 63u);
+            }
+        }
+        }
+#else
 #pragma unroll
         for (uint32_t h = 0; h < 2; h++) {
         if (h * DH_WAVE < m && DH_STOP_AFTER >= 5) {
@@ -2013,6 +2261,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         unsure[h] = vote_unsure;
         }
         }
+#endif
         if (BOUNDED && DH_UNLIKELY((unsure[0] | unsure[1]) != 0)) {
             DhExactCtx C;
             C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
@@ -2062,7 +2311,59 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             // kernels, the exact recomputation of the ring in front of it) only has to look at these rows.  All rows when no
             // valid set of intervals exists (no estimate, NaN / overflow, an estimate of exactly 0).
             uint64_t chain_rows = ~0ull;
-            if (SPS == 10 && !P.ordered_timing) {
+            if constexpr (RINGLESS) {
+                // The estimate from the block's per-phase sums (P3b): V' = Q' / 100 - mean'^2 as in the ring kernels' one-pass form
+                // below, whose derivation carries over with longer chains -- 13 fused terms per chain, one addition of the two
+                // chains, two (sps 10) or one (sps 20) in the quad, and one per further piece when the block was cut by the end of
+                // a run or push (at most 4 pieces are admitted): 21.4 u on Q' and on the sum, hence |V' - sigma^2| <= (3 x 21.4 + 1) u m2
+                // = 3.9e-6 m2, taken as 5e-6.  A block whose windows were all zeros has vmin = 0 exactly.  Everything else -- more
+                // pieces, ties, an estimate of exactly 0, NaN / overflow -- goes to the chain, which recomputes the block's samples.
+                const uint32_t bf = dh_uniform(BS->blk_flags), pieces = (bf >> 8) & 255u;
+                if (P.ordered_timing) {
+                } else if (!(bf & 4u)) {
+                    ordered = false;                            // a hundred symbols of exact zeros: vmin == 0, no step
+                } else if (pieces <= 4u) {
+                    DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
+                    uint64_t vote_guard = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
+                    DH_FOR_LANES_FRESH(lane) {
+                        float l = DH_FLT_MAX, h = DH_FLT_MAX;
+                        bool guard = true;
+                        if (lane < SPS) {
+                            const float total = S.part[lane], e = S.part[SPS + lane] * 0.01f;      // e = mean x^2
+                            const float mean = total * 0.01f;
+                            const float v = __builtin_fmaf(-mean, mean, e);
+                            float tol = __builtin_fmaf(e, 5e-6f, 1e-42f);
+                            if (e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;      // (see the ring kernels' estimate)
+                            guard = e < 1e30f && v != 0.0f;      // false for NaN / overflow, and for an estimate of exactly 0 (which proves nothing)
+                            l = v - tol; h = v + tol;
+                        }
+                        DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
+                        DH_BALLOT_ACC(vote_guard, guard, lane);
+                        DH_BALLOT_ACC(vote_pos, l > 0.0f, lane);
+                        DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
+                    }
+                    float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                    hmin = SPS <= 16 ? dh_row_min_to_lane15(hi[0]) : -dh_wave_max(-hi[0]);
+#else
+                    hmin = DH_FLT_MAX;
+                    for (int q = 0; q < SPS; q++) hmin = dh_fmin_(hmin, hi[q][0]);
+#endif
+                    DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
+                    const uint64_t phases = (1ull << SPS) - 1ull;
+                    const uint64_t cand = ~vote_above & phases;         // phases whose interval reaches below the smallest upper end
+                    if ((vote_guard & phases) != phases) {
+                    } else if (dh_popc64(cand) == 1 && (vote_pos & cand) && (vote_small & cand)) {
+                        ordered = false;
+                        const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
+                        if (vmin_pos > 0 && vmin_pos < (uint32_t) SPS / 2u) new_off = +1;
+                        else if (vmin_pos >= (uint32_t) SPS / 2u && vmin_pos < (uint32_t) SPS - 1u) new_off = -1;
+                    } else if (SPS != 10 && cand != 0) {
+                        chain_rows = cand;                      // (sps 10: not handed on -- one more live value costs that kernel scratch accesses in its hot loop)
+                    }
+                }
+            }
+            if (!RINGLESS && SPS == 10 && !P.ordered_timing) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
                 // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
@@ -2161,7 +2462,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // (the candidates are not handed on here: one more live value costs the 81-tap kernels four scratch accesses in
                 // their hot loop, and they reach this point in 0.02 % of the blocks -- the 161-tap, sps-20 kernel in 1.3 %)
             }
-            if (ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
+            if (!RINGLESS && ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
                 // (sps 33 .. 64, e.g. POCSAG's 40: one lane per phase, chains of 100 + 1 fused terms -- (1 + u)^102 - 1 < 6.1e-6, still
                 // inside the 8e-6 V' below; the float mean is then the reference's own chain, within 100.1 u A of the true one.  The
                 // in-order double chain cost that slicer a fifth of its time, every block.)
@@ -2264,7 +2565,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // by |2 cov(x, d) + var(d)| <= 2 e sigma + e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken
                 // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
                 // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
-                const bool approx_ring = BOUNDED && e_blk > 0.0f;
+                const bool approx_ring = BOUNDED && (e_blk > 0.0f || RINGLESS);      // (ring-less: there is no ring at all -- the block's samples are always recomputed)
                 for (int attempt = (approx_ring && SPS != 10 && sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
                     DH_BARRIER();
                     if (approx_ring && attempt == 1) {
@@ -2279,6 +2580,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         else dh_exact_var_ring<NZ>(C, S, sps);
                         BS->n_exact_blocks++;
                         DH_BARRIER();
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                        if (RINGLESS) __syncthreads();          // the recomputed samples went to scratch in HBM: the chain below reads them back
+#endif
                     }
                     DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1); DH_LANE_ARRAY(uint32_t, iv_ok, 1);
                     DH_FOR_LANES_FRESH(lane) {
@@ -2409,7 +2713,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else { BS->e_cur = ec; BS->e_count = cnt; }
             if (block_done) { BS->prev_start = BS->cur_start; BS->prev_off = BS->cur_off; BS->blk_flags = (BS->blk_flags & 1u) ? 2u : 0u; }
         }
+#if !DH_TAPFRAG_LATE
         DH_TAPFRAG_LOAD();                              // for the next run
+#endif
         DH_CLK(6);
     }
 
@@ -2424,7 +2730,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const uint32_t new_tc = nv - base;                 // = history + unread filtered samples + NZ
     DH_FOR_LANES(lane) {
         for (uint32_t j = lane; j < DH_VOLUME_RB_SIZE; j += DH_WAVE) st[DH_ST_VOL + j] = S.vol_old[j];
-        for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) st[DH_ST_VAR + j] = S.var_rb[j];
+        if (!RINGLESS) { for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) st[DH_ST_VAR + j] = S.var_rb[j]; }
+        else { for (uint32_t j = lane; j < 2u * sps; j += DH_WAVE) st[dh_state_part_offset(sps) + j] = S.part[j]; }
     }
     // the tail may overlap its own source when base < tc: in chunks through LDS (a chunk is read completely before any of
     // it is written, and later chunks only read further ahead)

@@ -64,7 +64,7 @@ int hip_fail(hipError_t e, const char* what) {
 template <int NZ, bool FAST, int SPS>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
+    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
     dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
 }
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
         sym_base = dh_uniform(__hip_atomic_load(P.sym_count + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     {
-        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
+        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
         dh_rrc_demod_channel<NZ, FAST, SPS, (PROTO == DH_PROTO_DSTAR ? 2 : 4)>(P, ch, L, part_lo, part_hi, sym_base);      // (launch_chain checked P.levels)
     }
     // This wavefront's symbol / count stores are read back by its own decoder half below: a WORKGROUP-scope fence (part of
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     const uint32_t last_end = P.split_n0 ? (P.split_n1 ? 2u : 1u) : 0u;
     if (P.split_n0 && P.split_fixup) part_end = last_end;                                 // the fix-up launch finishes the row
     else while (P.split_n0 && part_end < last_end && bid_end >= P.split_pad) { part_end++; bid_end -= P.split_pad; }
-    if (P.split_n0 && (part_end < last_end || P.split_fixup)) {
+    if (P.split_n0) {                                   // (the last part publishes too: the fix-up launch reads how far the row got)
         uint32_t* const flag_end = reinterpret_cast<uint32_t*>(P.state) + (size_t) (bid_end + P.ch_base) * P.state_stride + DH_ST_PART;
         // everything this workgroup stored is in the XCD's L2 before the flag is
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -713,7 +713,7 @@ struct HipBackend {
     }
 
     template <int NZ, bool FAST, int SPS> int go_rrc_demod(const DhDspParams& P) {
-        const size_t lds = dh_dsp_shared_bytes(P.sps, NZ);
+        const size_t lds = dh_dsp_shared_bytes(P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
         if (lds > 48 * 1024) {
             if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
                          "hipFuncSetAttribute")) return -1;
@@ -734,7 +734,7 @@ struct HipBackend {
         return -1;
     }
     template <int NZ, bool FAST, int PROTO, int SPS = 10, bool MAY_SPLIT = false> int go_chain(const DhDspParams& P, const DhDecParams& D) {
-        size_t lds = dh_dsp_shared_bytes(SPS ? (uint32_t) SPS : P.sps, NZ);
+        size_t lds = dh_dsp_shared_bytes(SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
         if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
 #ifdef DH_LDS_PAD
         lds += DH_LDS_PAD;                  // occupancy experiments (tools/build_variant.sh)

@@ -25,6 +25,17 @@ for path in sys.argv[2:] * 2:
         for _ in range(5): eng.push(x)
         eng.sync()
         a, b, c = eng.timing_read()
-        row.append("%s slicer %.2f decoder %.2f" % ("split" if split else "chain", b.mean(), c.mean()))
+        tag = ""
+        if hasattr(eng, "read_rows") and not split:          # what came out, for 128 channels spread over the batch: variants must agree
+            import hashlib
+            pick = list(range(0, B, B // 128))
+            h = hashlib.sha256()
+            for what in ("symbols", "frames"):
+                rows, cnt = eng.read_rows(what, pick)
+                h.update(cnt.tobytes())
+                for j in range(len(pick)):
+                    h.update(rows[j, :cnt[j]].tobytes())
+            tag = " out " + h.hexdigest()[:12]
+        row.append("%s slicer %.3f decoder %.3f%s" % ("split" if split else "chain", b.mean(), c.mean(), tag))
         eng.close()
     print(os.path.basename(path), " | ".join(row), flush=True)
