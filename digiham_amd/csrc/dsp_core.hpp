@@ -686,6 +686,18 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #ifndef DH_P5_PAIRED
 #define DH_P5_PAIRED 1                       // ... and so does the slicing phase
 #endif
+#ifndef DH_P345_MERGED
+#define DH_P345_MERGED 0                     // split-f16 sps-10 kernels: window, AGC and slicing phases as ONE phase on runs that start a variance block (see "P3 - P5 merged"; measured, round 4: five LDS round trips less per run and no faster -- the twenty-word lane stride doubles the bank conflicts of the sample reads -- off)
+#endif
+#ifndef DH_P5_SHORT_STORES
+#define DH_P5_SHORT_STORES 1                 // paired slicing phase: a lane's two dibits leave as one 16-bit store
+#endif
+#ifndef DH_P6_LEAN
+#define DH_P6_LEAN 1                         // sps-10 timing estimate: partial sums meet through DPP instead of LDS, two votes (see P6)
+#endif
+#ifndef DH_EXACT_BATCH
+#define DH_EXACT_BATCH 2                     // exact evaluations of the 81-tap kernels: this many products at a time, their LDS reads in flight together (the 161-tap ones: 8)
+#endif
 #ifndef DH_EXACT_STAGED
 #define DH_EXACT_STAGED 1                    // the exact re-evaluations of the sps-10 kernels stage their raw samples through LDS, like the generic-sps ones
 #endif
@@ -1235,12 +1247,13 @@ DH_HD float dh_exact_filtered_lds(const float* raw, int32_t base, uint32_t nv, c
     // (the 161-tap kernels only: in the 81-tap ones, at 128 registers, the eight products push spills into the hot loop --
     // 24 scratch accesses in the commit phase, DMR chain 6.8 -> 11.9 ms -- and their exact evaluations are 4x rarer and 2x shorter)
     int i = 0;
-    for (; NZ > 80 && i + 8 <= NZ + 1; i += 8) {
-        float prod[8];
+    constexpr int B = NZ > 80 ? 8 : DH_EXACT_BATCH;
+    for (; B > 1 && i + B <= NZ + 1; i += B) {
+        float prod[B];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const int t = i + j; prod[j] = tapsf[t <= NZ / 2 ? t : NZ - t] * x[t]; }
+        for (int j = 0; j < B; j++) { const int t = i + j; prod[j] = tapsf[t <= NZ / 2 ? t : NZ - t] * x[t]; }
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc = acc + prod[j];
+        for (int j = 0; j < B; j++) acc = acc + prod[j];
     }
     for (; i <= NZ; i++) {
         const float prod = tapsf[i <= NZ / 2 ? i : NZ - i] * x[i];
@@ -1271,11 +1284,21 @@ DH_HD void dh_stage_raw(float* raw, const float* tail, uint32_t tc, const float*
     }
     DH_BARRIER();
 }
-// `stage`: LDS floats free at the caller's phase, at least sps + NZ + 2 + 64 of them (the last 64 are the result scratch)
+// `stage`: `cap` LDS floats free at the caller's phase.  The mid-symbol window of symbol k and the ten (sps) samples of every
+// candidate slot are evaluated TOGETHER: their raw samples are staged side by side (areas of STRIDE words), all chains run at once
+// on different lanes, one round of two barriers for the window and up to A - 1 slots -- one after the other (a staging round trip
+// to HBM / L2 and an 81-long dependent chain each, three or four times per doubtful symbol) these evaluations were 3 % of the DMR
+// chain kernel's time for 0.008 % of its symbols.
 template <int NZ>
-DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint32_t k, float* stage, uint32_t sps, uint32_t LO, uint32_t HI) {
+DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint32_t k, float* stage, uint32_t cap, uint32_t sps, uint32_t LO, uint32_t HI) {
     const uint32_t W = HI - LO;
-    float* scratch = stage + sps + NZ + 2;
+    const uint32_t STRIDE = ((W > sps ? W : sps) + (uint32_t) NZ + 1u + 3u) & ~3u;
+    const uint32_t A = (cap - 80u) / STRIDE;                          // areas in front of 64 result words + 16 words of slot table (A >= 2: area 0 is the window's)
+    uint32_t per_round = dh_min<uint32_t>(A - 1u, (DH_WAVE - W) / sps);
+    if (per_round > 8u) per_round = 8u;
+    float* scratch = stage + A * STRIDE;
+    int32_t* tbl_pos = reinterpret_cast<int32_t*>(scratch + DH_WAVE);  // [8] filtered position of the round's slots (INT32_MIN: never written)
+    uint32_t* tbl_slot = reinterpret_cast<uint32_t*>(scratch + DH_WAVE + 8);
     const float mn_a = S.mn[k], mx_a = S.mx[k];
     const float lo_thr = mn_a + 2.5f * C.e_eff, hi_thr = mx_a - 2.5f * C.e_eff;
     uint64_t cand_lo[2] = { 0, 0 }, cand_hi[2] = { 0, 0 };
@@ -1292,35 +1315,68 @@ DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint
         }
         cand_lo[h] = vlo; cand_hi[h] = vhi;
     }
-    // the mid-symbol window of symbol k
+    const int32_t mid_base = dh_slot_position(C, k, k, sps) + (int32_t) LO;
+    float exact_min = DH_FLT_MAX, exact_max = DH_FLT_MIN;            // the reference's seeds (gfsk_demodulator.cpp:110-111)
     float avg_sum = 0.0f;
-    {
-        const int32_t s0 = dh_slot_position(C, k, k, sps);
-        const int32_t base = s0 + (int32_t) LO;
-        dh_stage_raw(stage, C.tail, C.tc, C.in, C.nv, base, W + NZ + 1u);
+    bool first = true;
+    uint64_t todo[2] = { cand_lo[0] | cand_hi[0], cand_lo[1] | cand_hi[1] };
+    while (first || todo[0] || todo[1]) {
+        // this round's slots: the first `ns` set bits of todo, their positions into the table
+        const uint32_t pending = (uint32_t) (dh_popc64(todo[0]) + dh_popc64(todo[1]));
+        const uint32_t ns = dh_min<uint32_t>(pending, per_round);
+        DH_BARRIER();                                                  // the previous round's results and table have been read
         DH_FOR_LANES_FRESH(lane) {
-            if ((uint32_t) lane < W) scratch[lane] = dh_exact_filtered_lds<NZ>(stage, base, C.nv, C.tapsf, C.gain, C.rgain, base + lane);
+            if ((uint32_t) lane < ns) {
+                uint64_t t0 = todo[0], t1 = todo[1];
+                for (uint32_t b = 0; b < (uint32_t) lane; b++) { if (t0) t0 &= t0 - 1; else t1 &= t1 - 1; }
+                const uint32_t j = t0 ? (uint32_t) dh_ffs64(t0) : 64u + (uint32_t) dh_ffs64(t1);
+                tbl_slot[lane] = j; tbl_pos[lane] = dh_slot_position(C, j, k, sps);
+            }
+        }
+        for (uint32_t b = 0; b < ns; b++) { if (todo[0]) todo[0] &= todo[0] - 1; else todo[1] &= todo[1] - 1; }
+        DH_BARRIER();
+        // raw samples of all areas: area 0 = V[mid_base ..) (first round only), area 1 + c = V[pos_c ..); four loads per lane in flight
+        const uint32_t a_lo = first ? 0u : 1u, total = (1u + ns) * STRIDE;
+        DH_FOR_LANES_FRESH(lane) {
+            for (uint32_t e0 = a_lo * STRIDE + (uint32_t) lane; e0 < total; e0 += 4u * DH_WAVE) {
+                float v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t e = e0 + u * DH_WAVE;
+                    const uint32_t a = e < total ? e / STRIDE : a_lo, i = e - a * STRIDE;
+                    const int32_t base = a == 0u ? mid_base : tbl_pos[a - 1u];
+                    const uint32_t count = (a == 0u ? W : sps) + (uint32_t) NZ + 1u;
+                    const int32_t idx = base + (int32_t) i;
+                    const bool have = e < total && i < count && base != INT32_MIN && idx >= 0 && (uint32_t) idx < C.nv;
+                    const uint32_t at = have ? (uint32_t) idx : C.tc;            // (any valid address for the lanes that store a zero)
+                    const float* src = at < C.tc ? C.tail + at : C.in + (at - C.tc);
+                    v[u] = (have || C.nv > C.tc) ? *src : 0.0f;
+                    if (!have) v[u] = 0.0f;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) { const uint32_t e = e0 + u * DH_WAVE; if (e < total) stage[e] = v[u]; }
+            }
         }
         DH_BARRIER();
-        for (uint32_t i = 0; i < W; i++) avg_sum += scratch[i];
-    }
-    float exact_min = DH_FLT_MAX, exact_max = DH_FLT_MIN;            // the reference's seeds (gfsk_demodulator.cpp:110-111)
-    uint64_t todo[2] = { cand_lo[0] | cand_hi[0], cand_lo[1] | cand_hi[1] };
-    for (int h = 0; h < 2; h++) {
-        while (todo[h]) {
-            const uint32_t j = (uint32_t) dh_ffs64(todo[h]) + 64u * (uint32_t) h;
-            todo[h] &= todo[h] - 1;
-            const int32_t s0 = dh_slot_position(C, j, k, sps);
-            float vol = 0.0f;                                        // a slot never written holds an exact zero
-            if (s0 != INT32_MIN) {
-                dh_stage_raw(stage, C.tail, C.tc, C.in, C.nv, s0, sps + NZ + 1u);
-                DH_FOR_LANES_FRESH(lane) {
-                    if ((uint32_t) lane < sps) scratch[lane] = dh_exact_filtered_lds<NZ>(stage, s0, C.nv, C.tapsf, C.gain, C.rgain, s0 + lane);
+        DH_FOR_LANES_FRESH(lane) {
+            float y = 0.0f;
+            if ((uint32_t) lane < W) { if (first) y = dh_exact_filtered_lds<NZ>(stage, mid_base, C.nv, C.tapsf, C.gain, C.rgain, mid_base + lane); }
+            else {
+                const uint32_t c = ((uint32_t) lane - W) / sps, i = ((uint32_t) lane - W) - c * sps;
+                if (c < ns) {
+                    const int32_t s0 = tbl_pos[c];
+                    if (s0 != INT32_MIN) y = dh_exact_filtered_lds<NZ>(stage + (1u + c) * STRIDE, s0, C.nv, C.tapsf, C.gain, C.rgain, s0 + (int32_t) i);
                 }
-                DH_BARRIER();
-                for (uint32_t i = 0; i < sps; i++) vol += scratch[i];
-                vol = dh_div_const(vol, (float) sps, C.sps_rcp);
             }
+            scratch[lane] = y;
+        }
+        DH_BARRIER();
+        if (first) { for (uint32_t i = 0; i < W; i++) avg_sum += scratch[i]; first = false; }
+        for (uint32_t c = 0; c < ns; c++) {
+            float vol = 0.0f;                                        // (a slot never written holds an exact zero: ten zeros above)
+            for (uint32_t i = 0; i < sps; i++) vol += scratch[W + c * sps + i];
+            vol = dh_div_const(vol, (float) sps, C.sps_rcp);
+            const uint32_t j = dh_uniform(tbl_slot[c]);
             if ((cand_lo[j >> 6] >> (j & 63u)) & 1u) exact_min = dh_fmin_(exact_min, vol);
             if ((cand_hi[j >> 6] >> (j & 63u)) & 1u) exact_max = dh_fmax_(exact_max, vol);
         }
@@ -1404,6 +1460,30 @@ DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps
     }
 }
 
+
+// Diagnostic builds (results unchanged): DH_PROBE_AT=<place> adds DH_PROBE_N independent v_add_f32 (or, with DH_PROBE_SALU, dependent
+// s_add_u32) at one place of the run loop -- 0: in front of the FIR, 1: behind the FIR's write-back, 2: behind the window phase,
+// 3: in front of the slicing phase, 4: in front of the timing phase, 5: in front of the commit, 6: at the end of the iteration.
+// Same instructions, different places: where does the step time respond?  (tools/README.md)
+#if defined(DH_PROBE_AT) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#ifndef DH_PROBE_N
+#define DH_PROBE_N 128
+#endif
+__device__ __forceinline__ void dh_probe_body() {
+#ifdef DH_PROBE_SALU
+#pragma unroll
+    for (int u = 0; u < DH_PROBE_N; u++) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
+#else
+    float xv[8]; for (int j = 0; j < 8; j++) xv[j] = (float) j;
+#pragma unroll
+    for (int u = 0; u < DH_PROBE_N; u++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xv[u & 7]));
+    asm volatile("" :: "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(xv[4]), "v"(xv[5]), "v"(xv[6]), "v"(xv[7]));
+#endif
+}
+#define DH_PROBE(place) do { if ((place) == DH_PROBE_AT) dh_probe_body(); } while (0)
+#else
+#define DH_PROBE(place) ((void) 0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
 // once (host harness; the DH_FOR_LANES loops then iterate the lanes).
@@ -1421,6 +1501,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
     constexpr bool RINGLESS = DhIsRingless<NZ, FAST, SPS>::value;                                     // no variance ring in LDS: per-phase sums instead (see DH_RINGLESS)
+    // P3 - P5 merged (below): the filtered samples of a run then start FOFF words into the window block, so that the copy of symbol 0
+    // one word in front of its place (a pending step of -1) stays inside the block
+    constexpr bool CAN_MERGE = DH_P345_MERGED && MF16 && SPS == 10 && !RINGLESS && NZ == 80 && DH_STOP_AFTER >= 99;
+    constexpr uint32_t FOFF = CAN_MERGE ? 4u : 0u;
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -1442,6 +1526,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     DH_CLK_BEGIN();
 #if defined(DH_WAVE_TIMELINE) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     const uint32_t dh_t_start = (uint32_t) wall_clock64();        // diagnostic build: when this channel's wavefront ran (100 MHz)
+#endif
+#if defined(DH_STAGGER) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    // diagnostic builds: wavefronts start up to DH_STAGGER x 64 cycles apart (do the wavefronts of the chip move in lock-step?)
+    for (uint32_t w = (ch * 37u) % (uint32_t) DH_STAGGER; w >= 8u; w -= 8u) __builtin_amdgcn_s_sleep(8);
 #endif
     // ---- load carried state
     uint32_t k0 = sth[DH_ST_K];
@@ -1622,6 +1710,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         const uint32_t last_start = p + (m - 1) * sps + (m > 1 ? (uint32_t) step_off : 0u);
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
+        const bool merged = CAN_MERGE && DH_LIKELY(k0 == 0);     // a run that starts a variance block: ring slot == symbol index
         // (bits 2.. of blk_flags, ring-less kernels: 4 = some run of the current block had a non-zero window, bits 8..15 = runs the block has been cut into)
         if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags = (BS->blk_flags & 3u) | 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
         bool use_exact = BOUNDED && P.exact_mode == 2;  // this run through the exact FIR (odd samples, odd staging path)
@@ -1766,6 +1855,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else use_exact = true;                      // tiny, huge or infinite samples: outside the bound's assumptions
         }
         DH_CLK(0);
+        DH_PROBE(0);
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
         // The filtered samples go back UNPADDED (element n at word n, four 16-byte stores per lane): the symbol
@@ -1873,11 +1963,19 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_BARRIER();
             if (MF16 && mf_layout == 2) {
                 DH_FOR_LANES_FRESH(lane) {
-                    float* dst = S.xf + DH_F16_OUT(0, 0, lane >> 4, lane & 15);
+                    float* dst = S.xf + FOFF + DH_F16_OUT(0, 0, lane >> 4, lane & 15);
 #pragma unroll
                     for (int T = 0; T < 4; T++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) dst[DH_F16_OUT(T, r, 0, 0)] = DH_LA(fo, lane)[4 * T + r];
+                }
+                // P3 - P5 merged: symbol 0 sits in FRONT of the pending step, every other symbol behind it; a second copy of
+                // its ten samples `step_off` words further (lanes 0..9 hold them: sample n of the run is register 0 of lane n)
+                // puts the whole run on one grid of ten words.  The words it overwrites belong to symbol 0 alone (and the one
+                // skipped sample); LDS stores of a wavefront land in program order, so this one, issued after every lane's
+                // sixteen, wins.
+                if (CAN_MERGE && merged && step_off != 0) {
+                    DH_FOR_LANES_FRESH(lane) { if (lane < 10) S.xf[(int32_t) (FOFF + (uint32_t) lane) + step_off] = DH_LA(fo, lane)[0]; }
                 }
             } else if (MFMA && mf_layout == 1) {
                 // sample DH_MF_OUT(T, r, g, n) of the run from register 4 T + r of lane 16 g + n: compile-time offsets
@@ -1891,7 +1989,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             } else {
                 DH_FOR_LANES_FRESH(lane) {
                     if ((uint32_t) (lane * DH_FIR_L) < need) {
-                        dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
+                        dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + FOFF + DH_FIR_L * lane);
 #pragma unroll
                         for (int j = 0; j < DH_FIR_L / 4; j++) {
                             dh_f4a v; v.x = DH_LA(fo, lane)[4 * j]; v.y = DH_LA(fo, lane)[4 * j + 1];
@@ -1899,6 +1997,13 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                             dst[j] = v;
                         }
                     }
+                }
+                if (CAN_MERGE && merged && step_off != 0) {        // (the reference-order FIR of a split-f16 kernel, a rare run: symbol 0 copied as above, from LDS)
+                    DH_BARRIER();
+                    DH_LANE_ARRAY(float, s0, 1);
+                    DH_FOR_LANES_FRESH(lane) { DH_LA(s0, lane)[0] = S.xf[FOFF + (uint32_t) (lane < 10 ? lane : 0)]; }
+                    DH_BARRIER();
+                    DH_FOR_LANES_FRESH(lane) { if (lane < 10) S.xf[(int32_t) (FOFF + (uint32_t) lane) + step_off] = DH_LA(s0, lane)[0]; }
                 }
             }
             DH_BARRIER();
@@ -1912,8 +2017,242 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         DH_TAPFRAG_SETTLE();
         DH_CLK(1);
-        const float* fbuf = S.xf;
+        DH_PROBE(1);
+        const float* fbuf = S.xf + FOFF;
 #define DH_FB(n) fbuf[n]
+
+        // ---- prefetch: the raw window of the NEXT run.  Its start is already known (the timing decision of this
+        // block only moves symbols 1.. of the next one), the window block is idle from here to the end of the
+        // iteration, and P4-P6 are latency-bound with few live registers: the HBM latency of these loads hides
+        // behind them.  Five 16-byte loads per lane, parked in registers until P7.
+        const uint32_t p_next = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
+        const bool pf_ok = p_next >= tc && p_next < nv;
+        const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
+#if !DH_PF_L2
+        DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
+#endif
+        DH_LANE_ARRAY(dh_f4, pfr, PF_REG ? DH_PF_N : 1);  // split-f16 kernels: the next window, parked in registers through P4 - P6
+        // Only when the whole window lies inside the input buffer (every run but the last ones of the last
+        // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
+        // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
+        const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
+        const bool pf_reg = PF_REG && pf_plain && P.exact_mode != 2;
+        auto issue_next_window = [&]() __attribute__((always_inline)) {
+        if (DH_LIKELY(pf_reg)) {
+            // The split-f16 FIR leaves registers free where the packed-FMA FIR had none: the next window's five 16-byte loads
+            // per lane are issued here, straight from HBM, land while P4 - P6 run, and P7 turns them into the two arrays of
+            // halves -- the next iteration starts at the matrix cores.
+            constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;
+            const float* src = in + (p_next - tc);
+            DH_FOR_LANES_FRESH(lane) {
+                const float* lsrc = src + 4u * (uint32_t) lane;
+                const bool in_last = (uint32_t) lane < LAST_LANES;
+#pragma unroll
+                for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(pfr, lane)[PF_REG ? r : 0] = dh_load4_stream(lsrc + 4 * DH_WAVE * r);
+                DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_stream(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+            }
+        } else {
+#if DH_PF_L2
+        // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
+        // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The dwords themselves are not
+        // wanted: global_load_lds_dword drops them (lane l -> m0 + 4 l) into a part of the window block that is dead
+        // until the next staging, so no vector register is tied to a load the compiler does not know about.  They
+        // have landed before the next P1 stores anything there (its own, younger loads are waited for first), and
+        // an explicit s_waitcnt follows the loop for the last one.
+        if (pf_plain) {
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t pf_lane = (uint32_t) dh_fresh_lane_id_();       // not loop-invariant: a hoisted address is spilled
+            const float* line = in + (p_next - tc) + 32u * pf_lane;
+            const uint32_t sink = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) (S.xf + DH_PF_SINK);
+            uint32_t keep_m0;
+            if (32u * pf_lane < DH_FTILE + NZ)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep_m0) : "s"(sink), "v"(line) : "memory");
+#endif
+        }
+#else
+        if (pf_plain) {
+            const float* src = in + (p_next - tc);
+            DH_FOR_LANES_FRESH(lane) {
+#pragma unroll
+                for (int r = 0; r < DH_PF_N; r++) {
+                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
+                    DH_LA(pf, lane)[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
+                }
+            }
+        }
+#endif
+        }
+        };
+
+        DH_COMPILER_FENCE();                            // the bookkeeping in LDS is read here, not carried across the FIR
+        float e_blk = 0.0f;
+        if (BOUNDED) { e_blk = dh_uniform_f(__builtin_fmaxf(BS->e_blk, e_run)); BS->e_blk = e_blk; }
+        if (RINGLESS) {                                 // one more piece of the current block; did its window hold anything but zeros?
+            const uint32_t f = dh_uniform(BS->blk_flags), pieces = dh_min<uint32_t>(((f >> 8) & 255u) + 1u, 255u);
+            BS->blk_flags = (f & ~0xFF00u) | (pieces << 8) | ((use_exact || e_run > 0.0f) ? 4u : 0u);
+        }
+        const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
+        const float T = DH_BOUND_T_FACTOR * e_eff;
+        uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
+        // Straight-line per half of the run (m <= 100 symbols: lanes 0..63, then 0..35): every lane computes, a predicate
+        // guards the store -- written as a loop over the lane's symbols this compiled to a real loop with exec-mask
+        // bookkeeping (half of this phase's instructions were scalar).  The wave-uniform choices (4 / 2 levels, invert,
+        // exact_mode) are selects, not branches.
+        const bool four_levels = LV ? LV == 4 : P.levels == 4;
+        // (DH_FLAG_EXACT_SYMBOLS -- every symbol decided exactly -- is an infinite threshold, not another mask)
+        const bool force_doubt = BOUNDED && P.exact_mode == 1;
+        const bool e_pos = e_eff > 0.0f || force_doubt;
+        const float T_eff = force_doubt ? __builtin_inff() : T;
+        const float inv_width = 1.0f / (float) (ev_hi - ev_lo);                       // (a power of two for sps 10: the product below is the division)
+        const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
+        const bool pair_store = ((uint32_t) (uintptr_t) syms + nsym) % 2u == 0u;      // (paired slicing phases: symbols 2 l, 2 l + 1 of the run as one 16-bit store)
+
+        // ---- P3 - P5 merged (split-f16 sps-10 kernels, runs that start a variance block: ring slot == symbol index).
+        // As three phases, symbol windows -> AGC scans -> slicing hand the sums, the volumes and the extremes of every symbol from
+        // one lane mapping to the next through LDS: six dependent LDS round trips per run on a wavefront that has three others to
+        // hide behind, and a step that follows the latency of a run.  Here lane l owns symbols 2 l and 2 l + 1 from the samples
+        // to the dibits: their samples are twenty consecutive words from ONE base (the copy of symbol 0 made behind the FIR put
+        // the whole run on one grid), a ds_read2_b32 delivers sample i of both, the sums are packed additions, the two volumes are
+        // this lane's entries of the prefix scans as they stand, and the extremes never leave the registers.  Only the suffix
+        // extremes of the OLD ring pass through LDS (read backwards, scanned forwards, handed to the owning lanes -- as in
+        // dh_agc_scan), and they depend on nothing this run computes: that exchange runs beside the sample reads.  Every
+        // operation is the one the three-phase form performs on the same operands in the same order (sums in sample order,
+        // dh_div_const2, v_min / v_max scans, one FMA per threshold), so dibits and doubts are the same; the old form still
+        // takes every run that starts inside a block (the first of a push).
+        DH_LANE_ARRAY(dh_f2, mg_volume, 1); DH_LANE_ARRAY(dh_f2, mg_mn, 1); DH_LANE_ARRAY(dh_f2, mg_mx, 1);
+        if (CAN_MERGE && merged) {
+            float* const xch_mn = S.vol_new;            // suffix extremes of the old ring per slot (S.vol_new is otherwise unused on this path)
+            float* const xch_mx = S.sum;                // (behind the last filtered sample)
+            DH_LANE_ARRAY(dh_f2, mg_mid, 1);
+            (void) xch_mn; (void) xch_mx;
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t l = (uint32_t) lane, lc = l < 50u ? l : 49u;          // (lanes beyond the run repeat lane 49's reads and store nothing)
+                const bool va = 2u * l < m, vb = 2u * l + 1u < m;
+                const float* src = fbuf + step_off + (int32_t) (20u * lc);
+                dh_f2 v[10];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                {
+                    // Issue order: the lane's two entries of the OLD ring read backwards (slots 126 - 2 l and 127 - 2 l), then the
+                    // twenty samples.  LDS answers in order, so the ring entries are there while the samples are still on their
+                    // way (lgkmcnt(10)): the suffix scan and its exchange stores run inside the samples' latency.
+                    const uint32_t r0 = 126u - 2u * l, r1 = r0 + 1u;
+                    const uint32_t ao = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (S.vol_old + r0);
+                    const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
+                    dh_f2 o;
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(o) : "v"(ao) : "memory");
+                    v[0] = dh_lds_read2<0, 10>(a); v[1] = dh_lds_read2<1, 11>(a); v[2] = dh_lds_read2<2, 12>(a); v[3] = dh_lds_read2<3, 13>(a);
+                    v[4] = dh_lds_read2<4, 14>(a); v[5] = dh_lds_read2<5, 15>(a); v[6] = dh_lds_read2<6, 16>(a); v[7] = dh_lds_read2<7, 17>(a);
+                    v[8] = dh_lds_read2<8, 18>(a); v[9] = dh_lds_read2<9, 19>(a);
+                    asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(o) :: "memory");
+                    const float omn0 = r0 < DH_VOLUME_RB_SIZE ? o.x : DH_FLT_MAX, omn1 = r1 < DH_VOLUME_RB_SIZE ? o.y : DH_FLT_MAX;
+                    const float omx0 = r0 < DH_VOLUME_RB_SIZE ? o.x : DH_FLT_MIN, omx1 = r1 < DH_VOLUME_RB_SIZE ? o.y : DH_FLT_MIN;
+                    float smn = dh_vmin(omn0, omn1), smx = dh_vmax(omx0, omx1);
+                    dh_wave_prefix_minmax(smn, smx);
+                    const float esmn = dh_wave_prev(smn, DH_FLT_MAX), esmx = dh_wave_prev(smx, DH_FLT_MIN);
+                    // exclusive suffix of slot r1, then of slot r0 (= r1's, and r1 itself)
+                    xch_mn[r1] = esmn; xch_mx[r1] = esmx;
+                    xch_mn[r0] = dh_vmin(omn1, esmn); xch_mx[r0] = dh_vmax(omx1, esmx);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]) :: "memory");
+                }
+#else
+                for (int i = 0; i < 10; i++) v[i] = dh_f2_make(src[i], src[10 + i]);
+#endif
+                dh_f2 vol = v[0];
+#pragma unroll
+                for (int i = 1; i < 10; i++) vol = dh_f2_add(vol, v[i]);
+                const dh_f2 mid = dh_f2_add(dh_f2_add(dh_f2_add(v[3], v[4]), v[5]), v[6]);          // samples ev_lo .. ev_hi - 1 = 3 .. 6
+                const dh_f2 volume = dh_div_const2(vol, 10.0f, sps_rcp);
+                float* ring = S.var_rb + 2u * lc;                                                     // transposed ring: phase-major
+                if (vb) {
+                    dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);
+                    dh_lds_store_row10<1>(ring, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y);
+                } else if (va) dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);
+                DH_LA(mg_volume, lane)[0] = volume; DH_LA(mg_mid, lane)[0] = mid;
+#if !(DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__))
+                if (va) { S.vol_new[2u * l] = volume.x; }          // harness: the scans below are dh_agc_scan's sequential statement
+                if (vb) { S.vol_new[2u * l + 1u] = volume.y; }
+#endif
+            }
+            DH_CLK(2);
+            issue_next_window();
+            // the AGC extremes of the lane's two symbols
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            {
+                const uint32_t l = (uint32_t) dh_fresh_lane_id_();
+                const bool va = 2u * l < m, vb = 2u * l + 1u < m;
+                const dh_f2 sn = *reinterpret_cast<const dh_f2*>(xch_mn + 2u * l), sx = *reinterpret_cast<const dh_f2*>(xch_mx + 2u * l);
+                const float c0 = mg_volume[0].x, c1 = mg_volume[0].y;
+                const float pmn0 = va ? c0 : DH_FLT_MAX, pmn1 = vb ? c1 : DH_FLT_MAX;
+                const float pmx0 = va ? c0 : DH_FLT_MIN, pmx1 = vb ? c1 : DH_FLT_MIN;
+                float pmn = dh_vmin(pmn0, pmn1), pmx = dh_vmax(pmx0, pmx1);
+                dh_wave_prefix_minmax(pmn, pmx);
+                const float epmn = dh_wave_prev(pmn, DH_FLT_MAX), epmx = dh_wave_prev(pmx, DH_FLT_MIN);
+                mg_mn[0] = dh_f2_make(dh_vmin(dh_vmin(epmn, pmn0), sn.x), dh_vmin(pmn, sn.y));
+                mg_mx[0] = dh_f2_make(dh_vmax(dh_vmax(epmx, pmx0), sx.x), dh_vmax(pmx, sx.y));
+            }
+#else
+            dh_agc_scan(S, 0, m);                       // (S.mn / S.mx alias the filtered samples, which every lane has consumed by now)
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t k = 2u * (uint32_t) lane < m ? 2u * (uint32_t) lane : 0u;
+                DH_LA(mg_mn, lane)[0] = dh_f2_make(S.mn[k], S.mn[k + 1u]); DH_LA(mg_mx, lane)[0] = dh_f2_make(S.mx[k], S.mx[k + 1u]);
+            }
+#endif
+            DH_CLK(3);
+            // thresholds + slice (gfsk_demodulator.cpp:88-106): the two-symbols-per-lane form of P5 below, operands from registers
+            uint64_t vote_a = 0, vote_b = 0;
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t qa = 2u * (uint32_t) lane;
+                const bool va = qa < m, vb = qa + 1u < m;
+                const dh_f2 mn = DH_LA(mg_mn, lane)[0], mx = DH_LA(mg_mx, lane)[0], sumq = DH_LA(mg_mid, lane)[0];
+                const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);
+                const dh_f2 average = dh_f2_scale(sumq, inv_width);                  // (ev_hi - ev_lo = 4: the product is the division)
+                const dh_f2 c625 = dh_f2_make(0.625f, 0.625f);
+                const dh_f2 umid = dh_f2_fma(dh_f2_sub(mx, center), c625, center);
+                const dh_f2 lmid = dh_f2_fma(dh_f2_sub(mn, center), c625, center);
+                const bool above_a = average.x > center.x, above_b = average.y > center.y;
+                const uint8_t sym4a = above_a ? (average.x > umid.x ? 1 : 0) : (average.x < lmid.x ? 3 : 2);
+                const uint8_t sym4b = above_b ? (average.y > umid.y ? 1 : 0) : (average.y < lmid.y ? 3 : 2);
+                const uint8_t sym2a = LV == 4 ? (uint8_t) 0 : above_a ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+                const uint8_t sym2b = LV == 4 ? (uint8_t) 0 : above_b ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+                const uint8_t sa = four_levels ? sym4a : sym2a, sb = four_levels ? sym4b : sym2b;
+                bool doubt_a = false, doubt_b = false;
+                if (BOUNDED) {
+                    const dh_f2 du = dh_f2_sub(average, umid), dl = dh_f2_sub(average, lmid), dc = dh_f2_sub(average, center);
+                    const float da = dh_min3_abs(four_levels ? du.x : DH_FLT_MAX, four_levels ? dl.x : DH_FLT_MAX, dc.x);
+                    const float db = dh_min3_abs(four_levels ? du.y : DH_FLT_MAX, four_levels ? dl.y : DH_FLT_MAX, dc.y);
+                    doubt_a = va && e_pos && !(da > T_eff);
+                    doubt_b = vb && e_pos && !(db > T_eff);
+                }
+#ifdef DH_IGNORE_DOUBT
+                doubt_a = false; doubt_b = false;
+#endif
+#if DH_P5_SHORT_STORES
+                if (pair_store && va && !doubt_a && vb && !doubt_b) *reinterpret_cast<uint16_t*>(syms + nsym + qa) = (uint16_t) ((uint32_t) sa | ((uint32_t) sb << 8));
+                else
+#endif
+                {
+                    if (va && !doubt_a) syms[nsym + qa] = sa;
+                    if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
+                }
+                DH_BALLOT_ACC(vote_a, doubt_a, lane);
+                DH_BALLOT_ACC(vote_b, doubt_b, lane);
+            }
+            if (DH_UNLIKELY((vote_a | vote_b) != 0)) {
+                for (uint32_t l = 0; l < 50u; l++) {
+                    if ((vote_a >> l) & 1ull) unsure[(2u * l) >> 6] |= 1ull << ((2u * l) & 63u);
+                    if ((vote_b >> l) & 1ull) unsure[(2u * l + 1u) >> 6] |= 1ull << ((2u * l + 1u) & 63u);
+                }
+                // what the exact evaluation of a symbol looks at: the extremes and this run's volumes, per slot
+                DH_BARRIER();
+                DH_FOR_LANES_FRESH(lane) {
+                    const uint32_t qa = 2u * (uint32_t) lane;
+                    if (qa < m) { S.mn[qa] = DH_LA(mg_mn, lane)[0].x; S.mx[qa] = DH_LA(mg_mx, lane)[0].x; S.vol_new[qa] = DH_LA(mg_volume, lane)[0].x; }
+                    if (qa + 1u < m) { S.mn[qa + 1u] = DH_LA(mg_mn, lane)[0].y; S.mx[qa + 1u] = DH_LA(mg_mx, lane)[0].y; S.vol_new[qa + 1u] = DH_LA(mg_volume, lane)[0].y; }
+                }
+                DH_BARRIER();
+            }
+        }
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
 #if DH_P3_PAIRED
@@ -1927,7 +2266,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // as the reference's do) and the division; loads and stores carry their offsets as immediates, so the phase costs ~35
         // vector instructions instead of the ~85 of two passes of one symbol per lane.  Lanes beyond the run read words of the
         // window block that nothing will look at (possibly halves of the staged arrays) and store nothing.
-        if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        if (SPS == 10 && DH_STOP_AFTER >= 3 && !merged) DH_FOR_LANES_FRESH(lane) {
             const uint32_t l = (uint32_t) lane;
             const uint32_t qa = l < 51u ? l + 1u + (l >= 24u ? 24u : 0u) : 0u, qb = qa + 24u;
             const bool va = (l < 48u || l == 51u) && qa < m, vb = l < 51u && qb < m;
@@ -1967,7 +2306,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         if (SPS != 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
 #else
-        if (DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        if (DH_STOP_AFTER >= 3 && !merged) DH_FOR_LANES_FRESH(lane) {
 #endif
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
@@ -2072,104 +2411,67 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         DH_BARRIER();
         DH_CLK(2);
+        DH_PROBE(2);
 
-        // ---- prefetch: the raw window of the NEXT run.  Its start is already known (the timing decision of this
-        // block only moves symbols 1.. of the next one), the window block is idle from here to the end of the
-        // iteration, and P4-P6 are latency-bound with few live registers: the HBM latency of these loads hides
-        // behind them.  Five 16-byte loads per lane, parked in registers until P7.
-        const uint32_t p_next = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
-        const bool pf_ok = p_next >= tc && p_next < nv;
-        const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
-#if !DH_PF_L2
-        DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
-#endif
-        DH_LANE_ARRAY(dh_f4, pfr, PF_REG ? DH_PF_N : 1);  // split-f16 kernels: the next window, parked in registers through P4 - P6
-        // Only when the whole window lies inside the input buffer (every run but the last ones of the last
-        // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
-        // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
-        const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
-        const bool pf_reg = PF_REG && pf_plain && P.exact_mode != 2;
-        if (DH_LIKELY(pf_reg)) {
-            // The split-f16 FIR leaves registers free where the packed-FMA FIR had none: the next window's five 16-byte loads
-            // per lane are issued here, straight from HBM, land while P4 - P6 run, and P7 turns them into the two arrays of
-            // halves -- the next iteration starts at the matrix cores.
-            constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;
-            const float* src = in + (p_next - tc);
-            DH_FOR_LANES_FRESH(lane) {
-                const float* lsrc = src + 4u * (uint32_t) lane;
-                const bool in_last = (uint32_t) lane < LAST_LANES;
-#pragma unroll
-                for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(pfr, lane)[PF_REG ? r : 0] = dh_load4_stream(lsrc + 4 * DH_WAVE * r);
-                DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_stream(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
-            }
-        } else {
-#if DH_PF_L2
-        // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
-        // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The dwords themselves are not
-        // wanted: global_load_lds_dword drops them (lane l -> m0 + 4 l) into a part of the window block that is dead
-        // until the next staging, so no vector register is tied to a load the compiler does not know about.  They
-        // have landed before the next P1 stores anything there (its own, younger loads are waited for first), and
-        // an explicit s_waitcnt follows the loop for the last one.
-        if (pf_plain) {
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            const uint32_t pf_lane = (uint32_t) dh_fresh_lane_id_();       // not loop-invariant: a hoisted address is spilled
-            const float* line = in + (p_next - tc) + 32u * pf_lane;
-            const uint32_t sink = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) (S.xf + DH_PF_SINK);
-            uint32_t keep_m0;
-            if (32u * pf_lane < DH_FTILE + NZ)
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep_m0) : "s"(sink), "v"(line) : "memory");
-#endif
-        }
-#else
-        if (pf_plain) {
-            const float* src = in + (p_next - tc);
-            DH_FOR_LANES_FRESH(lane) {
-#pragma unroll
-                for (int r = 0; r < DH_PF_N; r++) {
-                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                    DH_LA(pf, lane)[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
-                }
-            }
-        }
-#endif
-        }
+        if (!merged) issue_next_window();
 
         // ---- P4: sliding AGC min/max as two wave scans
-        if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
+        if (DH_STOP_AFTER >= 4 && !merged) dh_agc_scan(S, k0, k0 + m);
         DH_BARRIER();
         DH_CLK(3);
+        DH_PROBE(3);
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && (defined(DH_EXTRA_VALU) || defined(DH_EXTRA_CVT) || defined(DH_EXTRA_LDS) || defined(DH_EXTRA_MFMA) || defined(DH_EXTRA_SALU) || defined(DH_EXTRA_SLEEP))
+        // Diagnostic builds (results unchanged): what does the step time respond to?  n extra instructions of one kind per run,
+        // in independent chains, between the AGC scans and the slicing phase (tools/sensitivity.sh).
+        {
+            float xv[8]; for (int j = 0; j < 8; j++) xv[j] = (float) j;
+#ifdef DH_EXTRA_VALU
+#pragma unroll
+            for (int u = 0; u < DH_EXTRA_VALU; u++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xv[u & 7]));
+#endif
+#ifdef DH_EXTRA_CVT
+#pragma unroll
+            for (int u = 0; u < DH_EXTRA_CVT; u++) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(xv[u & 7]));
+#endif
+#ifdef DH_EXTRA_SALU
+#pragma unroll
+            for (int u = 0; u < DH_EXTRA_SALU; u++) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
+#endif
+#ifdef DH_EXTRA_SLEEP
+            asm volatile("s_sleep %0" :: "n"(DH_EXTRA_SLEEP));        // units of 64 cycles: pure latency, no issue
+#endif
+#ifdef DH_EXTRA_LDS
+            {
+                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) S.xf + 16u * (uint32_t) dh_fresh_lane_id_();
+                dh_u4 sink[4];
+#pragma unroll
+                for (int u = 0; u < DH_EXTRA_LDS; u++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink[u & 3]) : "v"(a), "n"(1024 * (u & 3)));
+                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(sink[0]), "v"(sink[1]), "v"(sink[2]), "v"(sink[3]));
+            }
+#endif
+#ifdef DH_EXTRA_MFMA
+            {
+                dh_f32x4 acc[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+                dh_h8 za = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+                for (int u = 0; u < DH_EXTRA_MFMA; u++) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(za, za, acc[u & 3], 0, 0, 0);
+                asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+            }
+#endif
+            asm volatile("" :: "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(xv[4]), "v"(xv[5]), "v"(xv[6]), "v"(xv[7]));
+        }
+#endif
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
         // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
         // reference's; those symbols are not stored here but decided exactly below
-        DH_COMPILER_FENCE();                            // the bookkeeping in LDS is read here, not carried across the FIR
-        float e_blk = 0.0f;
-        if (BOUNDED) { e_blk = dh_uniform_f(__builtin_fmaxf(BS->e_blk, e_run)); BS->e_blk = e_blk; }
-        if (RINGLESS) {                                 // one more piece of the current block; did its window hold anything but zeros?
-            const uint32_t f = dh_uniform(BS->blk_flags), pieces = dh_min<uint32_t>(((f >> 8) & 255u) + 1u, 255u);
-            BS->blk_flags = (f & ~0xFF00u) | (pieces << 8) | ((use_exact || e_run > 0.0f) ? 4u : 0u);
-        }
-        const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
-        const float T = DH_BOUND_T_FACTOR * e_eff;
-        uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
-        // Straight-line per half of the run (m <= 100 symbols: lanes 0..63, then 0..35): every lane computes, a predicate
-        // guards the store -- written as a loop over the lane's symbols this compiled to a real loop with exec-mask
-        // bookkeeping (half of this phase's instructions were scalar).  The wave-uniform choices (4 / 2 levels, invert,
-        // exact_mode) are selects, not branches.
-        const bool four_levels = LV ? LV == 4 : P.levels == 4;
-        // (DH_FLAG_EXACT_SYMBOLS -- every symbol decided exactly -- is an infinite threshold, not another mask)
-        const bool force_doubt = BOUNDED && P.exact_mode == 1;
-        const bool e_pos = e_eff > 0.0f || force_doubt;
-        const float T_eff = force_doubt ? __builtin_inff() : T;
-        const float inv_width = 1.0f / (float) (ev_hi - ev_lo);                       // (a power of two for sps 10: the product below is the division)
-        const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
 #if DH_P5_PAIRED
+        // (runs that start inside a variance block; the others were sliced by the merged phase above)
         // TWO symbols per lane, q = 2 lane and 2 lane + 1 (a run has at most 100): their AGC extremes, window sums and everything
         // derived from them are pairs, so centre, average, the two thresholds and the three distances are packed operations for
         // both symbols -- one pass of ~40 vector instructions instead of two of ~37.  Every operation is the one the one-symbol
         // form performs (same operands, same order), so the dibits and the doubts are the same.
-        if (DH_STOP_AFTER >= 5) {
+        if (DH_STOP_AFTER >= 5 && !merged) {
         uint64_t vote_a = 0, vote_b = 0;
         DH_FOR_LANES_FRESH(lane) {
             const uint32_t qa = 2u * (uint32_t) lane;
@@ -2202,6 +2504,13 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #ifdef DH_P5_NOSTORE
             if (va && !doubt_a && sa == 77) syms[nsym + qa] = sa;
             if (vb && !doubt_b && sb == 77) syms[nsym + qa + 1u] = sb;
+#elif DH_P5_SHORT_STORES
+            // the lane's two dibits are neighbours: one 16-bit store when the row position is even (wave-uniform) and both are decided
+            if (pair_store && va && !doubt_a && vb && !doubt_b) *reinterpret_cast<uint16_t*>(syms + nsym + qa) = (uint16_t) ((uint32_t) sa | ((uint32_t) sb << 8));
+            else {
+                if (va && !doubt_a) syms[nsym + qa] = sa;
+                if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
+            }
 #else
             if (va && !doubt_a) syms[nsym + qa] = sa;
             if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
@@ -2220,7 +2529,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #else
 #pragma unroll
         for (uint32_t h = 0; h < 2; h++) {
-        if (h * DH_WAVE < m && DH_STOP_AFTER >= 5) {
+        if (h * DH_WAVE < m && DH_STOP_AFTER >= 5 && !merged) {
         uint64_t vote_unsure = 0;
         DH_FOR_LANES_FRESH(lane) {
             const uint32_t q = h * DH_WAVE + (uint32_t) lane;
@@ -2276,7 +2585,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     todo &= todo - 1;
                     // (the raw samples behind each evaluation staged through the dead part of the window block: fetched one by
                     // one from HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
-                    const uint8_t sym = DH_EXACT_STAGED || SPS != 10 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, sps, ev_lo, ev_hi)
+                    const uint8_t sym = DH_EXACT_STAGED || SPS != 10 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi)
                                                  : dh_exact_symbol<NZ, 10>(C, S, k0 + q, S.xf + 640);
                     DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
                     BS->n_uncertain++;
@@ -2284,7 +2593,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
 
+        if (CAN_MERGE && merged) {                     // the merged phase's volumes into the ring (the exact evaluations above still saw the old entries)
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t qa = 2u * (uint32_t) lane;
+                if (qa < m) S.vol_old[qa] = DH_LA(mg_volume, lane)[0].x;
+                if (qa + 1u < m) S.vol_old[qa + 1u] = DH_LA(mg_volume, lane)[0].y;
+            }
+        }
         DH_CLK(4);
+        DH_PROBE(4);
         // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
         // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
         // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
@@ -2363,7 +2680,97 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     }
                 }
             }
+            bool est_done = false;
+#if DH_P6_LEAN
+            // The same estimate without its LDS exchange and with two votes instead of six.  Lane 16 r + 5 j + g takes piece g (20
+            // symbols) of phase i = 3 r + j -- three phases per DPP row, so that the five partial sums of a phase are five neighbouring
+            // lanes of one row and meet through row_shr (lane g = 4 of each group: ((s4 + s3) + (s2 + s1)) + s0, three roundings
+            // where the exchange form has four: the tolerance derived below covers it).  The ten lanes that then hold a phase form
+            // its interval; `above` (ruled out by the smallest upper end) and `fine` (guard holds, estimate not exactly 0, and the
+            // lane is either ruled out or positive and below 5e6) are the only votes: one candidate and every lane fine is the case
+            // decided here -- everything else (an estimate of exactly 0, NaN / overflow, ties) is left to the full form below, which
+            // starts over.  ~100 instructions instead of ~260 per block.
             if (!RINGLESS && SPS == 10 && !P.ordered_timing) {
+                DH_LANE_ARRAY(float, gs, 1); DH_LANE_ARRAY(float, gq, 1);
+                DH_FOR_LANES_FRESH(lane) {
+                    const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
+                    const uint32_t j = (c * 205u) >> 10, g = c - 5u * j, i = 3u * r + j;      // c / 5, c % 5
+                    const bool act = c < 15u && i < 10u;
+                    const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + (act ? i * DH_VARIANCE_SYMBOLS + g * 20u : 0u));
+                    dh_f2 s2 = dh_f2_make(0.0f, 0.0f), q2 = dh_f2_make(0.0f, 0.0f);
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        const dh_f4a v = row[q];
+                        const dh_f2 a = dh_f2_make(v.x, v.y), b = dh_f2_make(v.z, v.w);
+                        s2 = dh_f2_add(s2, a); s2 = dh_f2_add(s2, b);
+                        q2 = dh_f2_fma(a, a, q2); q2 = dh_f2_fma(b, b, q2);
+                    }
+                    DH_LA(gs, lane)[0] = act ? s2.x + s2.y : 0.0f; DH_LA(gq, lane)[0] = act ? q2.x + q2.y : 0.0f;
+                }
+                DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
+                uint64_t vote_above = 0, vote_fine = 0;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                {
+                    float s = gs[0], q = gq[0], t1, t2, u1, u2;
+                    // (row_shr with bound_ctrl: lanes without a source read 0 -- only lanes 4, 9, 14 of a row are looked at, and theirs exist)
+                    asm volatile("s_nop 4\n\t"               // (a VALU write of EXEC just before would need 5 wait states ahead of a DPP op)
+                                 "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "v_add_f32_dpp %2, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "s_nop 0\n\t"                // (a DPP read needs two wait states after the write of its source: the other stream's add + this)
+                                 "v_add_f32_dpp %1, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "v_add_f32_dpp %3, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "v_add_f32_dpp %1, %4, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "v_add_f32_dpp %3, %5, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                 : "=&v"(t1), "=&v"(t2), "=&v"(u1), "=&v"(u2) : "v"(s), "v"(q));
+                    gs[0] = t2; gq[0] = u2;
+                }
+#else
+                {
+                    float ts[DH_WAVE], tq[DH_WAVE];
+                    for (int l = 0; l < DH_WAVE; l++) {
+                        const int c = l & 15;
+                        auto at = [&](float (*arr)[1], int d) { return c - d >= 0 ? arr[l - d][0] : 0.0f; };
+                        ts[l] = ((at(gs, 0) + at(gs, 1)) + (at(gs, 2) + at(gs, 3))) + at(gs, 4);
+                        tq[l] = ((at(gq, 0) + at(gq, 1)) + (at(gq, 2) + at(gq, 3))) + at(gq, 4);
+                    }
+                    for (int l = 0; l < DH_WAVE; l++) { gs[l][0] = ts[l]; gq[l][0] = tq[l]; }
+                }
+#endif
+                DH_FOR_LANES_FRESH(lane) {
+                    const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
+                    const bool own = (((r == 3u ? 0x0010u : 0x4210u) >> c) & 1u) != 0u;      // this lane holds a phase: lane 4, 9 or 14 of its row (row 3: phase 9 only)
+                    const float total = DH_LA(gs, lane)[0], e = DH_LA(gq, lane)[0] * 0.01f;      // e = mean x^2
+                    const float mean = total * 0.01f;
+                    const float v = __builtin_fmaf(-mean, mean, e);
+                    float tol = __builtin_fmaf(e, 4e-6f, 1e-42f);
+                    if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;      // (see the full form below)
+                    const float l = own ? v - tol : DH_FLT_MAX, h = own ? v + tol : DH_FLT_MAX;
+                    DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
+                    DH_LA(gs, lane)[0] = own ? ((e < 1e30f && v != 0.0f && l > 0.0f && h < 4999999.0f) ? 1.0f : 0.0f) : 1.0f;      // fine as a candidate
+                    DH_LA(gq, lane)[0] = own ? ((e < 1e30f && v != 0.0f) ? 1.0f : 0.0f) : 1.0f;                                      // fine when ruled out
+                }
+                float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                hmin = -dh_wave_max(-hi[0]);
+#else
+                hmin = DH_FLT_MAX;
+                for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, hi[q][0]);
+#endif
+                DH_FOR_LANES_FRESH(lane) {
+                    const bool above = DH_LA(lo, lane)[0] > hmin;
+                    DH_BALLOT_ACC(vote_above, above, lane);
+                    DH_BALLOT_ACC(vote_fine, (above ? DH_LA(gq, lane)[0] : DH_LA(gs, lane)[0]) != 0.0f, lane);
+                }
+                const uint64_t cand = ~vote_above;
+                if (DH_LIKELY(vote_fine == ~0ull && cand != 0 && (cand & (cand - 1)) == 0)) {
+                    est_done = true; ordered = false;
+                    const uint32_t b = (uint32_t) dh_ffs64(cand), vmin_pos = 3u * (b >> 4) + ((b & 15u) - 4u) / 5u;
+                    if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
+                    else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
+                }
+            }
+#endif
+            if (!RINGLESS && SPS == 10 && !P.ordered_timing && !est_done) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
                 // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
@@ -2663,9 +3070,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
 
         DH_CLK(5);
+        DH_PROBE(5);
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
         DH_FOR_LANES_FRESH(lane) {
-            for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k];
+            if (!merged) { for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k]; }      // (the merged phase committed its volumes from registers)
 #if DH_PF_L2
             (void) pf_have;
 #else
@@ -2717,6 +3125,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_TAPFRAG_LOAD();                              // for the next run
 #endif
         DH_CLK(6);
+        DH_PROBE(6);
     }
 
 #if DH_PF_L2 && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
