@@ -48,6 +48,9 @@ WORKLOADS = {
                  "rrc(wide) materialised + gfsk(10), float path (BASELINE configs[1])"),
     "rrc_gfsk_fast": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="none", keep_filtered=True, fast_fir=True),
                       "rrc(wide) materialised with the FMA FIR (1e-6 float tolerance of configs[1]) + gfsk(10)"),
+    "rrc_gfsk_one": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="none", keep_filtered=True, one_launch=True),
+                     "rrc(wide) + gfsk(10) in ONE launch (DH_FLAG_ONE_LAUNCH): dibits bit-exact, filtered samples from the split-f16 matrix-core FIR -- "
+                     "2.5e-6 of max(|ref|, rms), NOT configs[1]'s 1e-6: shown for what one kernel reaches, not as the configs[1] number"),
     "dmr_fast": ("dmr", dict(rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=True),
                  "full DMR chain with the FMA FIR (float outputs 1e-6, dibits not guaranteed bit-exact)"),
     # narrow RRC -> gfsk -s 20 -> nxdn_decoder (examples/nxdn48-decoder.sh)
@@ -93,7 +96,7 @@ def profiled_counters(workload, channels, T, part0=False):
     that does not say what it ran on is not used.  Newest round first.
     part0: the push goes out as two launches; take the lines of the first one (kernel template argument PART = 0)."""
     pdir = os.path.join(ROOT, "profiles")
-    kern = "k_rrc_tile" if workload.startswith("rrc_gfsk") else "k_chain"
+    kern = "k_rrc_demod" if workload == "rrc_gfsk_one" else "k_rrc_tile" if workload.startswith("rrc_gfsk") else "k_chain"
     want = lambda line: kern in line and (not part0 or ", 10, 0>" in line)
     names = sorted((f for f in os.listdir(pdir) if f.endswith("_%s_pmc.txt" % workload) or (workload == "dmr_full" and f.endswith("_chain_pmc.txt"))), reverse=True)
     for name in names:
@@ -388,7 +391,12 @@ class Job:
         rrc_ms, slicer_ms, dec_ms = p["eng"].timing_read()
         frame_bytes = int(p["eng"].frames()[1].sum()) if kw["proto"] != "none" else 0      # decoder output of the last step
         alg_bytes = B * T * 4.0 + B * (T / float(kw["sps"]))          # input f32 (4 B/sample) + dibits out (1 B per sps samples)
-        if kw.get("keep_filtered"):
+        if kw.get("keep_filtered") and kw.get("one_launch"):
+            # DH_FLAG_ONE_LAUNCH (engine_impl.hpp, fused_keep): the error-bounded slicer kernel also stores the filtered samples
+            dom_ms = float(np.mean(slicer_ms)) if len(slicer_ms) else float("nan")
+            alg_bytes = B * T * 8.0 + B * (T / float(kw["sps"]))                          # 4 B in + 4 B out per sample + 1 B per symbol (8.1)
+            dom_name = "k_rrc_demod"
+        elif kw.get("keep_filtered"):
             dom_ms = float(np.mean(rrc_ms)) if len(rrc_ms) else float("nan")              # unfused config: the RRC kernel dominates
             alg_bytes = B * T * 8.0                                                       # 4 B in + 4 B out per sample
             dom_name = "k_rrc_tile"
@@ -418,7 +426,7 @@ class Job:
         fir_flops = B * T * 2.0 * taps              # one mul + one add per tap and sample, unfused
         pc = profiled_counters(self.workload, p["B"], T, part0=group is not None)
         mean = lambda a: float(np.mean(a)) if len(a) else None
-        f16 = dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "wide" and kw["sps"] == 10
+        f16 = (dom_name == "k_chain" or kw.get("one_launch")) and not kw.get("fast_fir") and kw["rrc"] == "wide" and kw["sps"] == 10
         bounded = f16 or (dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "narrow")
         ceiling, ceiling_rates = copy_ceiling(self.torch, p["x"].device, p["eng"].ctx)
         if f16:
@@ -456,6 +464,7 @@ class Job:
         if any("iq" in p for p in self.parts):
             return None, None                       # (the front-end's state makes every push's floats different: Job.verify replays those)
         ok, frame_bytes, worst, checked = True, 0, 0.0, 0
+        dibits_ok = True
         for p in self.parts:
             kw, T, eng = p["kw"], p["T"], p["eng"]
             n = min(nv, p["B"])
@@ -478,6 +487,7 @@ class Job:
                 same = gsc[j] == len(want) and gs[j, :gsc[j]].tobytes() == want.tobytes()
                 if kw.get("fast_fir"):
                     same = True                      # dibits are not guaranteed with the FMA FIR; the floats are checked below
+                dibits_ok = dibits_ok and bool(same)
                 ok &= bool(same)
                 if kw["proto"] != "none":
                     wf = full["out"][j, lo("out_count", j):full["out_count"][j]]
@@ -490,19 +500,21 @@ class Job:
             if keep:
                 y = eng.read_rows("filtered", pick)[0][:, :T]
                 r = full["filtered"][:, (pushes - 1) * T:]
-                if kw.get("fast_fir"):               # 1e-6 relative to max(|ref|, rms(ref))
+                if kw.get("fast_fir") or kw.get("one_launch"):               # 1e-6 relative to max(|ref|, rms(ref)); DH_FLAG_ONE_LAUNCH promises 2.5e-6
                     rms = np.sqrt(np.mean(r.astype(np.float64) ** 2)) + 1e-30
                     err = float(np.max(np.abs(y.astype(np.float64) - r) / np.maximum(np.abs(r), rms)))
                     worst = max(worst, err)
-                    ok &= err <= 1e-6
+                    ok &= err <= (2.5e-6 if kw.get("one_launch") else 1e-6)
                 else:
                     ok &= bool((y.view(np.uint32) == r.view(np.uint32)).all())
             checked += n
         out = {"what": "the timed engines' own last push (push %d of %d identical pushes since reset) against the oracle run over the same stream" % (pushes, pushes),
                "channels": checked, "sampling": "evenly spread over the batch", "pushes": pushes,
-               "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir"), "frame_bytes": frame_bytes}
+               "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir") and not self.kw.get("one_launch"), "frame_bytes": frame_bytes}
         if self.kw.get("fast_fir"):
             out.update({"within_1e-6_vs_oracle": bool(ok), "max_rel_err": worst})
+        if self.kw.get("one_launch"):
+            out.update({"dibits_bit_exact_vs_oracle": bool(dibits_ok), "floats_within_2.5e-6_vs_oracle": bool(ok), "max_rel_err": worst, "within_1e-6_vs_oracle": bool(ok and worst <= 1e-6)})
         return bool(ok), out
 
     def verify(self, ctx, nv, reps=2):
@@ -548,16 +560,19 @@ class Job:
                     frame_bytes += len(gf)
             if kw.get("keep_filtered"):
                 y, r = np.concatenate(got_y, axis=1), ref["filtered"]
-                if kw.get("fast_fir"):               # 1e-6 relative to max(|ref|, rms(ref))
+                if kw.get("fast_fir") or kw.get("one_launch"):               # 1e-6 relative to max(|ref|, rms(ref)); DH_FLAG_ONE_LAUNCH promises 2.5e-6
                     rms = np.sqrt(np.mean(r.astype(np.float64) ** 2)) + 1e-30
                     err = float(np.max(np.abs(y.astype(np.float64) - r) / np.maximum(np.abs(r), rms)))
                     worst = max(worst, err)
-                    ok &= err <= 1e-6
+                    ok &= err <= (2.5e-6 if kw.get("one_launch") else 1e-6)
                 else:
                     ok &= bool((y.view(np.uint32) == r.view(np.uint32)).all())
-        out = {"channels": nv, "sampling": "evenly spread over the batch", "pushes": reps, "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir"), "frame_bytes": frame_bytes}
+        out = {"channels": nv, "sampling": "evenly spread over the batch", "pushes": reps,
+               "bit_exact_vs_oracle": bool(ok) and not self.kw.get("fast_fir") and not self.kw.get("one_launch"), "frame_bytes": frame_bytes}
         if self.kw.get("fast_fir"):
             out.update({"within_1e-6_vs_oracle": bool(ok), "max_rel_err": worst})
+        if self.kw.get("one_launch"):
+            out.update({"dibits_bit_exact_vs_oracle": bool(ok), "floats_within_2.5e-6_vs_oracle": bool(ok), "max_rel_err": worst, "within_1e-6_vs_oracle": bool(ok and worst <= 1e-6)})
         return ok, out
 
 
@@ -567,7 +582,7 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
     out = []
     # ("mixed", (4096, 4096)) is one GPU's share of BASELINE configs[4] (65 536 channels over 8 GPUs), ("dmr_full", 8192) its
     # share of the north-star target (65 536 DMR channels over 8 GPUs)
-    for workload, channels, overlap, streams in (("rrc_gfsk", 4096, False, 1), ("rrc_gfsk_fast", 4096, False, 1), ("ysf_full", 16384, False, 1),
+    for workload, channels, overlap, streams in (("rrc_gfsk", 4096, False, 1), ("rrc_gfsk_fast", 4096, False, 1), ("rrc_gfsk_one", 4096, False, 1), ("ysf_full", 16384, False, 1),
                                                  ("mixed", (8192, 8192), False, 1), ("mixed", (8192, 8192), False, 2),
                                                  ("mixed", (4096, 4096), False, 1), ("mixed", (4096, 4096), False, 2), ("dmr_full", 8192, False, 1),
                                                  ("dmr_full", 16384, True, 1), ("ysf_full", 16384, True, 1)):

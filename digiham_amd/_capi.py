@@ -15,7 +15,7 @@ RRC = {"none": 0, None: 0, "wide": 1, "narrow": 2, "custom": 3}
 DEMOD = {"none": 0, None: 0, "fsk": 2, "fsk2": 2, "gfsk": 4, "gfsk4": 4}
 PROTO = {"none": 0, None: 0, "dmr": 1, "ysf": 2, "nxdn": 3, "pocsag": 4, "dstar": 5}
 FLAG_FAST_FIR, FLAG_KEEP_FILTERED, FLAG_FSK_INVERT, FLAG_NO_EVENTS, FLAG_ORDERED_TIMING, FLAG_SPLIT_STAGES = 1, 2, 4, 8, 16, 32
-FLAG_EXACT_SYMBOLS, FLAG_EXACT_FIR, FLAG_OVERLAP_PUSHES = 64, 128, 256
+FLAG_EXACT_SYMBOLS, FLAG_EXACT_FIR, FLAG_OVERLAP_PUSHES, FLAG_ONE_LAUNCH = 64, 128, 256, 512
 
 
 class EngineConfig(C.Structure):

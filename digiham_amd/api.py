@@ -191,7 +191,7 @@ class Engine:
 
     def __init__(self, n_channels, max_samples, rrc="wide", demod="gfsk", sps=10, proto="dmr", fast_fir=False,
                  keep_filtered=False, invert=False, events=True, slot_filter=3, ctx=None, device=0, ordered_timing=False, split_stages=False,
-                 taps=None, gain=None, exact_symbols=False, exact_fir=False, overlap_pushes=False):
+                 taps=None, gain=None, exact_symbols=False, exact_fir=False, overlap_pushes=False, one_launch=False):
         """rrc = "custom" takes the caller's coefficient table: `taps` (nZeros + 1 floats, any shape) and `gain`, as
         Digiham::RrcFilter::RrcFilter(nZeros, gain, coeffs[]) does (include/rrc_filter.hpp:12)."""
         self.ctx = ctx if ctx is not None else Context(device=device)
@@ -200,7 +200,7 @@ class Engine:
                 (_capi.FLAG_FSK_INVERT if invert else 0) | (0 if events else _capi.FLAG_NO_EVENTS) | \
                 (_capi.FLAG_ORDERED_TIMING if ordered_timing else 0) | (_capi.FLAG_SPLIT_STAGES if split_stages else 0) | \
                 (_capi.FLAG_EXACT_SYMBOLS if exact_symbols else 0) | (_capi.FLAG_EXACT_FIR if exact_fir else 0) | \
-                (_capi.FLAG_OVERLAP_PUSHES if overlap_pushes else 0)
+                (_capi.FLAG_OVERLAP_PUSHES if overlap_pushes else 0) | (_capi.FLAG_ONE_LAUNCH if one_launch else 0)
         cfg = _capi.EngineConfig(C.sizeof(_capi.EngineConfig), getattr(mem, "index", 0), n_channels, max_samples,
                                  _capi.RRC[rrc], _capi.DEMOD[demod], sps, _capi.PROTO[proto], flags, slot_filter,
                                  mem.stream())

@@ -789,6 +789,132 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
     DH_BARRIER();
 }
 
+// Clean-codeword shortcut of the reference's decoder (src/ysf_decoder/trellis.c:32-109).  The code is G1 = 1 + D^3 + D^4 (bit 1 of a
+// dibit), G2 = 1 + D + D^2 + D^4 (bit 0).  With h, l the two received bit streams:
+//   * syndrome  s_t = h_t + h_(t-1) + h_(t-2) + h_(t-4) + l_t + l_(t-3) + l_(t-4)   (h G2 = l G1), t = 4 .. N - 1: all zero <=> the N
+//     dibits are EXACTLY the encoder's output for some start state and some message (2 N bits, N + 4 free, N - 4 independent checks);
+//   * the encoder map (start state, message) -> dibits is injective for N >= 4 (rank N + 4, tools/trellis_rank.py), so that path is the
+//     ONLY one of metric 0.  The reference starts every state at metric 0 and keeps, per state, the smaller of two candidates (k = 0 on
+//     ties): on the true path the true predecessor arrives with 0 and the other one with at least 2 (the two transitions into a state
+//     differ in both bits), so it survives strictly at every step; no other end state can have metric 0 (it would be a second path of
+//     metric 0), and no metric wraps (every state is within four steps = 8 errors of the true path).  The reference therefore returns
+//     metric 0 and the message bits of that path, whatever its tie rules would do elsewhere;
+//   * the message comes straight out of the dibits: D^2 = (1 + D + D^2) G1 + (1 + D^2) G2, so u_t = h_(t+2) + h_(t+1) + h_t + l_(t+2) + l_t
+//     for t <= N - 3, and the last two bits from G1: u_t = h_t + u_(t-3) + u_(t-4).
+// Bit vectors of up to 192 bits in three 64-bit scalars per stream (lane l takes dibits l, l + 64, l + 128: one vote per word and bit):
+// ~150 scalar instructions per codeword instead of ~10 vector instructions per trellis step and lane group plus the trace-back.  Returns
+// false (nothing written) unless EVERY codeword of the pass is clean; tests/test_fec.py checks it against the reference compiled in
+// place for every start state, and that one flipped bit anywhere falls through to the full decoder.
+// MEASURED AND OFF (round 4, profiles/r04_b_ab_logs.txt): the batch kernel (dh_trellis) gains 28 % on clean words and loses nothing on
+// dirty ones, but the YSF pipe does not: the reference's own demodulator leaves about one wrong dibit per two hundred even on a noiseless
+// channel of the bench (57 % of the FICH codewords and half of the DCH ones arrive clean), a pass holds four codewords, and 8 % of the
+// passes qualify -- the checks cost the decoder more than the shortcut saves (YSF decoder 3.03 -> 3.17 ms, chain 7.10 -> 7.2).
+#ifndef DH_VIT_CLEAN
+#define DH_VIT_CLEAN 0
+#endif
+#ifndef DH_VIT_CLEAN_CALL
+#define DH_VIT_CLEAN_CALL 0
+#endif
+struct DhBits192 { uint64_t w0, w1, w2; };        // (three named words: nothing here may be indexed at run time -- a private array would live in scratch memory)
+DH_HD DhBits192 dh_b192_shl(const DhBits192& x, int k) {          // bit t of the result = bit t - k (0 < k < 64)
+    DhBits192 r;
+    r.w0 = x.w0 << k; r.w1 = (x.w1 << k) | (x.w0 >> (64 - k)); r.w2 = (x.w2 << k) | (x.w1 >> (64 - k));
+    return r;
+}
+DH_HD DhBits192 dh_b192_shr(const DhBits192& x, int k) {          // bit t of the result = bit t + k
+    DhBits192 r;
+    r.w0 = (x.w0 >> k) | (x.w1 << (64 - k)); r.w1 = (x.w1 >> k) | (x.w2 << (64 - k)); r.w2 = x.w2 >> k;
+    return r;
+}
+DH_HD DhBits192 dh_b192_xor(const DhBits192& a, const DhBits192& b) { DhBits192 r; r.w0 = a.w0 ^ b.w0; r.w1 = a.w1 ^ b.w1; r.w2 = a.w2 ^ b.w2; return r; }
+DH_HD DhBits192 dh_b192_and(const DhBits192& a, const DhBits192& b) { DhBits192 r; r.w0 = a.w0 & b.w0; r.w1 = a.w1 & b.w1; r.w2 = a.w2 & b.w2; return r; }
+DH_HD uint64_t dh_mask_below64(int n) { return n >= 64 ? ~0ull : n <= 0 ? 0ull : (~0ull >> (64 - n)); }
+DH_HD DhBits192 dh_b192_below(int n) { DhBits192 r; r.w0 = dh_mask_below64(n); r.w1 = dh_mask_below64(n - 64); r.w2 = dh_mask_below64(n - 128); return r; }      // bits 0 .. n - 1
+// the two bit streams of codeword g as votes: lane l takes dibits l, l + 64, l + 128 (one dibit per byte in S.vit_in[g])
+DH_HD void dh_clean_streams(const DhDecShared& S, int g, int N, DhBits192& H, DhBits192& L) {
+    const uint8_t* dib = reinterpret_cast<const uint8_t*>(S.vit_in[g]);
+    uint64_t h0 = 0, l0 = 0, h1 = 0, l1 = 0, h2 = 0, l2 = 0;
+    DH_FOR_LANES(lane) {
+        const uint32_t d = lane < N ? dib[lane] : 0u;
+        DH_BALLOT_ACC(h0, (d & 2u) != 0u, lane); DH_BALLOT_ACC(l0, (d & 1u) != 0u, lane);
+    }
+    if (N > 64) {
+        DH_FOR_LANES(lane) {
+            const uint32_t d = 64 + lane < N ? dib[64 + lane] : 0u;
+            DH_BALLOT_ACC(h1, (d & 2u) != 0u, lane); DH_BALLOT_ACC(l1, (d & 1u) != 0u, lane);
+        }
+    }
+    if (N > 128) {
+        DH_FOR_LANES(lane) {
+            const uint32_t d = 128 + lane < N ? dib[128 + lane] : 0u;
+            DH_BALLOT_ACC(h2, (d & 2u) != 0u, lane); DH_BALLOT_ACC(l2, (d & 1u) != 0u, lane);
+        }
+    }
+    H.w0 = h0; H.w1 = h1; H.w2 = h2; L.w0 = l0; L.w1 = l1; L.w2 = l2;
+}
+// one codeword: false when it is not exactly a codeword (or too short for the argument above); otherwise its message bits
+DH_HD bool dh_clean_one(const DhDecShared& S, int g, int N, DhBits192& U) {
+    U.w0 = U.w1 = U.w2 = 0;
+    if (N == 0) return true;
+    if (N < 8 || N > 192) return false;
+    DhBits192 H, L;
+    dh_clean_streams(S, g, N, H, L);
+    // syndrome, checks t = 4 .. N - 1
+    DhBits192 syn = dh_b192_xor(dh_b192_xor(dh_b192_xor(H, dh_b192_shl(H, 1)), dh_b192_xor(dh_b192_shl(H, 2), dh_b192_shl(H, 4))),
+                                dh_b192_xor(dh_b192_xor(L, dh_b192_shl(L, 3)), dh_b192_shl(L, 4)));
+    DhBits192 chk = dh_b192_below(N); chk.w0 &= ~0xFull;
+    syn = dh_b192_and(syn, chk);
+    if ((syn.w0 | syn.w1 | syn.w2) != 0) return false;
+    // message bits 0 .. N - 3 by the inverse, N - 2 and N - 1 from G1 on bits that are then known
+    U = dh_b192_and(dh_b192_xor(dh_b192_xor(dh_b192_xor(dh_b192_shr(H, 2), dh_b192_shr(H, 1)), H), dh_b192_xor(dh_b192_shr(L, 2), L)), dh_b192_below(N - 2));
+    const DhBits192 tailbits = dh_b192_xor(H, dh_b192_xor(dh_b192_shl(U, 3), dh_b192_shl(U, 4)));
+    DhBits192 last = dh_b192_xor(dh_b192_below(N), dh_b192_below(N - 2));        // bits N - 2, N - 1
+    const DhBits192 t2 = dh_b192_and(tailbits, last);
+    U.w0 |= t2.w0; U.w1 |= t2.w1; U.w2 |= t2.w2;
+    return true;
+}
+// message bytes MSB first (trellis.c:55-56, 84), zeros behind them, metric 0 -- written as soon as a codeword has passed: if a later
+// one of the pass does not, the full decoder overwrites all of them (keeping four messages in scalar registers until the end cost the
+// YSF decoder kernel its register budget)
+DH_HD void dh_clean_store(DhDecShared& S, int g, const DhBits192& U) {
+    DH_FOR_LANES(lane) {
+        if (lane < 24) {
+            const int q = lane >> 3;
+            const uint64_t w = q == 0 ? U.w0 : q == 1 ? U.w1 : U.w2;
+            S.vit_out[g][lane] = (uint8_t) (dh_brev32((uint32_t) ((w >> (8 * (lane & 7))) & 0xFFull)) >> 24);
+        }
+        if (lane == 24) S.vit_best_metric[g] = 0;
+    }
+}
+// (a REAL function on the device -- noinline: inlined into the YSF decoder, which already sits on its 128-register budget, the four checks
+// cost it 76 more bytes of spills and the decoder ran slower than without the shortcut; a call per Viterbi pass -- every other frame --
+// costs nothing, and the callee has its own register allocation.  Its arguments are values and one LDS pointer.)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_VIT_CLEAN_CALL
+__device__ __attribute__((noinline)) bool dh_viterbi_clean_sizes(DhDecShared* Sp, int n0, int n1, int n2, int n3) {
+    DhDecShared& S = *Sp;
+#else
+DH_HD bool dh_viterbi_clean_sizes(DhDecShared* Sp, int n0, int n1, int n2, int n3) {
+    DhDecShared& S = *Sp;
+#endif
+#if DH_VIT_CLEAN
+    DhBits192 U;
+    if (!dh_clean_one(S, 0, n0, U)) return false;
+    if (n0 > 0) dh_clean_store(S, 0, U);
+    if (!dh_clean_one(S, 1, n1, U)) return false;
+    if (n1 > 0) dh_clean_store(S, 1, U);
+    if (!dh_clean_one(S, 2, n2, U)) return false;
+    if (n2 > 0) dh_clean_store(S, 2, U);
+    if (!dh_clean_one(S, 3, n3, U)) return false;
+    if (n3 > 0) dh_clean_store(S, 3, U);
+    DH_BARRIER();
+    return true;
+#else
+    (void) S; (void) n0; (void) n1; (void) n2; (void) n3;
+    return false;
+#endif
+}
+DH_HD bool dh_viterbi_clean(DhDecShared& S, const int* sizes /*[4]*/) { return dh_viterbi_clean_sizes(&S, sizes[0], sizes[1], sizes[2], sizes[3]); }      // (static indices only)      // (static indices only)
+
 #ifndef DH_VIT_DPP
 #define DH_VIT_DPP 0                 // 1: the in-place forward pass below (measured: no gain alone, a loss inside the chain kernels -- DESIGN.md section 5)
 #endif
@@ -852,6 +978,7 @@ __device__ __forceinline__ void dh_vit_step(uint32_t& m, uint32_t pc_own, uint32
 }
 template <bool NXDN = false, bool RAGGED = NXDN>
 __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
+    if (!NXDN && dh_viterbi_clean(S, sizes)) return;
     const int lane = (int) threadIdx.x, g = lane >> 4;
     const uint32_t L = (uint32_t) lane & 15u;
     int steps = 0;
@@ -989,6 +1116,7 @@ __device__ __forceinline__ void dh_vitb_step(uint32_t& m, uint32_t h0, uint32_t 
 // ignored.
 template <bool NXDN = false, bool RAGGED = NXDN>
 __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
+    if (!NXDN && dh_viterbi_clean(S, sizes)) return;
     const int lane = (int) threadIdx.x, g = lane >> 4, i = lane & 15;
     int steps = 0;
 #pragma unroll
@@ -1032,6 +1160,7 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
 // plain statement of the same recursion for the CPU harness: metrics exchanged through the LDS arrays
 template <bool NXDN = false, bool RAGGED = NXDN>
 inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
+    if (!NXDN && dh_viterbi_clean(S, sizes)) return;
     int steps = 0;
     for (int g = 0; g < 4; g++) steps = sizes[g] > steps ? sizes[g] : steps;
     DH_FOR_LANES(lane) { S.vit_metric[0][lane] = 0; }

@@ -85,6 +85,9 @@ struct DhDspParams {
     // stopped; every other workgroup leaves at once.  split_force_fail = k > 0 (tests: DH_TAIL_SPLIT_FORCE_FAIL): the later parts
     // of the channels with ch % k == 1 give up without looking.
     uint32_t split_fixup, split_force_fail;
+    // DH_FLAG_KEEP_FILTERED | DH_FLAG_FAST_FIR on the wide filter at sps 10 (BASELINE configs[1] within its 1e-6): the error-bounded slicer
+    // also delivers the filtered samples of the push it has in LDS anyway -- filt_out[ch][t] for every new sample t -- in ONE launch
+    float* filt_out; size_t filt_stride;
 };
 
 // (behind the tail: the per-phase partial sums of the ring-less kernels, see DH_RINGLESS)
@@ -1495,7 +1498,7 @@ __device__ __forceinline__ void dh_probe_body() {
 // LV = 4 / 2: the number of levels is known where the kernel is instantiated (the chain kernels: 4 for DMR / YSF / NXDN, 2 for
 // D-Star; engine.hip checks P.levels against it) and the other slicer's selects, its invert mask and two scalar register
 // pairs drop out of the slicing phase; 0 = taken from P.levels.
-template <int NZ, bool FAST, int SPS, int LV = 0>
+template <int NZ, bool FAST, int SPS, int LV = 0, bool KEEPF = false>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu, uint32_t sym_base = 0) {
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
@@ -1503,7 +1506,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     constexpr bool RINGLESS = DhIsRingless<NZ, FAST, SPS>::value;                                     // no variance ring in LDS: per-phase sums instead (see DH_RINGLESS)
     // P3 - P5 merged (below): the filtered samples of a run then start FOFF words into the window block, so that the copy of symbol 0
     // one word in front of its place (a pending step of -1) stays inside the block
-    constexpr bool CAN_MERGE = DH_P345_MERGED && MF16 && SPS == 10 && !RINGLESS && NZ == 80 && DH_STOP_AFTER >= 99;
+    constexpr bool CAN_MERGE = DH_P345_MERGED && MF16 && SPS == 10 && !RINGLESS && NZ == 80 && DH_STOP_AFTER >= 99 && !KEEPF;
     constexpr uint32_t FOFF = CAN_MERGE ? 4u : 0u;
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
@@ -1710,6 +1713,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         const uint32_t last_start = p + (m - 1) * sps + (m > 1 ? (uint32_t) step_off : 0u);
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
+        const uint32_t need_fir = KEEPF ? (uint32_t) DH_FTILE : need;      // (a kernel that also delivers the filtered samples wants the whole pass)
         const bool merged = CAN_MERGE && DH_LIKELY(k0 == 0);     // a run that starts a variance block: ring slot == symbol index
         // (bits 2.. of blk_flags, ring-less kernels: 4 = some run of the current block had a non-zero window, bits 8..15 = runs the block has been cut into)
         if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags = (BS->blk_flags & 3u) | 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
@@ -1922,7 +1926,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
                         DH_FOR_LANES_FRESH(lane) {
                             bool bad = false;
-                            if ((uint32_t) (lane * DH_FIR_L) < need)
+                            if ((uint32_t) (lane * DH_FIR_L) < need_fir)
                                 dh_fir_lane<NZ, true>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane), &bad);
                             DH_BALLOT_ACC(vote_bad, bad, lane);
                         }
@@ -1939,9 +1943,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         DH_BARRIER();
                     }
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                    dh_exact_fir_pass<NZ>(P, S, need, nullptr, fo);
+                    dh_exact_fir_pass<NZ>(P, S, need_fir, nullptr, fo);
 #else
-                    dh_exact_fir_pass<NZ>(P, S, need, fo, nullptr);
+                    dh_exact_fir_pass<NZ>(P, S, need_fir, fo, nullptr);
 #endif
                 }
             } else if constexpr (MFMA) {
@@ -1956,7 +1960,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #pragma unroll
                 for (int i = 0; i <= NZ / 2; i++) tv[i] = S.tapsf[i];
                 DH_FOR_LANES_FRESH(lane) {
-                    if ((uint32_t) (lane * DH_FIR_L) < need)
+                    if ((uint32_t) (lane * DH_FIR_L) < need_fir)
                         dh_fir_lane<NZ, FAST>(tv, P.gain, P.rgain, P.inv_gain, S.xf, lane, DH_LA(fo, lane));
                 }
             }
@@ -1988,7 +1992,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
             } else {
                 DH_FOR_LANES_FRESH(lane) {
-                    if ((uint32_t) (lane * DH_FIR_L) < need) {
+                    if ((uint32_t) (lane * DH_FIR_L) < need_fir) {
                         dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + FOFF + DH_FIR_L * lane);
 #pragma unroll
                         for (int j = 0; j < DH_FIR_L / 4; j++) {
@@ -2037,6 +2041,18 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
         const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
         const bool pf_reg = PF_REG && pf_plain && P.exact_mode != 2;
+        if constexpr (KEEPF) {
+            // This run's filtered samples [p, p_next) leave as they stand in LDS (each store instruction a run of 64 consecutive
+            // words); what the previous push already delivered -- positions in front of tc - NZ, the first new sample's -- is
+            // skipped, and nothing is delivered beyond the last complete output.
+            const uint32_t f_lo = tc > (uint32_t) NZ ? tc - (uint32_t) NZ : 0u;
+            const uint32_t s0 = p < f_lo ? f_lo - p : 0u;
+            const uint32_t s1 = dh_min<uint32_t>(p_next - p, nf > p ? nf - p : 0u);
+            float* orow = P.filt_out + (size_t) ch * P.filt_stride + ((ptrdiff_t) p + (ptrdiff_t) NZ - (ptrdiff_t) tc);
+            DH_FOR_LANES_FRESH(lane) {
+                for (uint32_t e = s0 + (uint32_t) lane; e < s1; e += DH_WAVE) orow[e] = fbuf[e];
+            }
+        }
         auto issue_next_window = [&]() __attribute__((always_inline)) {
         if (DH_LIKELY(pf_reg)) {
             // The split-f16 FIR leaves registers free where the packed-FMA FIR had none: the next window's five 16-byte loads
@@ -3131,6 +3147,16 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #if DH_PF_L2 && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // a last L2-touch load may still be writing into the window block
 #endif
+    if constexpr (KEEPF) {
+        // the outputs behind the last run (less than a symbol's worth, unless the symbol buffer is full): the reference's arithmetic,
+        // sample by sample, while the tail it reads is still the old one
+        const uint32_t f_lo = tc > (uint32_t) NZ ? tc - (uint32_t) NZ : 0u;
+        float* orow = P.filt_out + (size_t) ch * P.filt_stride;
+        DH_FOR_LANES(lane) {
+            for (uint32_t f = dh_max<uint32_t>(p, f_lo) + (uint32_t) lane; f < nf; f += DH_WAVE)
+                orow[f + (uint32_t) NZ - tc] = dh_exact_filtered<NZ>(tail, tc, in, nv, S.tapsf, P.gain, P.rgain, (int32_t) f);
+        }
+    }
     // ---- write back state: rings, header, and the raw tail V[base .. nv): the unread samples (from p) and, in the
     // error-bounded kernels, up to dh_history(sps) samples behind them
     const uint32_t tail_max = dh_tail_max(sps);

@@ -61,11 +61,12 @@ int hip_fail(hipError_t e, const char* what) {
 #endif
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
-template <int NZ, bool FAST, int SPS>
+// KEEPF: the launch also delivers the filtered samples (DhDspParams::filt_out; BASELINE configs[1] in one kernel)
+template <int NZ, bool FAST, int SPS, bool KEEPF = false>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
-    dh_rrc_demod_channel<NZ, FAST, SPS>(P, blockIdx.x, S);
+    dh_rrc_demod_channel<NZ, FAST, SPS, 0, KEEPF>(P, blockIdx.x, S);
 }
 
 // The whole chain of one channel in one wavefront: slice this push's samples, then run the protocol decoder over
@@ -712,16 +713,17 @@ struct HipBackend {
         return DH_OK;
     }
 
-    template <int NZ, bool FAST, int SPS> int go_rrc_demod(const DhDspParams& P) {
+    template <int NZ, bool FAST, int SPS, bool KEEPF = false> int go_rrc_demod(const DhDspParams& P) {
         const size_t lds = dh_dsp_shared_bytes(P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
         if (lds > 48 * 1024) {
-            if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
+            if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS, KEEPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
                          "hipFuncSetAttribute")) return -1;
         }
-        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST, SPS>), dim3(P.n_channels), dim3(DH_WAVE), lds, ms(), P);
+        hipLaunchKernelGGL((k_rrc_demod<NZ, FAST, SPS, KEEPF>), dim3(P.n_channels), dim3(DH_WAVE), lds, ms(), P);
         return launched("k_rrc_demod");
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
+        if (P.filt_out) return (P.sps == 10 && nz == 80 && !fast) ? go_rrc_demod<80, false, 10, true>(P) : -1;      // (engine_impl.hpp: only this pipe asks for it)
         if (P.sps == 10) {                      // DMR / YSF: specialised symbol loops
             if (nz == 0) return go_rrc_demod<0, false, 10>(P);
             if (nz == 80) return fast ? go_rrc_demod<80, true, 10>(P) : go_rrc_demod<80, false, 10>(P);

@@ -33,6 +33,7 @@ struct Layout {
     uint32_t sym_cap, out_cap, ev_cap;
     size_t sym_stride, state_words;
     bool fused;          // RRC folded into the slicer kernel (no filtered signal in HBM)
+    bool fused_keep;     // ... which also delivers the filtered samples (DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH, wide filter, sps 10): one launch
 };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -55,7 +56,12 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     // GfskDemodulator ctor: lowestEval = round(sps/3), highestEval = round(2*sps/3)  (gfsk_demodulator.cpp:8-9)
     L.lo = (uint32_t) (int) __builtin_roundf((float) L.sps / 3);
     L.hi = (uint32_t) (int) __builtin_roundf((float) L.sps * 2 / 3);
-    L.fused = L.rrc != DH_RRC_NONE && L.rrc != DH_RRC_CUSTOM && L.demod != DH_DEMOD_NONE && !(L.flags & DH_FLAG_KEEP_FILTERED);
+    // DH_FLAG_ONE_LAUNCH: the error-bounded slicer kernel filters on the matrix cores, decides every dibit as the reference does and
+    // stores the filtered samples it holds in LDS -- one kernel instead of RRC tiles + slicer (8.1 instead of 12.1 bytes per sample
+    // through HBM).  Its floats are the split-f16 FIR's: 1.1e-6 of max(|ref|, rms) measured, outside the 1e-6 of BASELINE configs[1].
+    L.fused_keep = (L.flags & DH_FLAG_KEEP_FILTERED) && (L.flags & DH_FLAG_ONE_LAUNCH) && L.rrc == DH_RRC_WIDE && L.demod != DH_DEMOD_NONE && L.sps == 10
+                   && !(L.flags & DH_FLAG_EXACT_FIR);
+    L.fused = L.rrc != DH_RRC_NONE && L.rrc != DH_RRC_CUSTOM && L.demod != DH_DEMOD_NONE && (!(L.flags & DH_FLAG_KEEP_FILTERED) || L.fused_keep);
     // a symbol consumes at least sps-1 samples
     L.sym_cap = L.demod ? (L.max_samples + dh_tail_max(L.sps)) / (L.sps - 1) + 4 : L.max_samples;
     L.sym_stride = round_up(L.sym_cap, 64);
@@ -152,10 +158,8 @@ struct Engine {
             delete host;
             if (rc) return rc;
         }
-        if (L.rrc && !L.fused) {
-            DH_ALLOC(filtered, float, B * (size_t) L.max_samples);
-            DH_ALLOC(rrc_hist, float, B * (size_t) L.nz);
-        }
+        if (L.rrc && (!L.fused || L.fused_keep)) DH_ALLOC(filtered, float, B * (size_t) L.max_samples);
+        if (L.rrc && !L.fused) DH_ALLOC(rrc_hist, float, B * (size_t) L.nz);
         if (L.rrc == DH_RRC_CUSTOM) {
             DH_ALLOC(custom_taps, float, L.nz + 1);
             custom_gain = c.rrc_gain;
@@ -254,7 +258,7 @@ struct Engine {
         last_n = (uint32_t) n;
         int rc = 0;
         const float* demod_in = d_in; size_t demod_stride = stride;
-        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;
+        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0 && !L.fused_keep;      // (fused_keep: the error-bounded kernel, whose floats are within the fast path's tolerance)
         bool decoder_done = false;
         be.timing_mark(0);
         if (L.rrc == DH_RRC_CUSTOM) {
@@ -288,10 +292,11 @@ struct Engine {
                 dsp.err_coef = dh_fir_error_coefficient(dsp.taps, L.nz, dsp.gain);
                 dsp.tapfrag = tapfrag; dsp.err_coef_f16 = err_coef_f16;
             }
+            dsp.filt_out = L.fused_keep ? filtered : nullptr; dsp.filt_stride = L.max_samples;
             // slicer and decoder of a channel in one wavefront where the backend has that kernel (sps 10, wide or
             // no RRC); DH_FLAG_SPLIT_STAGES keeps the two launches (per-stage timing, A/B measurements)
             int chained = 1;
-            if (L.proto && !(L.flags & DH_FLAG_SPLIT_STAGES)) {
+            if (L.proto && !(L.flags & DH_FLAG_SPLIT_STAGES) && !L.fused_keep) {
                 fill_dec_params(syms, L.sym_stride, sym_count);
                 chained = be.launch_chain(dsp, dec, dsp.nz, fast, L.proto);
                 if (chained < 0) rc |= chained;

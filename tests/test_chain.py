@@ -52,6 +52,26 @@ def test_unfused_rrc_output_is_bit_exact(ctx, oracle):
         assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, x.shape[0])
 
 
+@pytest.mark.parametrize("chunks", [[10 ** 9], [3000, 50, 2049], [997], [5, 12345, 1, 1, 4000]])
+def test_rrc_and_gfsk_in_one_launch(ctx, oracle, chunks):
+    """DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH (wide filter, sps 10): ONE kernel per push -- the error-bounded slicer also delivers
+    the filtered samples.  Every filtered sample of every push within 2.5e-6 of the reference's (rrc_filter.cpp:22-34) relative to
+    max(|ref|, rms) -- the split-f16 FIR's accuracy, NOT the 1e-6 of BASELINE configs[1] --, the dibits the reference's bit for bit
+    (gfsk_demodulator.cpp:24-107), whatever the push sizes; with a decoder behind it (two launches) frames and events as well."""
+    x = make_channels("dmr", [7, 8, 9], 12)
+    ref = oracle.chain(x, proto=0, keep_filtered=True)
+    chunks = [min(c, x.shape[1]) for c in chunks]
+    res = run_engine(ctx, x, "none", chunks, keep_filtered=True, one_launch=True)
+    assert res["filtered"].shape == ref["filtered"].shape
+    assert rel_err(res["filtered"], ref["filtered"]).max() <= 2.5e-6
+    assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, x.shape[0], "one launch %s" % chunks[:2])
+    if chunks[0] > 10 ** 6:
+        full = oracle.chain(x, proto=1)
+        res = run_engine(ctx, x, "dmr", [x.shape[1]], keep_filtered=True, one_launch=True)
+        assert_matches_oracle(res, full, x.shape[0], "one launch + dmr")
+        assert rel_err(res["filtered"], ref["filtered"]).max() <= 2.5e-6
+
+
 def test_fast_fir_within_1e6(ctx, oracle):
     """FAST_FIR (FMA) is the float-path variant: 1e-6 relative to max(|ref|, rms(ref))."""
     x = make_channels("dmr", [7, 8], 12)

@@ -76,6 +76,49 @@ def test_trellis_encode_noise_decode(ctx, oracle):
     assert (metric == np.array([r % 3 for r in range(len(noisy))])).all()
 
 
+def _encode_from_state(msg_bits, start):
+    """Dibits of the K = 5 code (G1 = 1 + D^3 + D^4 -> bit 1, G2 = 1 + D + D^2 + D^4 -> bit 0; src/ysf_decoder/trellis.c:8-25) for a
+    message and a 4-bit start state (u(-1) in bit 3 .. u(-4) in bit 0), packed four per byte MSB first like the reference's input."""
+    hist = [(start >> 3) & 1, (start >> 2) & 1, (start >> 1) & 1, start & 1]        # u(t-1), u(t-2), u(t-3), u(t-4)
+    dib = []
+    for u in msg_bits:
+        hi = u ^ hist[2] ^ hist[3]
+        lo = u ^ hist[0] ^ hist[1] ^ hist[3]
+        dib.append((hi << 1) | lo)
+        hist = [int(u)] + hist[:3]
+    out = np.zeros((len(dib) + 3) // 4, np.uint8)
+    for t, d in enumerate(dib):
+        out[t // 4] |= d << (2 * (3 - t % 4))
+    return out
+
+
+def test_trellis_clean_codewords_from_every_start_state_vs_reference(ctx, oracle):
+    """The clean-codeword shortcut (decoder_core.hpp, dh_viterbi_clean): noiseless words from all 16 start states, every length class,
+    and the same words with one bit flipped (every position of one word per length; those must take the full decoder) -- outputs and
+    metrics equal the reference's decoder compiled in place (oracle `ref`), or the restatement where `_ref` is not built."""
+    which = "ref" if oracle.ref() is not None else "oracle"
+    rng = np.random.default_rng(77)
+    for nd in (8, 9, 12, 13, 37, 64, 65, 100, 128, 129, 180, 192):
+        words = []
+        for start in range(16):
+            for _ in range(3):
+                words.append(_encode_from_state(rng.integers(0, 2, nd), start))
+        base = words[5].copy()
+        for bit in range(2 * nd):                                # one flipped bit at every position
+            w = base.copy(); w[bit // 8] ^= 0x80 >> (bit % 8); words.append(w)
+        for _ in range(16):                                       # two flipped bits
+            w = words[int(rng.integers(0, 48))].copy()
+            for bit in rng.integers(0, 2 * nd, 2):
+                w[bit // 8] ^= 0x80 >> (bit % 8)
+            words.append(w)
+        x = np.stack(words)
+        o1, m1 = ctx.trellis(x, nd)
+        o2, m2 = oracle.trellis(x, nd, which)
+        assert (m1 == m2).all(), nd
+        assert (o1 == o2).all(), nd
+        assert (m1[:48] == 0).all() and (m1[48:48 + 2 * nd] > 0).all(), nd
+
+
 def test_crc_whitening_golden(ctx, golden):
     g = golden["fec"]
     for cnt in (4, 10, 20):
