@@ -17,7 +17,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-include-regex "k_chain|k_rrc_demod|k_dmr|k_ysf|k_rrc_tile" --pmc $set -d $OUT -o pmc$i -- python bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-include-regex "k_chain|k_rrc_demod|k_dmr|k_ysf|k_rrc_tile|k_nxdn" --pmc $set -d $OUT -o pmc$i -- python bench.py $ARGS > $OUT/pmc$i.log 2>&1
   # what the pass ran on, from its own bench line: bench.py scales the counters by it (profiled_counters)
   CFG=$(grep '^{' $OUT/pmc$i.log | tail -1 | python -c 'import json,sys; c=json.loads(sys.stdin.read())["config"]; print("channels_per_gpu=%d samples_per_channel=%d" % (c["channels_per_gpu"], c["samples_per_channel_per_step"]))' 2>/dev/null)
   { echo "## config: $CFG args=\"$ARGS\""; python tools/rocpd_summary.py $OUT/pmc${i}_results.db 2>&1 | grep -A200 "PMC counters" | grep -E "k_chain|k_rrc_demod|k_dmr|k_ysf|k_rrc_tile|PMC"; } > $OUT/pmc${i}_summary.txt

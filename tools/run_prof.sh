@@ -4,7 +4,7 @@
 #   and separate PMC passes (tools/profile_gpu.sh); rrc_gfsk runs at 4 096 channels, the size BASELINE configs[1] names.
 #   SKIP_BENCH=1 leaves the default bench line out.  Afterwards: tools/collect_prof.sh <tag> copies the summaries into profiles/.
 TAG=${1:?tag}; shift
-WL=${*:-dmr_full ysf_full nxdn_full rrc_gfsk}
+WL=${*:-dmr_full ysf_full nxdn_full rrc_gfsk rrc_gfsk_one}
 set -x
 mkdir -p gpurun_out
 if [ -z "${SKIP_BENCH:-}" ]; then
@@ -12,7 +12,7 @@ if [ -z "${SKIP_BENCH:-}" ]; then
   head -c 2500 gpurun_out/${TAG}_bench_default.json; echo
 fi
 for w in $WL; do
-  extra=""; [ "$w" = "rrc_gfsk" ] && extra="--channels 4096"
+  extra=""; case "$w" in rrc_gfsk*) extra="--channels 4096";; esac
   tools/profile_gpu.sh ${TAG}_$w --workload $w $extra > gpurun_out/${TAG}_prof_$w.log 2>&1
   grep -E "k_chain|k_rrc" gpurun_out/prof_${TAG}_$w/trace_summary.txt | cut -c1-160
 done
