@@ -706,9 +706,9 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #endif
 #ifndef DH_PF_REG
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
+#endif
 #ifndef DH_F16_EDGE_WINDOWS
 #define DH_F16_EDGE_WINDOWS 1                // split-f16 kernels: the first / last windows of a push take the split-f16 FIR too (0: the reference-order FIR, as before)
-#endif
 #endif
 // K = taps + 15 rounded up to whole MFMAs of 32: three for the wide filter (96), six for the narrow one (192; taps beyond the
 // response are zeros in the fragments, and the halves beyond the window are stored as zeros)
