@@ -695,6 +695,9 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #ifndef DH_P5_SHORT_STORES
 #define DH_P5_SHORT_STORES 1                 // paired slicing phase: a lane's two dibits leave as one 16-bit store
 #endif
+#ifndef DH_PLAN_FAST
+#define DH_PLAN_FAST 1                       // sps-10 kernels: the run planning of a whole-block run in three compares
+#endif
 #ifndef DH_P6_LEAN
 #define DH_P6_LEAN 1                         // sps-10 timing estimate: partial sums meet through DPP instead of LDS, two votes (see P6)
 #endif
@@ -1657,6 +1660,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     uint32_t nsym = sym_base;                           // symbols of this push so far (a later part of a split push starts behind the earlier ones')
     bool overflow = false;
     const uint32_t max_run = (DH_FTILE - 2) / sps;      // symbols whose windows fit one FIR pass
+    // (run planning, sps 10: a whole block fits from every position up to fast_p_end while the symbol count is at most fast_sym_end; -1 = never)
+    const int32_t fast_p_end = (nf >= 1003u && nf < 0x40000000u) ? (int32_t) (nf - 1003u) : -1;
+    const int32_t fast_sym_end = (P.sym_cap >= (uint32_t) DH_VARIANCE_SYMBOLS && P.sym_cap < 0x40000000u) ? (int32_t) (P.sym_cap - DH_VARIANCE_SYMBOLS) : -1;
 
     DH_CLK(7);
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -1688,7 +1694,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // s_0 = p, s_q = p + q*sps + step_off for q >= 1.
         const int32_t step_off = (k0 == 0) ? off : 0;   // applied after the first symbol of a block
         uint32_t m = 0;
-        {
+        if (DH_PLAN_FAST && SPS == 10 && DH_LIKELY(k0 == 0 && (int32_t) p <= fast_p_end && (int32_t) nsym <= fast_sym_end)) {
+            // the usual run: it starts a variance block and holds all of it -- the stream has the samples whatever the pending step
+            // is (nf - p >= 1003 >= 1002 + step_off) and the symbol buffer the room: what the general form below comes to, in three
+            // compares instead of forty-five scalar instructions and a load of the symbol capacity from the argument block
+            m = DH_VARIANCE_SYMBOLS;
+        } else {
             uint32_t lim = dh_min<uint32_t>(DH_VARIANCE_SYMBOLS - k0, max_run);
             lim = dh_min<uint32_t>(lim, P.sym_cap - nsym);
             const int64_t room = (int64_t) nf - (int64_t) p - (int64_t) sps - 2;     // >= 0  <=>  symbol 0 fits

@@ -49,7 +49,7 @@ def test_profiled_counters_are_scaled_to_the_size_of_the_run():
     import bench
     full = bench.profiled_counters("rrc_gfsk", 16384, 190080)
     quarter = bench.profiled_counters("rrc_gfsk", 4096, 190080)
-    assert full and quarter and "scaled" in quarter["traffic_source"]
+    assert full and quarter and ("scaled" in quarter["traffic_source"]) != ("scaled" in full["traffic_source"])      # (one of the two sizes is the one the pass ran on)
     assert abs(quarter["traffic"] / full["traffic"] - 0.25) < 1e-9
     alg = 4096 * 190080 * 8.0                       # 4 B in + 4 B out per sample
     assert 0.9 < quarter["traffic"] / alg < 1.3     # HBM traffic of the materialised-RRC kernel is its algorithmic bytes, give or take
