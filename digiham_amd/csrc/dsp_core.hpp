@@ -1603,16 +1603,25 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 }
             }
             float mx = 0.0f;                            // (a NaN is skipped here and caught behind the FIR)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            {
+                // ten v_max3_f32 in ONE statement (as ten statements the compiler put an s_nop behind each)
+                static_assert(DH_PF_N == 5, "five groups of four");
+                const dh_f4 w0 = varr[0], w1 = varr[1], w2 = varr[2], w3 = varr[3], w4 = varr[4];
+                asm("v_max3_f32 %0, |%1|, |%2|, 0\n\tv_max3_f32 %0, |%3|, |%4|, %0\n\tv_max3_f32 %0, |%5|, |%6|, %0\n\tv_max3_f32 %0, |%7|, |%8|, %0\n\t"
+                    "v_max3_f32 %0, |%9|, |%10|, %0\n\tv_max3_f32 %0, |%11|, |%12|, %0\n\tv_max3_f32 %0, |%13|, |%14|, %0\n\tv_max3_f32 %0, |%15|, |%16|, %0\n\t"
+                    "v_max3_f32 %0, |%17|, |%18|, %0\n\tv_max3_f32 %0, |%19|, |%20|, %0"
+                    : "=&v"(mx) : "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(w2.w),
+                                  "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w));
+            }
+#else
 #pragma unroll
             for (int r = 0; r < DH_PF_N; r++) {
                 const dh_f4 w = DH_LA(varr, lane)[r];
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                mx = dh_max3_abs(w.x, w.y, mx); mx = dh_max3_abs(w.z, w.w, mx);
-#else
                 mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y)));
                 mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(w.z), __builtin_fabsf(w.w)));
-#endif
             }
+#endif
             DH_LA(xm, lane)[0] = mx;
         }
         float xmax;
@@ -3093,14 +3102,20 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     break;
                 }
             }
-            DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[0]++; }
         }
 
         DH_CLK(5);
         DH_PROBE(5);
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
         DH_FOR_LANES_FRESH(lane) {
-            if (!merged) { for (uint32_t k = k0 + lane; k < k0 + m; k += DH_WAVE) S.vol_old[k] = S.vol_new[k]; }      // (the merged phase committed its volumes from registers)
+            if (!merged) {                              // (the merged phase committed its volumes from registers)
+                // a run has at most 100 symbols: two predicated copies per lane, both loads in flight together (as a loop this was
+                // two trips of exec-mask bookkeeping with a wait in each)
+                const uint32_t ka = k0 + (uint32_t) lane, kb = ka + DH_WAVE, ke = k0 + m;
+                const float va_ = S.vol_new[ka < ke ? ka : k0], vb_ = S.vol_new[kb < ke ? kb : k0];
+                if (ka < ke) S.vol_old[ka] = va_;
+                if (kb < ke) S.vol_old[kb] = vb_;
+            }
 #if DH_PF_L2
             (void) pf_have;
 #else
@@ -3193,11 +3208,15 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     }
     DH_FOR_LANES(lane) {
         if (DH_IS_LANE0(lane)) {
+            // (timing blocks completed by this call: the symbol counter of the block wraps at 100 exactly when one ends -- counted here,
+            // from the counter as the call found it, not with a read-modify-write of LDS by one lane in every run)
+            // (sym_base is not kept through the loop: a later part finds it where it read it, until P.sym_count is stored below)
+            const uint32_t produced = nsym - (part_lo ? P.sym_count[ch] : 0u);
+            sth[DH_ST_BLOCKS] += (sth[DH_ST_K] + produced) / DH_VARIANCE_SYMBOLS;
             sth[DH_ST_K] = k0;
             sth[DH_ST_OFF] = (uint32_t) off;
             sth[DH_ST_TAIL] = new_tc < tail_max ? new_tc : tail_max;
-            // (sym_base is not kept through the loop: a later part finds it where it read it, until the store below)
-            sth[DH_ST_NSYM] += nsym - (part_lo ? P.sym_count[ch] : 0u);
+            sth[DH_ST_NSYM] += produced;
             if (BOUNDED) {
                 sth[DH_ST_P0] = keep;
                 sth[DH_ST_CUR_START] = (uint32_t) (BS->cur_start - (int32_t) base); sth[DH_ST_CUR_OFF] = (uint32_t) BS->cur_off;
@@ -3214,7 +3233,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             sth[DH_ST_DIAG + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
             sth[DH_ST_DIAG + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
 #endif
-            sth[DH_ST_BLOCKS] += S.stats[0];
+
             sth[DH_ST_ORDERED] += S.stats[1];
             P.sym_count[ch] = nsym;
             if ((overflow || new_tc > tail_max) && P.overflow) *P.overflow = 1u;

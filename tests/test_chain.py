@@ -242,7 +242,8 @@ def test_custom_rrc_table(ctx, oracle):
         assert fc[b] == ref["out_count"][b] and (f[b, :fc[b]] == ref["out"][b, :fc[b]]).all()
 
 
-@pytest.mark.parametrize("kw,oproto", [(dict(proto="dmr"), 1), (dict(proto="ysf"), 2), (dict(proto="none", keep_filtered=True), 0)])
+@pytest.mark.parametrize("kw,oproto", [(dict(proto="dmr"), 1), (dict(proto="ysf"), 2), (dict(proto="none", keep_filtered=True), 0),
+                                       (dict(proto="none", keep_filtered=True, one_launch=True), 0)])
 def test_ragged_pushes_every_channel_at_its_own_pace(ctx, oracle, kw, oproto):
     """dh_engine_push_ragged: each push brings a different number of samples per channel (some none at all); every channel's
     concatenated outputs are those of its whole stream -- what N module instances sharing one launch need
@@ -283,7 +284,10 @@ def test_ragged_pushes_every_channel_at_its_own_pace(ctx, oracle, kw, oproto):
         if kw["proto"] != "none":
             gf = np.concatenate(frames[b])
             assert len(gf) == ref["out_count"][b] and (gf == ref["out"][b, :len(gf)]).all(), b
-        if kw.get("keep_filtered"):
+        if kw.get("one_launch"):                    # (DH_FLAG_ONE_LAUNCH: the matrix-core FIR's floats, 2.5e-6; every sample of every push delivered)
+            y = np.concatenate(filt[b])
+            assert y.shape == ref["filtered"][b].shape and rel_err(y, ref["filtered"][b]).max() <= 2.5e-6, b
+        elif kw.get("keep_filtered"):
             assert (np.concatenate(filt[b]).view(np.uint32) == ref["filtered"][b].view(np.uint32)).all(), b
 
 
