@@ -2807,6 +2807,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
 #endif
             if (!RINGLESS && SPS == 10 && !P.ordered_timing && !est_done) {
+#ifdef DH_DBG_P6_COUNT
+                if (BOUNDED) BS->n_exact_runs++;              // diagnostic builds: how often does the lean estimate hand over?  (header word 17)
+#endif
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
                 // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
