@@ -323,7 +323,8 @@ class Job:
                 continue
             x, info = synth_torch.make_batch(torch, device, p, B, units or UNITS[p], seed=1000 * (i + 1) + 7919 * rank, sps=k["sps"])
             T = info["samples_per_channel"]
-            stream = torch.cuda.Stream(device) if streams > 1 else None
+            iq_pipe = workload.endswith("_iq_full") and streams > 1      # int16 I/Q: the front-end of step k + 1 on its own stream beside the chain kernel of step k
+            stream = torch.cuda.Stream(device) if streams > 1 and not iq_pipe else None
             if stream is not None:
                 with torch.cuda.stream(stream):
                     eng = api.Engine(B, T, ctx=ctx, **k)
@@ -341,11 +342,35 @@ class Job:
                 part["fe_state"] = torch.zeros((B, 4), dtype=torch.float32, device=device)
                 part["x"] = torch.empty_like(x)                     # the front-end's output buffer = the engine's input
                 part["ctx"] = ctx
+                if iq_pipe:
+                    # two float buffers: the front-end writes one (its own stream) while the chain kernel reads the other; events order
+                    # "converted before pushed" and "pushed before overwritten" -- what a receiver with a ring of buffers does anyway
+                    part["xbuf"] = [part["x"], torch.empty_like(x)]
+                    part["fe_stream"] = torch.cuda.Stream(device)
+                    part["fe_done"] = [torch.cuda.Event(), torch.cuda.Event()]
+                    part["push_done"] = [torch.cuda.Event(), torch.cuda.Event()]
+                    part["k"] = 0
             self.parts.append(part)
         self.samples_per_step = float(sum(p["B"] * p["T"] for p in self.parts))
 
     def step(self):
         for p in self.parts:
+            if "fe_stream" in p:
+                torch = self.torch
+                c, mem = p["ctx"], p["ctx"].mem
+                b = p["k"] & 1
+                p["k"] += 1
+                xb = p["xbuf"][b]
+                cur = torch.cuda.current_stream(p["iq"].device)
+                with torch.cuda.stream(p["fe_stream"]):
+                    p["fe_stream"].wait_event(p["push_done"][b])            # the push that last read this buffer (two steps ago) is through
+                    rc = c.lib.dh_frontend_s16(mem.ptr(p["iq"]), 2 * p["T"], mem.ptr(xb), p["T"], mem.ptr(p["fe_state"]), p["B"], p["T"], 2, 1, mem.stream())
+                    assert rc == 0, "dh_frontend_s16 failed"
+                    p["fe_done"][b].record(p["fe_stream"])
+                cur.wait_event(p["fe_done"][b])
+                p["eng"].push(xb)
+                p["push_done"][b].record(cur)
+                continue
             if "iq" in p:
                 c, mem = p["ctx"], p["ctx"].mem
                 rc = c.lib.dh_frontend_s16(mem.ptr(p["iq"]), 2 * p["T"], mem.ptr(p["x"]), p["T"], mem.ptr(p["fe_state"]), p["B"], p["T"], 2, 1, mem.stream())
@@ -585,7 +610,8 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
     for workload, channels, overlap, streams in (("rrc_gfsk", 4096, False, 1), ("rrc_gfsk_fast", 4096, False, 1), ("rrc_gfsk_one", 4096, False, 1), ("ysf_full", 16384, False, 1),
                                                  ("mixed", (8192, 8192), False, 1), ("mixed", (8192, 8192), False, 2),
                                                  ("mixed", (4096, 4096), False, 1), ("mixed", (4096, 4096), False, 2), ("dmr_full", 8192, False, 1),
-                                                 ("dmr_full", 16384, True, 1), ("ysf_full", 16384, True, 1)):
+                                                 ("dmr_full", 16384, True, 1), ("ysf_full", 16384, True, 1),
+                                                 ("dmr_iq_full", 16384, False, 1)):       # (`--workload dmr_iq_full --streams 2`, the front-end on its own stream, gains 3 %: both kernels fill the chip)
         t_start = time.perf_counter()
         job = Job(torch, ctx, device, workload, channels, rank=0, overlap=overlap, streams=streams)
         dt = job.timed(steps, warmup)
@@ -600,6 +626,8 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
                  "stage_ms": stage}
         if verify:
             ok, entry["verified"] = job.verify_timed(verify, steps + warmup)
+            if ok is None:
+                ok, entry["verified"] = job.verify(ctx, verify)          # front-end workloads: a replay on a fresh small engine
             assert ok, "GPU output of the timed engines differs from the oracle (%s)" % entry["workload"]
         job.close()
         del job
@@ -619,7 +647,7 @@ def main():
     ap.add_argument("--channels", type=int, default=16384, help="channels per GPU (weak scaling)")
     ap.add_argument("--total-channels", type=int, default=65536, help="channels of the whole job (strong scaling)")
     ap.add_argument("--units", type=int, default=0, help="bursts (DMR, 30 ms) or frames (YSF, 100 ms) per step; 0 = ~4 s")
-    ap.add_argument("--streams", type=int, default=1, help="mixed: 2 = the two engines on their own HIP streams")
+    ap.add_argument("--streams", type=int, default=1, help="mixed: 2 = the two engines on their own HIP streams; dmr_iq_full: 2 = the front-end of the next step on its own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--split-stages", action="store_true", help="slicer and decoder as two kernels (per-stage timing)")

@@ -269,3 +269,27 @@ def test_bench_runs_its_distributed_path_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["verified"]["bit_exact_vs_oracle"]
+
+
+@pytest.mark.gpu
+def test_bench_iq_front_end_on_its_own_stream_equals_the_serial_order(gpu_ctx):
+    """bench.py `--workload dmr_iq_full --streams 2`: the front-end of step k + 1 runs on its own stream beside the chain kernel of
+    step k (two float buffers, events for "converted before pushed" and "pushed before overwritten").  Same symbols, frames and
+    events behind bursts of 1, 4 and 3 queued steps as with both on one stream."""
+    import torch
+    import bench
+    dev = gpu_ctx.mem.device
+    outs = []
+    for streams in (1, 2):
+        job = bench.Job(torch, gpu_ctx, dev, "dmr_iq_full", 512, rank=0, streams=streams, units=40)
+        got = []
+        for burst in (1, 4, 3):                               # steps queued back to back (the streams really overlap), outputs read behind each burst
+            for _ in range(burst):
+                job.step()
+            e = job.parts[0]["eng"]
+            s, sc = e.symbols(); f, fc = e.frames(); ev, ec = e.events()
+            got.append(_digest(s, sc) + _digest(f, fc) + [hashlib.sha256(ev[b, :ec[b]].tobytes()).hexdigest() for b in range(len(ec))])
+        job.close()
+        outs.append(got)
+    assert outs[0] == outs[1]
+    assert len(set(outs[0][-1])) > 1
