@@ -91,7 +91,7 @@ int dh_debug_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n, fl
 }
 
 int dh_debug_copy(const void* src, void* dst, size_t n_bytes, void* s) {
-    if (((!src || !dst) && n_bytes) || (n_bytes & 15u) || (((uintptr_t) src | (uintptr_t) dst) & 15u)) return DH_EINVAL;
+    if ((!src && n_bytes) || (n_bytes & 15u) || (((uintptr_t) src | (uintptr_t) dst) & 15u)) return DH_EINVAL;      // (dst == null: read only)
     return dh_be_copy_kernel(src, dst, n_bytes, s);
 }
 

@@ -489,6 +489,24 @@ __global__ __launch_bounds__(256) void k_copy16(const dh_u4s* __restrict__ src, 
     for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// ... and the read-only rate (dh_debug_copy with a null destination): eight 16-byte non-temporal loads in flight per lane, the words folded
+// into a value nobody stores -- what a kernel that mostly READS (the chain kernels: 93 % of their HBM traffic) can be priced against
+__device__ uint32_t g_read_sink[4];
+__global__ __launch_bounds__(256) void k_read16(const dh_u4s* __restrict__ src, size_t n16) {
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    dh_u4s acc = { 0, 0, 0, 0 };
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        dh_u4s v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= v[u];
+    }
+    for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(src + i);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u && acc.x == 0x9E3779B9u) { volatile uint32_t* sink = g_read_sink; sink[0] = acc.x; sink[1] = acc.y; }      // (volatile: the variable has internal linkage and no reader -- a plain store, and with it the whole kernel, is dead code)
+}
+
 inline unsigned grid_for(size_t n, unsigned block) {
     const size_t g = (n + block - 1) / block;
     return (unsigned) (g < 1 ? 1 : (g > 8192 ? 8192 : g));      // 256 CUs x 32 resident workgroups, grid-stride beyond
@@ -974,6 +992,12 @@ static int dh_be_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n
 static int dh_be_copy_kernel(const void* src, void* dst, size_t n_bytes, void* stream) {
     if (!n_bytes) return DH_OK;
     const size_t n16 = n_bytes / 16;
+    if (!dst) {
+        const unsigned rgrid = (unsigned) std::min<size_t>((n16 + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_read16, dim3(rgrid), dim3(256), 0, (hipStream_t) stream, (const dh_u4s*) src, n16);
+        HIP_TRY(hipGetLastError());
+        return DH_OK;
+    }
     const unsigned grid = (unsigned) std::min<size_t>((n16 + 255) / 256, 2048);      // 256 CUs x 8 resident workgroups of 256
     hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, (hipStream_t) stream, (const dh_u4s*) src, (dh_u4s*) dst, n16);
     HIP_TRY(hipGetLastError());

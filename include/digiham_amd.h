@@ -285,7 +285,8 @@ int dh_debug_f16_split(const float* d_in, uint16_t* d_h1, uint16_t* d_h2, size_t
 /* A plain streaming copy of n_bytes (a multiple of 16, both pointers 16-byte aligned): 16 bytes per lane, non-temporal
  * loads and stores, grid-stride over 2 048 workgroups.  Not part of the path -- bench.py times it on the lease it runs on
  * as the achievable HBM ceiling (read + write bytes over its duration) that the path's kernels are priced against beside
- * the 8 TB/s of the data sheet. */
+ * the 8 TB/s of the data sheet.  d_dst == NULL: the bytes are only read (eight loads in flight per lane, 8 192 workgroups) -- the read-only
+ * streaming rate, which is what a kernel that mostly reads (the chain kernels) can be priced against. */
 int dh_debug_copy(const void* d_src, void* d_dst, size_t n_bytes, void* stream);
 
 #ifdef __cplusplus

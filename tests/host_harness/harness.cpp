@@ -211,7 +211,7 @@ static int dh_be_f16_split(const float* in, uint16_t* h1, uint16_t* h2, size_t n
     }
     return 0;
 }
-static int dh_be_copy_kernel(const void* src, void* dst, size_t n_bytes, void*) { __builtin_memcpy(dst, src, n_bytes); return 0; }
+static int dh_be_copy_kernel(const void* src, void* dst, size_t n_bytes, void*) { if (dst) __builtin_memcpy(dst, src, n_bytes); return 0; }
 static int dh_be_div_const(const float* in, float* out, size_t n, unsigned divisor, void*) {
     const float d = (float) divisor, r = 1.0f / d;
     for (size_t i = 0; i < n; i++) out[i] = dh_div_const(in[i], d, r);
