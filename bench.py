@@ -353,6 +353,7 @@ class Job:
                     part["fe_done"] = [torch.cuda.Event(), torch.cuda.Event()]
                     part["push_done"] = [torch.cuda.Event(), torch.cuda.Event()]
                     part["k"] = 0
+                    part["fe_stream"].wait_stream(torch.cuda.current_stream(device))      # (the I/Q samples and the front-end's state were written on this stream)
             self.parts.append(part)
         self.samples_per_step = float(sum(p["B"] * p["T"] for p in self.parts))
 
