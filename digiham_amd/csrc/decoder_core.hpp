@@ -31,6 +31,29 @@
 #define DH_LV_READ(name, k) ((uint32_t) name[k])
 #define DH_LV_DOWN(name, lane, d) ((uint32_t) name[((lane) + (d)) < DH_WAVE ? (lane) + (d) : (lane)])
 #endif
+// the same for a struct of per-lane values (registers on the GPU, an array of structs in the harness); DH_LS_READ fetches a
+// field of lane k (wave-uniform k: v_readlane), DH_LS_WRITE sets it (v_writelane)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_LANE_STRUCT(type, name) type name
+#define DH_LANE_STRUCT_REF(type, name) type& name
+#define DH_LS(name, lane) name
+#define DH_LS_READ(name, field, k) ((uint32_t) __builtin_amdgcn_readlane((int) (name).field, (int) (k)))
+// (v_writelane takes value and lane from scalar registers, a VOP3 of gfx9 reads at most one: the lane select goes through m0,
+// which belongs to the compiler -- saved and restored around the write, as in DhState::set)
+static __device__ __forceinline__ uint32_t dh_writelane(uint32_t reg, uint32_t lane, uint32_t v) {
+    const uint32_t sv = (uint32_t) __builtin_amdgcn_readfirstlane((int) v), si = (uint32_t) __builtin_amdgcn_readfirstlane((int) lane);
+    uint32_t keep;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(reg), "=&s"(keep) : "s"(sv), "s"(si));
+    return reg;
+}
+#define DH_LS_WRITE(name, field, k, v) (name).field = dh_writelane((name).field, (uint32_t) (k), (uint32_t) (v))
+#else
+#define DH_LANE_STRUCT(type, name) type name[DH_WAVE]
+#define DH_LANE_STRUCT_REF(type, name) type* name
+#define DH_LS(name, lane) name[lane]
+#define DH_LS_READ(name, field, k) ((uint32_t) (name)[k].field)
+#define DH_LS_WRITE(name, field, k, v) (name)[k].field = (uint32_t) (v)
+#endif
 
 #define DH_SYM_CARRY_MAX 512          // symbols a decoder may leave unread between pushes (<= 480)
 #define DH_DSTAR_CARRY_MAX 704        // D-Star: the header phase waits for more than 660 bits (dstar_phase.hpp:52)
@@ -217,6 +240,17 @@ DH_HD void dh_dmr_enter_frame_phase(DhState& s) {
 #ifndef DH_SYMWIN
 #define DH_SYMWIN 1024               // fresh symbols staged in LDS per refill (a DMR burst is 144, a YSF frame 480)
 #endif
+// Frame-parallel DMR (dh_dmr_channel): the bit planes of a chunk of up to 64 bursts (dibit j of the chunk: bit j & 31 of
+// word j >> 5; plane_h bit 1, plane_l bit 0 of the dibit), and a block that first holds the collected embedded-signalling words of
+// the bursts that close an embedded LC (pass B -> pass C), then the voice payloads on their way out (pass C).
+#define DH_DMR_CHUNK 64
+#define DH_DMR_PLANE_GROUPS (DH_DMR_CHUNK * 9)                  /* 16-dibit groups: 64 bursts x 144 dibits */
+#define DH_DMR_PLANE_WORDS (DH_DMR_PLANE_GROUPS / 2 + 4)        /* + slack: a lane reads six consecutive words */
+struct DhDmrChunkShared {
+    uint32_t plane_h[DH_DMR_PLANE_WORDS], plane_l[DH_DMR_PLANE_WORDS];
+    union { uint32_t emb_words[DH_DMR_CHUNK][4]; uint32_t voice[DH_DMR_CHUNK][7]; };
+};
+
 struct DhDecShared {
     uint8_t  carry[DH_SYM_CARRY_MAX];     // symbols carried from the previous push
     uint8_t  symwin[DH_SYMWIN];           // window of this push's symbols (refilled with 16-byte-per-lane loads)
@@ -225,11 +259,16 @@ struct DhDecShared {
     uint32_t fec_small[(offsetof(DhFecTables, lut_g208) + 3) / 4];
     DhPlanes planes;                      // bit planes of the current frame (wave-uniform; LDS broadcast reads)
     uint32_t colword[16];
-    uint32_t vit_metric[2][64];
-    uint64_t vit_dec[192];
-    uint32_t vit_in[4][48];           // up to 4 concurrent codewords of 192 dibits, one dibit per byte (dh_vit_word)
-    uint8_t  vit_out[4][24];
-    uint8_t  vit_best_metric[4];
+    union {
+        struct {
+            uint32_t vit_metric[2][64];
+            uint64_t vit_dec[192];
+            uint32_t vit_in[4][48];           // up to 4 concurrent codewords of 192 dibits, one dibit per byte (dh_vit_word)
+            uint8_t  vit_out[4][24];
+            uint8_t  vit_best_metric[4];
+        };
+        DhDmrChunkShared dmr;                 // the frame-parallel DMR decoder's chunk (no Viterbi in DMR)
+    };
 #ifdef DH_PHASE_CLOCKS
     uint32_t clk[8];
 #endif
@@ -620,7 +659,610 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
 #define DH_DCLK(i) ((void) 0)
 #endif
 
+// =============================================================================================
+// Frame-parallel DMR decoder (round 5).
+//
+// The reference handles one 144-dibit burst per call (dmr_phase.cpp:61-302).  While a channel is in its FramePhase the burst
+// grid of a push is known up front (pos + 144 k), and almost everything a burst needs is a function of its own dibits alone:
+// sync correlation, TACT Hamming(7,4), EMB QR(16,7), slot-type Golay(20,8), BPTC(196,96), the 27 voice bytes.  Only the slot /
+// superframe / embedded-LC bookkeeping (:65-204) chains the bursts together, and it needs a dozen bits of each.  So a push is
+// taken in CHUNKS of up to 64 bursts:
+//   planes  the chunk's dibits -> two bit planes in LDS (16 dibits per lane and load, packed in registers)
+//   pass A  one burst per LANE: its 144 dibits as 2 x 5 words from the planes, every block code of the burst decoded lane-locally
+//           (bit-sliced Hamming(13,9) over the BPTC columns), results condensed into a summary word
+//   pass B  the reference's state machine, burst after burst, on the summaries: scalar code only (v_readlane in, v_writelane
+//           out), leaves one word of event / output flags per burst; a burst that sends the decoder back to its SyncPhase
+//           ends the chunk
+//   pass C  one burst per lane again: embedded LCs, event records (offsets by a vote-based prefix sum), voice payloads
+//           (staged in LDS, stored coalesced)
+// The SyncPhase search (dmr_phase.cpp:35-47) is unchanged.
+// =============================================================================================
+#if defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_DMARK(text) asm volatile("; DH_DMARK " text ::: "memory")      // (tools/asm_census.sh: the decoder's regions in the assembly)
+#else
+#define DH_DMARK(text) ((void) 0)
+#endif
+struct DhDmrLane {
+    uint32_t hw[5], lw[5];        // the burst's dibits: dibit i = bit i & 31 of word i >> 5 (hw: bit 1, lw: bit 0)
+    uint32_t summary;             // pass A -> B, C (DH_DS_*)
+    uint32_t frag;                // the 32 embedded-signalling bits (dmr_phase.cpp:141-145)
+    uint32_t bptc[3];             // BPTC(196,96) payload, 12 bytes in memory order
+    uint32_t flags;               // pass B -> C (DH_DF_*)
+};
+enum {   // summary word
+    DH_DS_HAS_TACT = 1u << 0, DH_DS_TACT_SLOT_SHIFT = 1, DH_DS_SYNC_SHIFT = 2 /*2 bits: 0 none, DATA, VOICE*/, DH_DS_EMB_OK = 1u << 4,
+    DH_DS_LCSS_SHIFT = 5 /*2*/, DH_DS_ST_OK = 1u << 7, DH_DS_DT_SHIFT = 8 /*4*/, DH_DS_BPTC_OK = 1u << 12,
+    DH_DS_EMB_CC_SHIFT = 16 /*4*/, DH_DS_ST_CC_SHIFT = 20 /*4*/,
+    DH_DS_DFLAGS_SHIFT = 24 /*4: what a data burst emits, DH_DF_SLOTTYPE .. DH_DF_BPTC_TAIL >> 6*/
+};
+enum {   // flag word, events in the order they are emitted
+    DH_DF_RESET_OTHER = 1u << 0, DH_DF_SYNC = 1u << 1, DH_DF_EMB = 1u << 2, DH_DF_EMB_LC = 1u << 3, DH_DF_SLOT_RESET = 1u << 4,
+    DH_DF_META_RESET = 1u << 5, DH_DF_SLOTTYPE = 1u << 6, DH_DF_SLOT_RESET2 = 1u << 7, DH_DF_BPTC = 1u << 8, DH_DF_BPTC_TAIL = 1u << 9,
+    DH_DF_EVENTS = 0x3FFu,
+    DH_DF_VOICE = 1u << 10, DH_DF_SLOT = 1u << 11, DH_DF_SOFT = 1u << 12
+};
+
+struct alignas(16) DhU4 { uint32_t x, y, z, w; };
+
+// 16 dibits, one per byte in four words -> their bit-1 mask | bit-0 mask << 16
+DH_HD uint32_t dh_pack16_dibits(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    const uint32_t t = w0 | (w1 << 2) | (w2 << 4) | (w3 << 6);      // byte q: dibits q, 4 + q, 8 + q, 12 + q
+    uint32_t r[2];
+    for (int b = 0; b < 2; b++) {
+        uint32_t x = (t >> b) & 0x55555555u;                       // bit 8 q + 2 g = dibit 4 g + q
+        x = (x | (x >> 7)) & 0x00FF00FFu;                          // byte 0: q = 0, 1 interleaved; byte 2: q = 2, 3
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        x = (x | (x << 2)) & 0x33333333u;                          // pair (q, q + 1) of group g at bit 4 g (+ 16)
+        r[b] = ((x & 0xFFFFu) | (x >> 14)) & 0xFFFFu;
+    }
+    return r[1] | (r[0] << 16);
+}
+
+// dibits [origin, origin + 16 ngroups) of the virtual stream -> S.dmr.plane_h / plane_l, 16 dibits per lane and step.  `origin`
+// (it may lie in front of the stream) is chosen by the caller so that every group inside the fresh part is a 16-byte aligned piece
+// of the row; groups that touch the carried part or the end of the stream are gathered dibit by dibit.
+DH_HD void dh_dmr_build_planes(const DhSymView& syms, int32_t origin, uint32_t ngroups, uint32_t total, DhDecShared& S) {
+    // a 16-byte piece of the row that may be loaded whatever a lane's own group is (loads are issued unconditionally: a load under a
+    // branch is waited for on the spot)
+    const int64_t first_fresh = (int64_t) syms.nc;
+    int64_t safe = origin;
+    while (safe < first_fresh) safe += 16;
+    const bool have_safe = safe + 16 <= (int64_t) total;
+    uint16_t* const ph = reinterpret_cast<uint16_t*>(S.dmr.plane_h);
+    uint16_t* const pl = reinterpret_cast<uint16_t*>(S.dmr.plane_l);
+    constexpr int BATCH = 5;
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += BATCH * DH_WAVE) {
+        DH_FOR_LANES(lane) {
+            uint32_t w[BATCH][4];
+            bool fast[BATCH];
+#pragma unroll
+            for (int b = 0; b < BATCH; b++) {
+                const uint32_t g = g0 + (uint32_t) b * DH_WAVE + (uint32_t) lane;
+                const int64_t j0 = (int64_t) origin + 16 * (int64_t) g;
+                fast[b] = have_safe && g < ngroups && j0 >= first_fresh && j0 + 16 <= (int64_t) total;
+                if (have_safe) {
+                    const DhU4 v = *reinterpret_cast<const DhU4*>(syms.fresh + ((fast[b] ? j0 : safe) - first_fresh));
+                    w[b][0] = v.x; w[b][1] = v.y; w[b][2] = v.z; w[b][3] = v.w;
+                } else { w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u; }
+            }
+#pragma unroll
+            for (int b = 0; b < BATCH; b++) {
+                const uint32_t g = g0 + (uint32_t) b * DH_WAVE + (uint32_t) lane;
+                if (g < ngroups) {
+                    if (DH_UNLIKELY(!fast[b])) {
+                        const int64_t j0 = (int64_t) origin + 16 * (int64_t) g;
+                        for (int q = 0; q < 4; q++) {
+                            uint32_t v = 0;
+                            for (int e = 0; e < 4; e++) {
+                                const int64_t j = j0 + 4 * q + e;
+                                uint32_t d = 0;
+                                if (j >= 0 && j < (int64_t) total) d = j < first_fresh ? (uint32_t) syms.carry[j] : (uint32_t) syms.fresh[j - first_fresh];
+                                v |= (d & 3u) << (8 * e);
+                            }
+                            w[b][q] = v;
+                        }
+                    }
+                    const uint32_t hl = dh_pack16_dibits(w[b][0] & 0x03030303u, w[b][1] & 0x03030303u, w[b][2] & 0x03030303u, w[b][3] & 0x03030303u);
+                    ph[g] = (uint16_t) hl; pl[g] = (uint16_t) (hl >> 16);
+                }
+            }
+        }
+    }
+    DH_BARRIER();
+}
+
+// CNT (<= 32) bits from bit START of a little-endian bit string in words
+template <int START, int CNT> DH_HD uint32_t dh_fld(const uint32_t* w) {
+    constexpr int i = START >> 5, sh = START & 31;
+    uint32_t v = w[i] >> sh;
+    if (sh + CNT > 32) v |= w[i + 1] << (32 - sh);
+    return CNT >= 32 ? v : v & ((1u << (CNT & 31)) - 1u);
+}
+
+// BPTC(196,96) (bptc_196_96.c:5-59), one block per lane.  get(r) = received bit r (0..195).  The de-interleave and the 13 x 15
+// pivot are one gather into ROW words (bit 14 - c of R[k] = column c, row k); the fifteen Hamming(13,9) column decodes run
+// bit-sliced over the row words: syndrome bit j of every column at once is the XOR of the rows in parity check j, a column's
+// error sits in the row whose check pattern equals its syndrome (no two rows share one; a non-zero syndrome that matches no row
+// is the reference's "syndrome not found": block rejected, hamming_13_9.c:70-84).  Rows: Hamming(15,11), every syndrome
+// correctable.  Output: the 96 payload bits as 12 bytes in memory order (3 words).
+#define DH_H139_SYN(k) ((k) == 0 ? 0xFu : (k) == 1 ? 0xEu : (k) == 2 ? 0x7u : (k) == 3 ? 0xAu : (k) == 4 ? 0x5u : (k) == 5 ? 0xBu : \
+                        (k) == 6 ? 0xCu : (k) == 7 ? 0x6u : (k) == 8 ? 0x3u : (1u << (12 - (k))))      /* parity part of the generator rows (hamming_13_9.c:5-13), then the identity */
+template <typename Get>
+DH_HD bool dh_dmr_bptc_lane(const DhFecTables& T, Get get, uint32_t* out3) {
+    uint32_t R[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 15; c++) w |= get(((k * 15 + c + 1) * 181) % 196) << (14 - c);
+        R[k] = w;
+    }
+    uint32_t Sy[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 13; k++) if ((DH_H139_SYN(k) >> j) & 1u) x ^= R[k];
+        Sy[j] = x;
+    }
+    const uint32_t nz = Sy[0] | Sy[1] | Sy[2] | Sy[3];
+    uint32_t matched = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        uint32_t f = nz;
+#pragma unroll
+        for (int j = 0; j < 4; j++) f &= ((DH_H139_SYN(k) >> j) & 1u) ? Sy[j] : ~Sy[j];
+        R[k] ^= f; matched |= f;
+    }
+    bool ok = (nz & ~matched) == 0u;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ok &= dh_block_decode_rows<4>(T.h1511, T.lut_h1511, R[i]);
+    // 96 information bits: row 0 carries 3 reserved + 8, rows 1..8 carry 11 each (:45-56)
+    uint64_t acc = 0; int nacc = 0, ob = 0;
+    out3[0] = out3[1] = out3[2] = 0u;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int nb = r == 0 ? 8 : 11;
+        acc = (acc << nb) | ((R[r] >> 4) & ((1u << nb) - 1u)); nacc += nb;
+        while (nacc >= 8) { out3[ob >> 2] |= (uint32_t) ((acc >> (nacc - 8)) & 0xFFu) << (8 * (ob & 3)); ob++; nacc -= 8; }
+    }
+    return ok;
+}
+
+// EmbeddedCollector::getLc (embedded.cpp:32-94), lane-local: the 16 collected bytes as 4 big-endian words -> 9 LC bytes
+DH_HD bool dh_dmr_embedded_lc_lane(const DhFecTables& T, const uint32_t* data, uint8_t* lc) {
+    uint32_t m[8];
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t row = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = (data[j] >> (7 - r)) & 0x01010101u;
+            row |= ((x * 0x10204080u) >> 28) << (12 - 4 * j);
+        }
+        if (r < 7) ok &= dh_block_decode_rows<5>(T.h1611, T.lut_h1611, row);
+        m[r] = row;
+    }
+    uint32_t parity = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) parity ^= m[i];
+    ok &= parity == 0u;
+    uint64_t acc = 0; int nacc = 0, ob = 0; uint32_t received = 0, sum = 0;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const int nb = r < 2 ? 11 : 10;
+        acc = (acc << nb) | ((m[r] >> (16 - nb)) & ((1u << nb) - 1)); nacc += nb;
+        while (nacc >= 8) { lc[ob] = (uint8_t) (acc >> (nacc - 8)); sum += lc[ob]; ob++; nacc -= 8; }
+        if (r >= 2) received |= ((m[r] >> 5) & 1u) << (4 - (r - 2));
+    }
+    return ok && (sum % 31u) == received;
+}
+
+// pass A: lane k takes the burst at bit `off0 + 144 k` of the planes
+DH_HD void dh_dmr_pass_a(const DhDecParams& P, const DhFecTables& T, const DhDecShared& S, uint32_t off0, DH_LANE_STRUCT_REF(DhDmrLane, L)) {
+    DH_FOR_LANES(lane) {
+        DhDmrLane& me = DH_LS(L, lane);
+        const uint32_t o = off0 + 144u * (uint32_t) lane, w0 = o >> 5, sh = o & 31u;
+        uint32_t a[6], b[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { a[i] = S.dmr.plane_h[w0 + i]; b[i] = S.dmr.plane_l[w0 + i]; }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            me.hw[i] = (uint32_t) ((((uint64_t) a[i + 1] << 32) | a[i]) >> sh);
+            me.lw[i] = (uint32_t) ((((uint64_t) b[i + 1] << 32) | b[i]) >> sh);
+        }
+        const uint32_t* hw = me.hw; const uint32_t* lw = me.lw;
+        uint32_t sm = 0;
+        // CACH: TACT bits = bit 1 of dibits 0, 2, 4, 6, 7, 9, 11, first one in the MSB (cach.cpp:7,11-19); Hamming(7,4)
+        const uint32_t c12 = hw[0];
+        uint32_t tact = ((c12 & 1u) << 6) | (((c12 >> 2) & 1u) << 5) | (((c12 >> 4) & 1u) << 4) | (((c12 >> 6) & 1u) << 3) |
+                        (((c12 >> 7) & 1u) << 2) | (((c12 >> 9) & 1u) << 1) | ((c12 >> 11) & 1u);
+        if (dh_block_decode_rows<3>(T.h74, T.lut_h74, tact)) sm |= DH_DS_HAS_TACT | ((tact >> 5) & 1u) << DH_DS_TACT_SLOT_SHIFT;
+        // sync slot: dibits 66..89 (dmr_phase.cpp:18-33)
+        const uint32_t sync_h = dh_fld<66, 24>(hw), sync_l = dh_fld<66, 24>(lw);
+        const int sync_type = dh_dmr_sync_type_bits(sync_h, sync_l);
+        if (sync_type > 0) sm |= (uint32_t) sync_type << DH_DS_SYNC_SHIFT;
+        // EMB: dibits 66..69 and 86..89 (:123-132), QR(16,7); the 32 embedded bits between them (:141-145)
+        uint32_t emb = (dh_pack_msb(sync_h & 15u, sync_l & 15u, 4) << 8) | dh_pack_msb(sync_h >> 20, sync_l >> 20, 4);
+        if (dh_block_decode_rows<9>(T.qr, T.lut_qr, emb)) sm |= DH_DS_EMB_OK | ((emb >> 9) & 3u) << DH_DS_LCSS_SHIFT | ((emb >> 12) & 15u) << DH_DS_EMB_CC_SHIFT;
+        me.frag = dh_pack_msb((sync_h >> 4) & 0xFFFFu, (sync_l >> 4) & 0xFFFFu, 16);
+        // slot type: dibits 61..65 and 90..94 (:236-245), Golay(20,8)
+        uint32_t slot_type = (dh_pack_msb(dh_fld<61, 5>(hw), dh_fld<61, 5>(lw), 5) << 10) | dh_pack_msb(dh_fld<90, 5>(hw), dh_fld<90, 5>(lw), 5);
+        if (dh_block_decode_rows<12>(T.g208, P.T->lut_g208, slot_type))
+            sm |= DH_DS_ST_OK | ((slot_type >> 12) & 15u) << DH_DS_DT_SHIFT | ((slot_type >> 16) & 15u) << DH_DS_ST_CC_SHIFT;
+        // BPTC(196,96) of the burst taken as a data burst: received bit r = dibit r / 2 of the 98 info dibits (12..60, 95..143), its
+        // bit 1 first (:256-269)
+        const bool bok = dh_dmr_bptc_lane(T, [hw, lw](int r) -> uint32_t {
+            const int d = r >> 1, pos = d < 49 ? 12 + d : 46 + d;
+            return (((r & 1) ? lw : hw)[pos >> 5] >> (pos & 31)) & 1u; }, me.bptc);
+        if (bok) sm |= DH_DS_BPTC_OK;
+        if (sm & DH_DS_ST_OK) {                                   // a data burst's events (:246-300); rate 3/4 data is not decoded (:251-253)
+            const uint32_t dt = (sm >> DH_DS_DT_SHIFT) & 15u;
+            uint32_t df = DH_DF_SLOTTYPE;
+            if (dt != 8u && bok) df |= DH_DF_BPTC | ((dt == 1u || dt == 2u || dt == 9u) ? (uint32_t) DH_DF_BPTC_TAIL : 0u);      // LC (:283-285) / soft reset (:286-293)
+            sm |= (df >> 6) << DH_DS_DFLAGS_SHIFT;
+        }
+        me.summary = sm;
+        me.flags = 0u;
+    }
+}
+
+// the FramePhase's members (dmr_phase.hpp:51-60) while a chunk is walked: scalar registers
+struct DhDmrMachine {
+    int slot, stab, sync_count, st0, st1, ss0, ss1, active, filter, sf0, sf1, eo0, eo1;
+    DH_HD void load(DhState& s) {
+        slot = (int) s[DS_SLOT]; stab = (int) s[DS_SLOT_STABILITY]; sync_count = (int) s[DS_SYNC_COUNT];
+        st0 = (int) s[DS_SYNC_TYPE0]; st1 = (int) s[DS_SYNC_TYPE1]; ss0 = (int) s[DS_SLOT_SYNC0]; ss1 = (int) s[DS_SLOT_SYNC1];
+        active = (int) s[DS_ACTIVE_SLOT]; filter = (int) s[DS_SLOT_FILTER]; sf0 = (int) s[DS_SUPERFRAME0]; sf1 = (int) s[DS_SUPERFRAME1];
+        eo0 = (int) s[DS_EMB_OFF0]; eo1 = (int) s[DS_EMB_OFF1];
+    }
+    DH_HD void store(DhState& s) const {
+        s[DS_SLOT] = (uint32_t) slot; s[DS_SLOT_STABILITY] = (uint32_t) stab; s[DS_SYNC_COUNT] = (uint32_t) sync_count;
+        s[DS_SYNC_TYPE0] = (uint32_t) st0; s[DS_SYNC_TYPE1] = (uint32_t) st1; s[DS_SLOT_SYNC0] = (uint32_t) ss0; s[DS_SLOT_SYNC1] = (uint32_t) ss1;
+        s[DS_ACTIVE_SLOT] = (uint32_t) active; s[DS_SUPERFRAME0] = (uint32_t) sf0; s[DS_SUPERFRAME1] = (uint32_t) sf1;
+        s[DS_EMB_OFF0] = (uint32_t) eo0; s[DS_EMB_OFF1] = (uint32_t) eo1;
+    }
+};
+#define DH_SEL2(a0, a1, i) ((i) ? (a1) : (a0))
+#define DH_SET2(a0, a1, i, v) do { const int dh_v_ = (v); if (i) (a1) = dh_v_; else (a0) = dh_v_; } while (0)
+
+// pass B: FramePhase::process (dmr_phase.cpp:65-254) for bursts 0 .. n - 1 of the chunk on their summaries.  Returns the number of
+// bursts consumed; `nflag` = bursts that got a flag word (one more when the last one sent the decoder back to its SyncPhase
+// without being consumed, :163-170, :201-204); `to_sync` says so.  `room` = bytes left in the output row.
+// Scalar code, and written for the scalar unit: the members of the burst's slot are picked once, updated with selects instead of
+// branches wherever both sides are a move, and put back once; what depends on the burst alone (which events a data burst emits)
+// comes ready-made in the summary.
+DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LANE_STRUCT_REF(DhDmrLane, L), uint32_t n, uint32_t& room,
+                             uint32_t& nflag, bool& to_sync, bool& overflow) {
+    to_sync = false;
+    uint32_t k = 0;
+    for (; k < n; k++) {
+        DH_DMARK("passB burst");
+        const uint32_t sm = DH_LS_READ(L, summary, k);
+        uint32_t fl = 0;
+        int slot = M.slot, stab = M.stab;
+        {   // CACH / TACT slot tracking (:67-101)
+            const int tact_slot = (int) ((sm >> DH_DS_TACT_SLOT_SHIFT) & 1u);
+            const int next = (slot ^ 1) & 0xFF;                  // unsigned char next = slot ^ 1  (:69)
+            if (DH_LIKELY((sm & DH_DS_HAS_TACT) && tact_slot == next)) {
+                stab = stab >= 100 ? 100 : stab + 1;
+                slot = next;
+            } else if (sm & DH_DS_HAS_TACT) {
+                if (stab < 5) {
+                    stab = 0; slot = tact_slot;
+                    const int other = slot ^ 1;
+                    DH_SET2(M.st0, M.st1, other, -1);
+                    fl |= DH_DF_RESET_OTHER;                      // the OTHER slot, after a TACT slot switch (:80)
+                    if (M.active == other) M.active = -1;
+                } else {
+                    stab--;
+                    if (slot != -1) slot = next;
+                }
+            } else if (slot != -1) {
+                stab = stab < -100 ? -100 : stab - 1;            // if (slotStability-- < -100) slotStability = -100  (:98)
+                slot = next;
+            }
+        }
+        M.slot = slot; M.stab = stab;
+        if (DH_UNLIKELY(slot == -1)) { DH_LS_WRITE(L, flags, k, fl); continue; }
+
+        const bool s1 = slot != 0;
+        int st = s1 ? M.st1 : M.st0, ss = s1 ? M.ss1 : M.ss0, sf = s1 ? M.sf1 : M.sf0, eo = s1 ? M.eo1 : M.eo0;
+        if (s1) fl |= DH_DF_SLOT;
+        const int sync_type = (int) ((sm >> DH_DS_SYNC_SHIFT) & 3u);
+        const bool is_sync = sync_type != 0;
+        const bool emb_path = !is_sync && st == DH_SYNCTYPE_VOICE && sf < 5;            // (:119-121)
+        const bool good = is_sync || (emb_path && (sm & DH_DS_EMB_OK) != 0u);
+        if (is_sync) {                                                                  // (:104-118)
+            fl |= DH_DF_SYNC;
+            if (st == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) fl |= DH_DF_SOFT;
+            st = sync_type;
+        }
+        sf = emb_path ? sf + 1 : 0;                               // sync: 0 (:116); EMB expected: ++ (:121); neither: 0 (:188)
+        if (!emb_path) eo = 0;                                    // (:117, :189)
+        if (DH_LIKELY(good)) {
+            M.sync_count = M.sync_count >= 5 ? 5 : M.sync_count + 1;
+            ss = ss >= 5 ? 5 : ss + 1;
+            if (!is_sync) {                                       // EMB (:133-172)
+                fl |= DH_DF_EMB;
+                const uint32_t lcss = (sm >> DH_DS_LCSS_SHIFT) & 3u;
+                uint32_t off = (uint32_t) eo;
+                const uint32_t dbase = s1 ? DS_EMB_DATA1 : DS_EMB_DATA0;
+                if (lcss == 1u) off = 0;                                     // LCSS_START: reset, then collect
+                if (lcss != 0u && off <= 3u) { s[dbase + off] = DH_LS_READ(L, frag, k); off++; }      // START / CONTINUATION / STOP collect
+                if (lcss == 2u) {                                            // LCSS_STOP: pass C decodes what has been collected
+                    if (off >= 3u) {
+                        const uint32_t d0 = s[dbase], d1 = s[dbase + 1u], d2 = s[dbase + 2u], d3 = s[dbase + 3u];
+                        DH_FOR_LANES(lane) {
+                            if (DH_IS_LANE0(lane)) { S.dmr.emb_words[k][0] = d0; S.dmr.emb_words[k][1] = d1; S.dmr.emb_words[k][2] = d2; S.dmr.emb_words[k][3] = d3; }
+                        }
+                        fl |= DH_DF_EMB_LC;
+                    }
+                    off = 0;
+                }
+                eo = (int) off;
+            }
+        } else {                                                  // dmr_phase.cpp:175-186 == :190-204
+            if (--ss < 0) {
+                ss = 0; st = -1;
+                fl |= DH_DF_SLOT_RESET;
+                if (M.active == slot) M.active = -1;
+            }
+            if (DH_UNLIKELY(--M.sync_count < 0)) {
+                fl |= DH_DF_META_RESET;
+                DH_LS_WRITE(L, flags, k, fl);
+                to_sync = true; nflag = k + 1u;
+                return k;
+            }
+        }
+        // payload (:206-300)
+        const bool isv = st == DH_SYNCTYPE_VOICE, isd = st == DH_SYNCTYPE_DATA;
+        if (isv && ((slot + 1) & M.filter) != 0 && (M.active == -1 || M.active == slot)) {
+            M.active = slot;
+            if (DH_UNLIKELY(room < 27u)) overflow = true; else { fl |= DH_DF_VOICE; room -= 27u; }
+        } else if (!isv && M.active == slot) M.active = -1;
+        if (isd) fl |= (sm >> (DH_DS_DFLAGS_SHIFT - 6)) & (DH_DF_SLOTTYPE | DH_DF_BPTC | DH_DF_BPTC_TAIL);
+        if (!isv && !isd) fl |= DH_DF_SLOT_RESET2;
+        M.st0 = s1 ? M.st0 : st; M.st1 = s1 ? st : M.st1; M.ss0 = s1 ? M.ss0 : ss; M.ss1 = s1 ? ss : M.ss1;
+        M.sf0 = s1 ? M.sf0 : sf; M.sf1 = s1 ? sf : M.sf1; M.eo0 = s1 ? M.eo0 : eo; M.eo1 = s1 ? eo : M.eo1;
+        DH_LS_WRITE(L, flags, k, fl);
+        if (DH_UNLIKELY(overflow)) { k++; break; }
+    }
+    nflag = k;
+    return k;
+}
+
+// exclusive prefix sum over the lanes of a small per-lane count (< 16), by votes
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#define DH_LANES_BELOW(mask, lane) ((uint32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) ((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) (mask), 0u)))
+#else
+#define DH_LANES_BELOW(mask, lane) ((uint32_t) dh_popc64((mask) & (((uint64_t) 1 << (lane)) - 1u)))
+#endif
+
 DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
+    DhDecCtx c;
+    c.P = &P; c.T = &dh_lds_tables(S);
+    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
+    DhState s; s.load(st_global);
+    c.st = &s;
+    c.out = P.out + (size_t) ch * P.out_stride;
+    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
+    c.nout = dh_uniform(append ? P.out_count[ch] : 0u); c.nev = dh_uniform(append && P.ev_count ? P.ev_count[ch] : 0u); c.overflow = false;      // (append: the second part of a split push, k_chain)
+    c.consumed = s[DS_CONSUMED];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+    c.writer = threadIdx.x == 0;
+#else
+    c.writer = true;
+#endif
+    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
+    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride + sym_base;
+    syms.nfresh = P.sym_count[ch] - sym_base; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
+    const uint32_t total = syms.nc + syms.nfresh;
+    dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
+    const DhFecTables& T = dh_lds_tables(S);
+    uint32_t pos = 0;
+    uint32_t phase = s[DS_PHASE];
+    DhDmrMachine M; M.load(s);
+    DH_LANE_STRUCT(DhDmrLane, L);
+
+    for (;;) {
+        const uint32_t avail = total - pos;
+        if (DH_UNLIKELY(phase == 0)) {                                 // SyncPhase (dmr_phase.cpp:35-47)
+            if (!(avail > 90)) break;
+            DhPlanes& pl = S.planes;
+            dh_view_ensure(syms, pos, 192);
+            dh_load_planes(syms, pos, total, pl, 3);
+            uint64_t hits = 0;
+            DH_FOR_LANES(lane) {
+                const bool valid = avail - (uint32_t) lane > 90 && avail > (uint32_t) lane;
+                const bool hit = valid && dh_dmr_sync_type(pl, 66 + lane) > 0;
+                DH_BALLOT_ACC(hits, hit, lane);
+            }
+            if (hits) {
+                const uint32_t l = (uint32_t) dh_ffs64(hits);
+                pos += l; c.consumed += l;
+                phase = 1; dh_dmr_enter_frame_phase(s); M.load(s);
+            } else {
+                const uint32_t adv = dh_min<uint32_t>(64u, avail - 90u);
+                pos += adv; c.consumed += adv;
+            }
+            continue;
+        }
+        // FramePhase (dmr_phase.cpp:61-302): a chunk of bursts
+        if (!(avail > 144)) break;
+        const uint32_t a16 = (uint32_t) ((uintptr_t) syms.fresh & 15u);
+        const uint32_t off0 = (pos - syms.nc + a16) & 15u;             // dibits between the planes' origin and the first burst
+        uint32_t n = dh_min<uint32_t>((avail - 1u) / 144u, (DH_DMR_PLANE_GROUPS * 16u - off0) / 144u);
+        const uint32_t ngroups = (off0 + 144u * n + 15u) / 16u;
+        DH_DMARK("planes");
+        dh_dmr_build_planes(syms, (int32_t) pos - (int32_t) off0, ngroups, total, S);
+        DH_DMARK("passA");
+        dh_dmr_pass_a(P, T, S, off0, L);
+        DH_DMARK("passA end");
+        const DhState s_before = s; const DhDmrMachine m_before = M;
+        uint32_t nflag = 0, ncons = 0; bool to_sync = false;
+        uint64_t voice_mask = 0;
+        DH_LANE_VALUE(uint32_t, ev_at);
+        DH_LANE_VALUE(uint32_t, ev_set);
+        uint32_t nev_chunk = 0;
+        for (;;) {
+            uint32_t room = dh_uniform(P.out_cap - c.nout);
+            bool ovf = false;
+            ncons = dh_dmr_pass_b(M, s, S, L, n, room, nflag, to_sync, ovf);
+            DH_DMARK("passC");
+            DH_BARRIER();                                              // the embedded-signalling words are in LDS
+            // pass C, part 1: which events does every burst emit, and where do they go
+            uint64_t cnt_bits[4] = { 0, 0, 0, 0 }, lcmask = 0;
+            DH_FOR_LANES(lane) {
+                DhDmrLane& me = DH_LS(L, lane);
+                uint32_t fl = (uint32_t) lane < nflag ? me.flags : 0u;
+                DH_BALLOT_ACC(lcmask, (fl & DH_DF_EMB_LC) != 0u, lane);
+                me.flags = fl;
+            }
+            if (lcmask) {
+                DH_FOR_LANES(lane) {
+                    DhDmrLane& me = DH_LS(L, lane);
+                    if (me.flags & DH_DF_EMB_LC) {
+                        uint8_t lc[9];
+                        const uint32_t data[4] = { S.dmr.emb_words[lane][0], S.dmr.emb_words[lane][1], S.dmr.emb_words[lane][2], S.dmr.emb_words[lane][3] };
+                        if (dh_dmr_embedded_lc_lane(T, data, lc)) {
+                            // the 9 LC bytes take the place of the BPTC words (a burst with an EMB is a voice burst: no BPTC event)
+                            me.bptc[0] = (uint32_t) lc[0] | (uint32_t) lc[1] << 8 | (uint32_t) lc[2] << 16 | (uint32_t) lc[3] << 24;
+                            me.bptc[1] = (uint32_t) lc[4] | (uint32_t) lc[5] << 8 | (uint32_t) lc[6] << 16 | (uint32_t) lc[7] << 24;
+                            me.bptc[2] = (uint32_t) lc[8];
+                        } else me.flags &= ~(uint32_t) DH_DF_EMB_LC;
+                    }
+                }
+            }
+            DH_FOR_LANES(lane) {
+                const uint32_t fl = DH_LS(L, lane).flags;
+                const uint32_t cnt = (uint32_t) dh_popc32(fl & DH_DF_EVENTS);
+                DH_LV(ev_set, lane) = fl;
+                DH_BALLOT_ACC(cnt_bits[0], (cnt & 1u) != 0u, lane); DH_BALLOT_ACC(cnt_bits[1], (cnt & 2u) != 0u, lane);
+                DH_BALLOT_ACC(cnt_bits[2], (cnt & 4u) != 0u, lane); DH_BALLOT_ACC(cnt_bits[3], (cnt & 8u) != 0u, lane);
+                DH_BALLOT_ACC(voice_mask, (fl & DH_DF_VOICE) != 0u, lane);
+            }
+            uint64_t over = 0;
+            const uint32_t ev_room = c.ev ? P.ev_cap - c.nev : 0xFFFFFFFFu;
+            DH_FOR_LANES(lane) {
+                const uint32_t at = DH_LANES_BELOW(cnt_bits[0], lane) + 2u * DH_LANES_BELOW(cnt_bits[1], lane) +
+                                    4u * DH_LANES_BELOW(cnt_bits[2], lane) + 8u * DH_LANES_BELOW(cnt_bits[3], lane);
+                const uint32_t cnt = (uint32_t) dh_popc32(DH_LV(ev_set, lane) & DH_DF_EVENTS);
+                DH_LV(ev_at, lane) = at;
+                DH_BALLOT_ACC(over, c.ev != nullptr && at + cnt > ev_room, lane);
+            }
+            nev_chunk = (uint32_t) (dh_popc64(cnt_bits[0]) + 2 * dh_popc64(cnt_bits[1]) + 4 * dh_popc64(cnt_bits[2]) + 8 * dh_popc64(cnt_bits[3]));
+            if (DH_UNLIKELY(over != 0)) {
+                // The event row overflows in burst k_ov: the reference-shaped loop drops what does not fit, finishes that burst and
+                // stops (dh_emit / `if (c.overflow) break`).  Walk the chunk again up to that burst only.
+                const uint32_t k_ov = (uint32_t) dh_ffs64(over);
+                c.overflow = true;
+                if (k_ov + 1u < nflag) { s = s_before; M = m_before; n = k_ov + 1u; voice_mask = 0; continue; }
+            }
+            if (ovf) c.overflow = true;
+            break;
+        }
+        // pass C, part 2: the event records
+        if (c.ev != nullptr && nev_chunk) {
+            dh_event* const evrow = c.ev + c.nev;
+            const uint32_t ev_room = P.ev_cap - c.nev;
+            const uint32_t sym0 = c.consumed;
+            DH_FOR_LANES(lane) {
+                const DhDmrLane& me = DH_LS(L, lane);
+                const uint32_t fl = DH_LV(ev_set, lane), sm = me.summary;
+                uint32_t at = DH_LV(ev_at, lane);
+                const uint32_t sym_index = sym0 + 144u * (uint32_t) lane;
+                const uint32_t slot = (fl & DH_DF_SLOT) ? 1u : 0u;
+                const uint32_t dt = (sm >> DH_DS_DT_SHIFT) & 15u;
+#pragma unroll
+                for (int e = 0; e < 10; e++) {
+                    if (!((fl >> e) & 1u)) continue;
+                    uint32_t type = 0, a = slot, b = 0, len = 0, p0 = 0, p1 = 0, p2 = 0;
+                    switch (e) {
+                    case 0: type = DH_EV_DMR_SLOT_RESET; a = slot ^ 1u; b = 1; break;
+                    case 1: type = DH_EV_DMR_SYNC; b = (sm >> DH_DS_SYNC_SHIFT) & 3u; len = 1; p0 = (fl & DH_DF_SOFT) ? 1u : 0u; break;
+                    case 2: type = DH_EV_DMR_EMB; b = (sm >> DH_DS_LCSS_SHIFT) & 3u; len = 1; p0 = (sm >> DH_DS_EMB_CC_SHIFT) & 15u; break;
+                    case 3: type = DH_EV_DMR_LC; b = 1; len = 9; p0 = me.bptc[0]; p1 = me.bptc[1]; p2 = me.bptc[2] & 0xFFu; break;
+                    case 4: type = DH_EV_DMR_SLOT_RESET; break;
+                    case 5: type = DH_EV_DMR_META_RESET; a = 0; break;
+                    case 6: type = DH_EV_DMR_SLOTTYPE; b = dt; len = 1; p0 = (sm >> DH_DS_ST_CC_SHIFT) & 15u; break;
+                    case 7: type = DH_EV_DMR_SLOT_RESET; break;
+                    case 8: type = DH_EV_DMR_BPTC; b = dt; len = 12; p0 = me.bptc[0]; p1 = me.bptc[1]; p2 = me.bptc[2]; break;
+                    default:
+                        if (dt == 1u) { type = DH_EV_DMR_LC; b = 0; len = 9; p0 = me.bptc[0]; p1 = me.bptc[1]; p2 = me.bptc[2] & 0xFFu; }
+                        else { type = DH_EV_DMR_SOFT_RESET; b = dt; }
+                        break;
+                    }
+                    if (at < ev_room) {
+                        uint32_t* const w = reinterpret_cast<uint32_t*>(evrow + at);
+                        w[0] = sym_index; w[1] = type | a << 8 | b << 16 | len << 24;
+                        w[2] = p0; w[3] = p1; w[4] = p2; w[5] = 0u; w[6] = 0u; w[7] = 0u;
+                    }
+                    at++;
+                }
+            }
+            c.nev += dh_min<uint32_t>(nev_chunk, ev_room);
+        }
+        // pass C, part 3: voice payloads (dmr_phase.cpp:213-226): 108 dibits -> 27 bytes, first dibit in the top bits
+        if (voice_mask) {
+            DH_BARRIER();                                              // the embedded-signalling words have been read
+            DH_FOR_LANES(lane) {
+                const DhDmrLane& me = DH_LS(L, lane);
+                if ((voice_mask >> lane) & 1u) {
+                    const uint32_t rank = DH_LANES_BELOW(voice_mask, lane);
+                    // dibits 12..65 and 90..143 as one string of 108
+                    const uint32_t h0 = dh_fld<12, 32>(me.hw), h1 = dh_fld<44, 22>(me.hw) | dh_fld<90, 10>(me.hw) << 22, h2 = dh_fld<100, 32>(me.hw), h3 = dh_fld<132, 12>(me.hw);
+                    const uint32_t l0 = dh_fld<12, 32>(me.lw), l1 = dh_fld<44, 22>(me.lw) | dh_fld<90, 10>(me.lw) << 22, l2 = dh_fld<100, 32>(me.lw), l3 = dh_fld<132, 12>(me.lw);
+                    const uint32_t hh[4] = { h0, h1, h2, h3 }, ll[4] = { l0, l1, l2, l3 };
+#pragma unroll
+                    for (int j = 0; j < 7; j++) {
+                        const uint32_t h16 = (hh[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, l16 = (ll[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                        const uint32_t be = j < 6 ? dh_pack_msb(h16, l16, 16) : dh_pack_msb(h16, l16, 12) << 8;      // first dibit on top
+                        S.dmr.voice[rank][j] = (be >> 24) | ((be >> 8) & 0xFF00u) | ((be << 8) & 0xFF0000u) | (be << 24);
+                    }
+                }
+            }
+            DH_BARRIER();
+            const uint32_t nbytes = 27u * (uint32_t) dh_popc64(voice_mask);
+            uint8_t* const o = c.out + c.nout;
+            const uint8_t* const stage = reinterpret_cast<const uint8_t*>(S.dmr.voice);
+            DH_FOR_LANES(lane) {
+                for (uint32_t j = (uint32_t) lane; j < nbytes; j += DH_WAVE) {
+                    const uint32_t r = j / 27u;
+                    o[j] = stage[r * 28u + (j - r * 27u)];
+                }
+            }
+            c.nout += nbytes;
+            DH_BARRIER();
+        }
+        DH_DMARK("chunk end");
+        pos += 144u * ncons; c.consumed += 144u * ncons;
+        if (to_sync) phase = 0;
+        if (c.overflow) break;
+    }
+
+    // carry the unread symbols to the front of the buffer
+    const uint32_t rem = total - pos;
+    dh_view_ensure(syms, pos, rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX);
+    DH_FOR_LANES(lane) {
+        // sources are LDS (carried part / window), destination is the global carry row: no overlap to worry about
+        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
+        if (DH_IS_LANE0(lane)) {
+            P.out_count[ch] = c.nout;
+            if (P.ev_count) P.ev_count[ch] = c.nev;
+            if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
+        }
+    }
+    if (phase == 1) M.store(s);
+    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
+    s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
+    s.store(st_global);
+    DH_BARRIER();
+}
+
+#if 0      // the burst-serial form of round 1-4 (kept until the frame-parallel one has been measured against it)
+DH_HD void dh_dmr_channel_serial(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
 #ifdef DH_PHASE_CLOCKS
     DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
 #endif
@@ -732,6 +1374,8 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     s.store(st_global);
     DH_BARRIER();
 }
+
+#endif
 
 // =============================================================================================
 // YSF
