@@ -930,9 +930,10 @@ struct DhDmrMachine {
 // pass B: FramePhase::process (dmr_phase.cpp:65-254) for bursts 0 .. n - 1 of the chunk on their summaries.  Returns the number of
 // bursts consumed; `nflag` = bursts that got a flag word (one more when the last one sent the decoder back to its SyncPhase
 // without being consumed, :163-170, :201-204); `to_sync` says so.  `room` = bytes left in the output row.
-// Scalar code, and written for the scalar unit: the members of the burst's slot are picked once, updated with selects instead of
-// branches wherever both sides are a move, and put back once; what depends on the burst alone (which events a data burst emits)
-// comes ready-made in the summary.
+// (Two variations were measured and lost, profiles/r05_a_ab_logs.txt: the slot's members picked once and updated by selects
+// instead of branches executes MORE scalar instructions -- 358 instead of 339 per 1 000-sample run of the chain, decoder alone
+// 0.75 -> 0.84 ms; a short cut for data-sync bursts that find their slot's members already in the "data sync held" state -- a
+// fixed point of the machine -- costs the other bursts more than it saves: decoder alone 0.75 -> 0.88 ms.)
 DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LANE_STRUCT_REF(DhDmrLane, L), uint32_t n, uint32_t& room,
                              uint32_t& nflag, bool& to_sync, bool& overflow) {
     to_sync = false;
@@ -941,14 +942,11 @@ DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LAN
         DH_DMARK("passB burst");
         const uint32_t sm = DH_LS_READ(L, summary, k);
         uint32_t fl = 0;
+        const int tact_slot = (int) ((sm >> DH_DS_TACT_SLOT_SHIFT) & 1u);
         int slot = M.slot, stab = M.stab;
-        {   // CACH / TACT slot tracking (:67-101)
-            const int tact_slot = (int) ((sm >> DH_DS_TACT_SLOT_SHIFT) & 1u);
-            const int next = (slot ^ 1) & 0xFF;                  // unsigned char next = slot ^ 1  (:69)
-            if (DH_LIKELY((sm & DH_DS_HAS_TACT) && tact_slot == next)) {
-                stab = stab >= 100 ? 100 : stab + 1;
-                slot = next;
-            } else if (sm & DH_DS_HAS_TACT) {
+        const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
+        if (DH_LIKELY(sm & DH_DS_HAS_TACT)) {
+            if (DH_UNLIKELY(tact_slot != next)) {
                 if (stab < 5) {
                     stab = 0; slot = tact_slot;
                     const int other = slot ^ 1;
@@ -959,40 +957,45 @@ DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LAN
                     stab--;
                     if (slot != -1) slot = next;
                 }
-            } else if (slot != -1) {
-                stab = stab < -100 ? -100 : stab - 1;            // if (slotStability-- < -100) slotStability = -100  (:98)
+            } else {
+                if (++stab > 100) stab = 100;
                 slot = next;
             }
+        } else if (slot != -1) {
+            if (stab-- < -100) stab = -100;
+            slot = next;
         }
         M.slot = slot; M.stab = stab;
         if (DH_UNLIKELY(slot == -1)) { DH_LS_WRITE(L, flags, k, fl); continue; }
+        fl |= slot ? DH_DF_SLOT : 0u;
 
-        const bool s1 = slot != 0;
-        int st = s1 ? M.st1 : M.st0, ss = s1 ? M.ss1 : M.ss0, sf = s1 ? M.sf1 : M.sf0, eo = s1 ? M.eo1 : M.eo0;
-        if (s1) fl |= DH_DF_SLOT;
         const int sync_type = (int) ((sm >> DH_DS_SYNC_SHIFT) & 3u);
-        const bool is_sync = sync_type != 0;
-        const bool emb_path = !is_sync && st == DH_SYNCTYPE_VOICE && sf < 5;            // (:119-121)
-        const bool good = is_sync || (emb_path && (sm & DH_DS_EMB_OK) != 0u);
-        if (is_sync) {                                                                  // (:104-118)
+        bool lost = false;
+        if (sync_type > 0) {
+            if (++M.sync_count > 5) M.sync_count = 5;
+            int ssc = DH_SEL2(M.ss0, M.ss1, slot) + 1; if (ssc > 5) ssc = 5;
+            DH_SET2(M.ss0, M.ss1, slot, ssc);
+            if (DH_SEL2(M.st0, M.st1, slot) == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) fl |= DH_DF_SOFT;
+            DH_SET2(M.st0, M.st1, slot, sync_type);
             fl |= DH_DF_SYNC;
-            if (st == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) fl |= DH_DF_SOFT;
-            st = sync_type;
-        }
-        sf = emb_path ? sf + 1 : 0;                               // sync: 0 (:116); EMB expected: ++ (:121); neither: 0 (:188)
-        if (!emb_path) eo = 0;                                    // (:117, :189)
-        if (DH_LIKELY(good)) {
-            M.sync_count = M.sync_count >= 5 ? 5 : M.sync_count + 1;
-            ss = ss >= 5 ? 5 : ss + 1;
-            if (!is_sync) {                                       // EMB (:133-172)
+            DH_SET2(M.sf0, M.sf1, slot, 0);
+            DH_SET2(M.eo0, M.eo1, slot, 0);
+        } else if (DH_SEL2(M.st0, M.st1, slot) == DH_SYNCTYPE_VOICE && DH_SEL2(M.sf0, M.sf1, slot) < 5) {
+            DH_SET2(M.sf0, M.sf1, slot, DH_SEL2(M.sf0, M.sf1, slot) + 1);
+            if (sm & DH_DS_EMB_OK) {
+                if (++M.sync_count > 5) M.sync_count = 5;
+                int ssc = DH_SEL2(M.ss0, M.ss1, slot) + 1; if (ssc > 5) ssc = 5;
+                DH_SET2(M.ss0, M.ss1, slot, ssc);
                 fl |= DH_DF_EMB;
                 const uint32_t lcss = (sm >> DH_DS_LCSS_SHIFT) & 3u;
-                uint32_t off = (uint32_t) eo;
-                const uint32_t dbase = s1 ? DS_EMB_DATA1 : DS_EMB_DATA0;
-                if (lcss == 1u) off = 0;                                     // LCSS_START: reset, then collect
-                if (lcss != 0u && off <= 3u) { s[dbase + off] = DH_LS_READ(L, frag, k); off++; }      // START / CONTINUATION / STOP collect
-                if (lcss == 2u) {                                            // LCSS_STOP: pass C decodes what has been collected
-                    if (off >= 3u) {
+                uint32_t off = (uint32_t) DH_SEL2(M.eo0, M.eo1, slot);
+                const uint32_t dbase = slot ? DS_EMB_DATA1 : DS_EMB_DATA0;
+                if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
+                if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
+                    if (off <= 3) { s[dbase + off] = DH_LS_READ(L, frag, k); off++; }
+                }
+                if (lcss == 2) {                                             // LCSS_STOP: pass C decodes what has been collected
+                    if (off >= 3) {
                         const uint32_t d0 = s[dbase], d1 = s[dbase + 1u], d2 = s[dbase + 2u], d3 = s[dbase + 3u];
                         DH_FOR_LANES(lane) {
                             if (DH_IS_LANE0(lane)) { S.dmr.emb_words[k][0] = d0; S.dmr.emb_words[k][1] = d1; S.dmr.emb_words[k][2] = d2; S.dmr.emb_words[k][3] = d3; }
@@ -1001,14 +1004,22 @@ DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LAN
                     }
                     off = 0;
                 }
-                eo = (int) off;
-            }
-        } else {                                                  // dmr_phase.cpp:175-186 == :190-204
-            if (--ss < 0) {
-                ss = 0; st = -1;
+                DH_SET2(M.eo0, M.eo1, slot, (int) off);
+            } else lost = true;
+        } else {
+            DH_SET2(M.sf0, M.sf1, slot, 0);
+            DH_SET2(M.eo0, M.eo1, slot, 0);
+            lost = true;
+        }
+        if (lost) {
+            int v = DH_SEL2(M.ss0, M.ss1, slot) - 1;                         // dmr_phase.cpp:175-182 == :194-200
+            if (v < 0) {
+                v = 0;
+                DH_SET2(M.st0, M.st1, slot, -1);
                 fl |= DH_DF_SLOT_RESET;
                 if (M.active == slot) M.active = -1;
             }
+            DH_SET2(M.ss0, M.ss1, slot, v);
             if (DH_UNLIKELY(--M.sync_count < 0)) {
                 fl |= DH_DF_META_RESET;
                 DH_LS_WRITE(L, flags, k, fl);
@@ -1016,16 +1027,18 @@ DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LAN
                 return k;
             }
         }
-        // payload (:206-300)
-        const bool isv = st == DH_SYNCTYPE_VOICE, isd = st == DH_SYNCTYPE_DATA;
-        if (isv && ((slot + 1) & M.filter) != 0 && (M.active == -1 || M.active == slot)) {
-            M.active = slot;
-            if (DH_UNLIKELY(room < 27u)) overflow = true; else { fl |= DH_DF_VOICE; room -= 27u; }
-        } else if (!isv && M.active == slot) M.active = -1;
-        if (isd) fl |= (sm >> (DH_DS_DFLAGS_SHIFT - 6)) & (DH_DF_SLOTTYPE | DH_DF_BPTC | DH_DF_BPTC_TAIL);
-        if (!isv && !isd) fl |= DH_DF_SLOT_RESET2;
-        M.st0 = s1 ? M.st0 : st; M.st1 = s1 ? st : M.st1; M.ss0 = s1 ? M.ss0 : ss; M.ss1 = s1 ? ss : M.ss1;
-        M.sf0 = s1 ? M.sf0 : sf; M.sf1 = s1 ? sf : M.sf1; M.eo0 = s1 ? M.eo0 : eo; M.eo1 = s1 ? eo : M.eo1;
+
+        const int st = DH_SEL2(M.st0, M.st1, slot);
+        if (st == DH_SYNCTYPE_VOICE) {
+            if (((slot + 1) & M.filter) && (M.active == -1 || M.active == slot)) {
+                M.active = slot;
+                if (DH_UNLIKELY(room < 27u)) overflow = true; else { fl |= DH_DF_VOICE; room -= 27u; }
+            }
+        } else {
+            if (M.active == slot) M.active = -1;
+            if (st == DH_SYNCTYPE_DATA) fl |= (sm >> (DH_DS_DFLAGS_SHIFT - 6)) & (DH_DF_SLOTTYPE | DH_DF_BPTC | DH_DF_BPTC_TAIL);      // (:246-300, from pass A)
+            else fl |= DH_DF_SLOT_RESET2;
+        }
         DH_LS_WRITE(L, flags, k, fl);
         if (DH_UNLIKELY(overflow)) { k++; break; }
     }

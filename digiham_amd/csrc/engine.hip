@@ -152,8 +152,8 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
     if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
 #endif
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
-#ifdef DH_SKIP_DECODER                      // diagnostic builds (tools/phase_budget.sh): the slicer half alone
-    if (P.n_channels) return;
+#ifdef DH_SKIP_DECODER                      // diagnostic builds (tools/phase_budget.sh): the slicer half alone (the hand-over of the tail split still takes place)
+    if (!P.n_channels)
 #endif
     if (PROTO == DH_PROTO_DMR) dh_dmr_channel(D, ch, S, sym_base, part != 0);
     else if (PROTO == DH_PROTO_DSTAR) dh_dstar_channel(D, ch, S, sym_base, part != 0);
