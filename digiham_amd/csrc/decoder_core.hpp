@@ -251,6 +251,19 @@ struct DhDmrChunkShared {
     union { uint32_t emb_words[DH_DMR_CHUNK][4]; uint32_t voice[DH_DMR_CHUNK][7]; };
 };
 
+// YSF (dh_ysf_channel): the decoded FICH and V/D2 DCH codewords of the next frames (13 bytes each, in 4 words), and a block that holds
+// the bit planes of those frames while the codewords are picked out of them, then the dibit streams of the codewords that need
+// the full Viterbi decoder.
+#define DH_YSF_CHUNK 24
+#define DH_YSF_PLANE_WORDS (DH_YSF_CHUNK * 15 + 4)              /* 480 dibits a frame; + slack: a lane reads consecutive words */
+struct DhYsfChunkShared {
+    uint32_t res[DH_YSF_CHUNK][2][4];
+    union {
+        struct { uint32_t plane_h[DH_YSF_PLANE_WORDS], plane_l[DH_YSF_PLANE_WORDS]; };
+        uint32_t dirty[2 * DH_YSF_CHUNK][8];                    // bit 1 / bit 0 streams (100 bits each) of a codeword
+    };
+};
+
 struct DhDecShared {
     uint8_t  carry[DH_SYM_CARRY_MAX];     // symbols carried from the previous push
     uint8_t  symwin[DH_SYMWIN];           // window of this push's symbols (refilled with 16-byte-per-lane loads)
@@ -266,6 +279,7 @@ struct DhDecShared {
             uint32_t vit_in[4][48];           // up to 4 concurrent codewords of 192 dibits, one dibit per byte (dh_vit_word)
             uint8_t  vit_out[4][24];
             uint8_t  vit_best_metric[4];
+            DhYsfChunkShared ysf;
         };
         DhDmrChunkShared dmr;                 // the frame-parallel DMR decoder's chunk (no Viterbi in DMR)
     };
@@ -718,18 +732,18 @@ DH_HD uint32_t dh_pack16_dibits(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t 
     return r[1] | (r[0] << 16);
 }
 
-// dibits [origin, origin + 16 ngroups) of the virtual stream -> S.dmr.plane_h / plane_l, 16 dibits per lane and step.  `origin`
+// dibits [origin, origin + 16 ngroups) of the virtual stream -> the two bit planes of a chunk, 16 dibits per lane and step.  `origin`
 // (it may lie in front of the stream) is chosen by the caller so that every group inside the fresh part is a 16-byte aligned piece
 // of the row; groups that touch the carried part or the end of the stream are gathered dibit by dibit.
-DH_HD void dh_dmr_build_planes(const DhSymView& syms, int32_t origin, uint32_t ngroups, uint32_t total, DhDecShared& S) {
+DH_HD void dh_build_chunk_planes(const DhSymView& syms, int32_t origin, uint32_t ngroups, uint32_t total, uint32_t* plane_h, uint32_t* plane_l) {
     // a 16-byte piece of the row that may be loaded whatever a lane's own group is (loads are issued unconditionally: a load under a
     // branch is waited for on the spot)
     const int64_t first_fresh = (int64_t) syms.nc;
     int64_t safe = origin;
     while (safe < first_fresh) safe += 16;
     const bool have_safe = safe + 16 <= (int64_t) total;
-    uint16_t* const ph = reinterpret_cast<uint16_t*>(S.dmr.plane_h);
-    uint16_t* const pl = reinterpret_cast<uint16_t*>(S.dmr.plane_l);
+    uint16_t* const ph = reinterpret_cast<uint16_t*>(plane_h);
+    uint16_t* const pl = reinterpret_cast<uint16_t*>(plane_l);
     constexpr int BATCH = 5;
     for (uint32_t g0 = 0; g0 < ngroups; g0 += BATCH * DH_WAVE) {
         DH_FOR_LANES(lane) {
@@ -1109,7 +1123,7 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         uint32_t n = dh_min<uint32_t>((avail - 1u) / 144u, (DH_DMR_PLANE_GROUPS * 16u - off0) / 144u);
         const uint32_t ngroups = (off0 + 144u * n + 15u) / 16u;
         DH_DMARK("planes");
-        dh_dmr_build_planes(syms, (int32_t) pos - (int32_t) off0, ngroups, total, S);
+        dh_build_chunk_planes(syms, (int32_t) pos - (int32_t) off0, ngroups, total, S.dmr.plane_h, S.dmr.plane_l);
         DH_DMARK("passA");
         dh_dmr_pass_a(P, T, S, off0, L);
         DH_DMARK("passA end");
@@ -1913,6 +1927,57 @@ DH_HD uint8_t dh_ysf_v2_voice_byte(const DhPlanes& p, int base, int byte) {
     return (uint8_t) v;
 }
 
+// decodeV2VoicePayload (ysf_phase.cpp:180-256) of one 52-dibit voice block, lane-local, on the block's two bit masks (dibit j of the
+// block in bit j of `hx` / `lx`).  The 26 x 4 de-interleave (:188-197) sends de[26 r + c] = bit (r & 1 ? 0 : 1) of dibit 2 c + (r >> 1):
+// the four rows ARE the even / odd positions of the two masks, so nothing is moved -- the whitening sequence is spread the same
+// way (a constant), a tribit (:221-239) whose three bits lie in one row is a majority of the mask with itself shifted by two and
+// four, the two tribits that straddle rows (voice bits 8 and 17) are taken bit by bit, and the 49 voice bits go straight to their
+// place in the AMBE order (ysf_phase.hpp:46-51).  Returns output bytes 0..3 and 4..6 (memory order).
+struct DhV2Masks {
+    uint64_t pnh, pnl;
+    constexpr DhV2Masks(): pnh(0), pnl(0) {
+        uint32_t wsr = 0x1C9u;                                    // whitening.c:8
+        for (int k = 0; k < 104; k++) {
+            const uint64_t wb = wsr & 1u;
+            const uint32_t fb = ((wsr >> 4) & 1u) ^ (wsr & 1u);
+            wsr = ((wsr & 0x1FEu) >> 1) | (fb << 8);
+            const int r = k / 26, c = k % 26, at = 2 * c + (r >> 1);
+            if (r & 1) pnl |= wb << at; else pnh |= wb << at;
+        }
+    }
+};
+// where de[k] sits: mask (0 = h, 1 = l) and bit
+constexpr int dh_v2_de_mask(int k) { return (k / 26) & 1; }
+constexpr int dh_v2_de_bit(int k) { return 2 * (k % 26) + ((k / 26) >> 1); }
+DH_HD void dh_ysf_v2_block(uint64_t hx, uint64_t lx, uint32_t& out_lo, uint32_t& out_hi) {
+    constexpr DhV2Masks W{};
+    const uint64_t hw = hx ^ W.pnh, lw = lx ^ W.pnl;
+    const uint64_t mh = (hw & (hw >> 2)) | (hw & (hw >> 4)) | ((hw >> 2) & (hw >> 4));
+    const uint64_t ml = (lw & (lw >> 2)) | (lw & (lw >> 4)) | ((lw >> 2) & (lw >> 4));
+    uint64_t out = 0;                                             // output bit ob (first on the air) in bit ob
+#pragma unroll
+    for (int ob = 0; ob < 49; ob++) {
+        const int ib = dh_v2_inverse(ob);
+        uint64_t bit;
+        if (ib < 27) {
+            const int k = 3 * ib;
+            if (k / 26 == (k + 2) / 26) {                        // the tribit lies in one row
+                bit = ((dh_v2_de_mask(k) ? ml : mh) >> dh_v2_de_bit(k)) & 1ull;
+            } else {
+                const uint64_t a = ((dh_v2_de_mask(k) ? lw : hw) >> dh_v2_de_bit(k)) & 1ull;
+                const uint64_t b = ((dh_v2_de_mask(k + 1) ? lw : hw) >> dh_v2_de_bit(k + 1)) & 1ull;
+                const uint64_t c = ((dh_v2_de_mask(k + 2) ? lw : hw) >> dh_v2_de_bit(k + 2)) & 1ull;
+                bit = (a + b + c) >> 1;
+            }
+        } else {
+            const int k = 81 + (ib - 27);
+            bit = ((dh_v2_de_mask(k) ? lw : hw) >> dh_v2_de_bit(k)) & 1ull;
+        }
+        out |= bit << ((ob & ~7) | (7 - (ob & 7)));               // byte ob / 8, first bit on top
+    }
+    out_lo = (uint32_t) out; out_hi = (uint32_t) (out >> 32);
+}
+
 DH_HD void dh_ysf_enter_frame_phase(DhState& s) {
     s[DS_SYNC_COUNT] = 0; s[DS_HAS_FICH] = 0; s[DS_FICH] = 0; s[DS_EXPECT_SUB] = 0;
 }
@@ -1920,6 +1985,206 @@ DH_HD void dh_ysf_enter_frame_phase(DhState& s) {
 DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.cpp:16-18
     constexpr uint32_t YH = DH_YSF_SYNC_H, YL = DH_YSF_SYNC_L;
     return dh_popc32(dh_plane_range(p.h, start, 20) ^ YH) + dh_popc32(dh_plane_range(p.l, start, 20) ^ YL) <= 3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The rate-1/2 codewords of the next frames, decoded ahead (round 5).
+//
+// Every frame carries two 100-dibit codewords, FICH (fich.cpp:12-23) and -- in V/D mode 2 -- the DCH (ysf_phase.cpp:258-261), and the
+// Viterbi forward pass over them was the largest single item of this decoder (1.5 ms of the 7 ms chain launch).  More than half of
+// the codewords arrive without a single wrong dibit (the clean-codeword argument above: zero syndrome <=> exactly one path of
+// metric 0, whose message falls out of the dibits), but a pass holds four codewords, of two frames, and is only saved when all
+// four are clean.  So while the frame grid holds (sync kept: pos + 480 k) the codewords of up to DH_YSF_CHUNK frames are taken
+// together: bit planes of the chunk in LDS (16 dibits per lane and load, as in the DMR decoder), then one FRAME per lane -- its two
+// codewords out of the planes (the 20 x 5 de-interleave as five nibble spreads per row), syndrome and message with 128-bit shifts,
+// lane-locally -- and only the codewords with a non-zero syndrome go through the Viterbi decoder, packed four to a pass whatever
+// frames they belong to.  The frame loop finds the decoded bytes in S.ysf.res.
+struct DhU128 { uint64_t lo, hi; };
+DH_HD DhU128 dh_u128_shl(const DhU128& x, int k) { DhU128 r; r.lo = x.lo << k; r.hi = (x.hi << k) | (x.lo >> (64 - k)); return r; }      // 0 < k < 64
+DH_HD DhU128 dh_u128_shr(const DhU128& x, int k) { DhU128 r; r.lo = (x.lo >> k) | (x.hi << (64 - k)); r.hi = x.hi >> k; return r; }
+DH_HD DhU128 dh_u128_xor(const DhU128& a, const DhU128& b) { DhU128 r; r.lo = a.lo ^ b.lo; r.hi = a.hi ^ b.hi; return r; }
+
+// `cnt` (<= 32) bits from bit `at` of a plane
+DH_HD uint32_t dh_plane_bits(const uint32_t* plane, uint32_t at, uint32_t cnt) {
+    const uint32_t w = at >> 5, sh = at & 31u;
+    const uint64_t v = (((uint64_t) plane[w + 1u] << 32) | plane[w]) >> sh;
+    return (uint32_t) v & (cnt >= 32u ? 0xFFFFFFFFu : ((1u << cnt) - 1u));
+}
+// 100 bits, bit 20 b + a (b < 5, a < 20) -> bit 5 a + b: row b spread to every fifth position, four bits at a time (a nibble times
+// 0x1111 puts bit j at j + 4 m for m = 0..3, of which j + 4 j = 5 j is kept)
+DH_HD void dh_transpose_5x20(const uint32_t* x, uint32_t* y) {
+    y[0] = y[1] = y[2] = y[3] = 0u;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+#pragma unroll
+        for (int g = 0; g < 5; g++) {
+            const int src = 20 * b + 4 * g, sw = src >> 5, ss = src & 31;
+            uint32_t nib = x[sw] >> ss;
+            if (ss > 28) nib |= x[sw + 1] << (32 - ss);
+            const uint32_t sp = ((nib & 15u) * 0x1111u) & 0x8421u;
+            const int dst = 20 * g + b, dw = dst >> 5, ds = dst & 31;
+            y[dw] |= sp << ds;
+            if (ds > 16) y[dw + 1] |= sp >> (32 - ds);
+        }
+    }
+}
+// one 100-dibit codeword given as its two bit streams: true = not a codeword (the full decoder must look at it); otherwise the 100
+// message bits as the 13 bytes trellis.c:55-56,84 writes (first bit in the MSB of byte 0), in four words
+DH_HD bool dh_ysf_clean100(const uint32_t* h, const uint32_t* l, uint32_t* out4) {
+    DhU128 H, L;
+    H.lo = (uint64_t) h[1] << 32 | h[0]; H.hi = (uint64_t) h[3] << 32 | h[2];
+    L.lo = (uint64_t) l[1] << 32 | l[0]; L.hi = (uint64_t) l[3] << 32 | l[2];
+    // syndrome, checks t = 4 .. 99
+    const DhU128 syn = dh_u128_xor(dh_u128_xor(dh_u128_xor(H, dh_u128_shl(H, 1)), dh_u128_xor(dh_u128_shl(H, 2), dh_u128_shl(H, 4))),
+                                   dh_u128_xor(dh_u128_xor(L, dh_u128_shl(L, 3)), dh_u128_shl(L, 4)));
+    const bool dirty = ((syn.lo & ~0xFull) | (syn.hi & ((1ull << 36) - 1ull))) != 0ull;
+    // message bits 0 .. 97 by the inverse, 98 and 99 from G1 on bits that are then known
+    DhU128 U = dh_u128_xor(dh_u128_xor(dh_u128_xor(dh_u128_shr(H, 2), dh_u128_shr(H, 1)), H), dh_u128_xor(dh_u128_shr(L, 2), L));
+    U.hi &= (1ull << 34) - 1ull;
+    const DhU128 t = dh_u128_xor(H, dh_u128_xor(dh_u128_shl(U, 3), dh_u128_shl(U, 4)));
+    U.hi |= t.hi & (3ull << 34);
+    const uint32_t u[4] = { (uint32_t) U.lo, (uint32_t) (U.lo >> 32), (uint32_t) U.hi, (uint32_t) (U.hi >> 32) };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t r = dh_brev32(u[j]);                    // bit i -> 31 - i: the bytes in reverse order, each with its first bit on top
+        out4[j] = (r >> 24) | ((r >> 8) & 0xFF00u) | ((r << 8) & 0xFF0000u) | (r << 24);
+    }
+    return dirty;
+}
+
+// CRC-16 (crc16.c:3-22) of N bytes held in registers, bit by bit (lane-local: a table would be a dependent load per byte)
+template <int N> DH_HD uint32_t dh_crc16_regs(const uint32_t* bytes) {
+    uint32_t crc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        crc ^= bytes[k] << 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) : (crc << 1);
+    }
+    return ~crc & 0xFFFFu;
+}
+
+// what every frame's codewords are worth, one frame per lane: FICH = 4 x Golay(24,12) + CRC-16 (fich.cpp:24-49), DCH = CRC-16 over
+// its first ten bytes (ysf_phase.cpp:262-267)
+DH_HD void dh_ysf_check_ahead(const DhDecParams& P, const DhFecTables& T, uint32_t n, DhDecShared& S) {
+    DH_FOR_LANES(lane) {
+        if ((uint32_t) lane < n) {
+            uint32_t w[4], b[12];
+#pragma unroll
+            for (int j = 0; j < 3; j++) w[j] = S.ysf.res[lane][0][j];
+#pragma unroll
+            for (int k = 0; k < 12; k++) b[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            uint32_t g[4]; bool fresh = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                g[i] = b[3 * i] << 16 | b[3 * i + 1] << 8 | b[3 * i + 2];
+                fresh &= dh_block_decode_rows<12>(T.g2412, P.T->lut_g2412, g[i]);
+            }
+            const uint32_t fich = (g[0] & 0x00FFF000u) << 8 | (g[1] & 0x00FFF000u) >> 4 | (g[2] & 0x00FF0000u) >> 16;
+            const uint32_t checksum = (g[2] & 0x0000F000u) | (g[3] & 0x00FFF000u) >> 12;
+            const uint32_t be[4] = { fich >> 24, (fich >> 16) & 0xFFu, (fich >> 8) & 0xFFu, fich & 0xFFu };
+            fresh = fresh && dh_crc16_regs<4>(be) == checksum;
+#pragma unroll
+            for (int j = 0; j < 3; j++) w[j] = S.ysf.res[lane][1][j];
+#pragma unroll
+            for (int k = 0; k < 12; k++) b[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const bool dch_ok = dh_crc16_regs<10>(b) == (b[10] << 8 | b[11]);
+            S.ysf.res[lane][0][0] = fich; S.ysf.res[lane][0][1] = (fresh ? 1u : 0u) | (dch_ok ? 2u : 0u);
+        }
+    }
+    DH_BARRIER();
+}
+
+// frames at pos + 480 k, k < n: their FICH and DCH codewords decoded.  S.ysf.res[k][0] = { FICH word (fich.cpp:37-43), bit 0: FICH
+// fresh (four Golay(24,12) words corrected and the CRC right, :24-49), bit 1: the DCH's CRC is right (ysf_phase.cpp:262-267) },
+// S.ysf.res[k][1] = the 13 DCH bytes
+DH_HD void dh_ysf_decode_ahead(const DhDecParams& P, const DhFecTables& T, const DhSymView& syms, uint32_t pos, uint32_t n, uint32_t total, DhDecShared& S) {
+    const uint32_t a16 = (uint32_t) ((uintptr_t) syms.fresh & 15u);
+    const uint32_t off0 = (pos - syms.nc + a16) & 15u;
+    dh_build_chunk_planes(syms, (int32_t) pos - (int32_t) off0, (off0 + 480u * n + 15u) / 16u, total, S.ysf.plane_h, S.ysf.plane_l);
+    uint64_t dirty_f = 0, dirty_d = 0;
+    DH_LANE_VALUE(uint32_t, keep0); DH_LANE_VALUE(uint32_t, keep1); DH_LANE_VALUE(uint32_t, keep2); DH_LANE_VALUE(uint32_t, keep3);      // the dirty codewords' streams: FICH h
+    DH_LANE_VALUE(uint32_t, keep4); DH_LANE_VALUE(uint32_t, keep5); DH_LANE_VALUE(uint32_t, keep6); DH_LANE_VALUE(uint32_t, keep7);      // FICH l
+    DH_LANE_VALUE(uint32_t, keep8); DH_LANE_VALUE(uint32_t, keep9); DH_LANE_VALUE(uint32_t, keep10); DH_LANE_VALUE(uint32_t, keep11);    // DCH h
+    DH_LANE_VALUE(uint32_t, keep12); DH_LANE_VALUE(uint32_t, keep13); DH_LANE_VALUE(uint32_t, keep14); DH_LANE_VALUE(uint32_t, keep15);  // DCH l
+    DH_FOR_LANES(lane) {
+        const uint32_t f = (uint32_t) lane < n ? (uint32_t) lane : 0u;         // (lanes beyond the chunk repeat frame 0 and store nothing)
+        const uint32_t o = off0 + 480u * f;
+        uint32_t xh[4], xl[4], fh[4], fl[4], dh[4], dl[4], out[4];
+        // FICH: dibits 20 .. 119 of the frame, codeword dibit i at 20 + 20 (i % 5) + i / 5 (fich.cpp:16-19)
+        xh[0] = dh_plane_bits(S.ysf.plane_h, o + 20u, 32); xh[1] = dh_plane_bits(S.ysf.plane_h, o + 52u, 32);
+        xh[2] = dh_plane_bits(S.ysf.plane_h, o + 84u, 32); xh[3] = dh_plane_bits(S.ysf.plane_h, o + 116u, 4);
+        xl[0] = dh_plane_bits(S.ysf.plane_l, o + 20u, 32); xl[1] = dh_plane_bits(S.ysf.plane_l, o + 52u, 32);
+        xl[2] = dh_plane_bits(S.ysf.plane_l, o + 84u, 32); xl[3] = dh_plane_bits(S.ysf.plane_l, o + 116u, 4);
+        dh_transpose_5x20(xh, fh); dh_transpose_5x20(xl, fl);
+        const bool bad_f = dh_ysf_clean100(fh, fl, out);
+        if ((uint32_t) lane < n) { S.ysf.res[f][0][0] = out[0]; S.ysf.res[f][0][1] = out[1]; S.ysf.res[f][0][2] = out[2]; S.ysf.res[f][0][3] = out[3]; }
+        // DCH: the first 20 dibits of each of the five 72-dibit blocks behind dibit 120, dibit i at 120 + 72 (i % 5) + i / 5 (ysf_phase.cpp:103-106)
+        {
+            uint32_t rh[5], rl[5];
+#pragma unroll
+            for (int b = 0; b < 5; b++) { rh[b] = dh_plane_bits(S.ysf.plane_h, o + 120u + 72u * (uint32_t) b, 20); rl[b] = dh_plane_bits(S.ysf.plane_l, o + 120u + 72u * (uint32_t) b, 20); }
+            xh[0] = rh[0] | rh[1] << 20; xh[1] = rh[1] >> 12 | rh[2] << 8 | rh[3] << 28; xh[2] = rh[3] >> 4 | rh[4] << 16; xh[3] = rh[4] >> 16;
+            xl[0] = rl[0] | rl[1] << 20; xl[1] = rl[1] >> 12 | rl[2] << 8 | rl[3] << 28; xl[2] = rl[3] >> 4 | rl[4] << 16; xl[3] = rl[4] >> 16;
+        }
+        dh_transpose_5x20(xh, dh); dh_transpose_5x20(xl, dl);
+        const bool bad_d = dh_ysf_clean100(dh, dl, out);
+        if ((uint32_t) lane < n) { S.ysf.res[f][1][0] = out[0]; S.ysf.res[f][1][1] = out[1]; S.ysf.res[f][1][2] = out[2]; S.ysf.res[f][1][3] = out[3]; }
+        DH_BALLOT_ACC(dirty_f, (uint32_t) lane < n && bad_f, lane);
+        DH_BALLOT_ACC(dirty_d, (uint32_t) lane < n && bad_d, lane);
+        DH_LV(keep0, lane) = fh[0]; DH_LV(keep1, lane) = fh[1]; DH_LV(keep2, lane) = fh[2]; DH_LV(keep3, lane) = fh[3];
+        DH_LV(keep4, lane) = fl[0]; DH_LV(keep5, lane) = fl[1]; DH_LV(keep6, lane) = fl[2]; DH_LV(keep7, lane) = fl[3];
+        DH_LV(keep8, lane) = dh[0]; DH_LV(keep9, lane) = dh[1]; DH_LV(keep10, lane) = dh[2]; DH_LV(keep11, lane) = dh[3];
+        DH_LV(keep12, lane) = dl[0]; DH_LV(keep13, lane) = dl[1]; DH_LV(keep14, lane) = dl[2]; DH_LV(keep15, lane) = dl[3];
+    }
+    const uint32_t nf = (uint32_t) dh_popc64(dirty_f), nd = nf + (uint32_t) dh_popc64(dirty_d);
+    if (nd == 0u) { DH_BARRIER(); dh_ysf_check_ahead(P, T, n, S); return; }
+    DH_BARRIER();                                                  // every lane has read the planes: their block takes the dirty streams
+    uint8_t* const who = reinterpret_cast<uint8_t*>(S.colword);    // rank -> frame | codeword << 7
+    DH_FOR_LANES(lane) {
+        if ((dirty_f >> lane) & 1ull) {
+            const uint32_t r = DH_LANES_BELOW(dirty_f, lane);
+            uint32_t* d = S.ysf.dirty[r];
+            d[0] = DH_LV(keep0, lane); d[1] = DH_LV(keep1, lane); d[2] = DH_LV(keep2, lane); d[3] = DH_LV(keep3, lane);
+            d[4] = DH_LV(keep4, lane); d[5] = DH_LV(keep5, lane); d[6] = DH_LV(keep6, lane); d[7] = DH_LV(keep7, lane);
+            who[r] = (uint8_t) lane;
+        }
+        if ((dirty_d >> lane) & 1ull) {
+            const uint32_t r = nf + DH_LANES_BELOW(dirty_d, lane);
+            uint32_t* d = S.ysf.dirty[r];
+            d[0] = DH_LV(keep8, lane); d[1] = DH_LV(keep9, lane); d[2] = DH_LV(keep10, lane); d[3] = DH_LV(keep11, lane);
+            d[4] = DH_LV(keep12, lane); d[5] = DH_LV(keep13, lane); d[6] = DH_LV(keep14, lane); d[7] = DH_LV(keep15, lane);
+            who[r] = (uint8_t) (lane | 128);
+        }
+    }
+    DH_BARRIER();
+    for (uint32_t r0 = 0; r0 < nd; r0 += 4u) {
+        // four codewords into the decoder's input format: one dibit per byte, first in byte 0 (dh_vit_word)
+        DH_FOR_LANES(lane) {
+            for (uint32_t e = (uint32_t) lane; e < 100u; e += DH_WAVE) {
+                const uint32_t g = e / 25u, w = e - 25u * g;
+                uint32_t v = 0;
+                if (r0 + g < nd) {
+                    const uint32_t* d = S.ysf.dirty[r0 + g];
+                    const uint32_t hb = (d[w >> 3] >> (4u * (w & 7u))) & 15u, lb = (d[4u + (w >> 3)] >> (4u * (w & 7u))) & 15u;
+                    v = ((hb * 0x00204081u) & 0x01010101u) << 1 | ((lb * 0x00204081u) & 0x01010101u);      // bit q -> byte q
+                }
+                S.vit_in[g][w] = v;
+            }
+        }
+        DH_BARRIER();
+        const int sizes[4] = { 100, r0 + 1u < nd ? 100 : 0, r0 + 2u < nd ? 100 : 0, r0 + 3u < nd ? 100 : 0 };
+        dh_viterbi_wave<false, false>(S, sizes);
+        DH_FOR_LANES(lane) {
+            const uint32_t g = (uint32_t) lane >> 2, j = (uint32_t) lane & 3u;
+            if (lane < 16 && r0 + g < nd) {
+                const uint32_t id = who[r0 + g];
+                S.ysf.res[id & 127u][id >> 7][j] = reinterpret_cast<const uint32_t*>(S.vit_out[g])[j];
+            }
+        }
+        DH_BARRIER();
+    }
+    dh_ysf_check_ahead(P, T, n, S);
 }
 
 // One YSF channel, one push.
@@ -1949,9 +2214,8 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0, phase = s[DS_PHASE];
-    // position of a frame whose two codewords are already decoded in S.vit_out[2], [3]: a Viterbi pass has room for
-    // four codewords, a frame needs two, so the pass of frame k also decodes frame k+1 when its symbols are here
-    uint32_t ahead_pos = 0xFFFFFFFFu;
+    // frames whose two codewords are already decoded (dh_ysf_decode_ahead): the one at ahead_pos is S.ysf.res[ahead_i], ahead_n in all
+    uint32_t ahead_pos = 0xFFFFFFFFu, ahead_i = 0, ahead_n = 0;
 
     for (;;) {
         const uint32_t avail = total - pos;
@@ -1977,70 +2241,33 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         // FramePhase (ysf_phase.cpp:41-172)
         if (!(avail > 480)) break;
         DH_DCLK(0);
-        const bool have = ahead_pos == pos;
-        const bool two = !have && avail > 960;                     // the next frame is complete in this push as well
-        dh_view_ensure(syms, pos, two ? 960 : 512);
+        if (!(ahead_pos == pos && ahead_i < ahead_n)) {
+            // the codewords of every frame of the push that is complete (up to DH_YSF_CHUNK), on the grid this frame starts
+            const uint32_t n = dh_min<uint32_t>((avail - 1u) / 480u, (uint32_t) DH_YSF_CHUNK);
+            dh_ysf_decode_ahead(P, T, syms, pos, n, total, S);
+            ahead_pos = pos; ahead_i = 0; ahead_n = n;
+        }
+        dh_view_ensure(syms, pos, 512);
         dh_load_planes(syms, pos, total, pl, 8);
         DH_DCLK(1);
         int sync_count = (int) s[DS_SYNC_COUNT];
         if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
         else if (DH_UNLIKELY(--sync_count < 0)) {
             dh_emit(c, DH_EV_YSF_META_RESET, 0, 0, nullptr, 0);
-            phase = 0; continue;
+            phase = 0; ahead_pos = 0xFFFFFFFFu; continue;
         }
         s[DS_SYNC_COUNT] = (uint32_t) sync_count;
-
-        // stage 1: the two 100-dibit codewords of a frame (FICH and, speculatively, the V/D2 DCH) in one Viterbi pass,
-        // together with those of the following frame when it is already here
-        const int vo = have ? 2 : 0;                               // where this frame's decoded codewords are
-        if (have) ahead_pos = 0xFFFFFFFFu;
-        else {
-            DH_FOR_LANES(lane) {
-                if (lane < 25) {
-                    uint32_t f = 0, d = 0, f2 = 0, d2 = 0;
-                    for (int q = 0; q < 4; q++) {
-                        const int i = lane * 4 + q;
-                        const int fi = 20 + (i * 20) % 100 + (i * 20) / 100;                     // fich.cpp:16-19
-                        const int di = 120 + (i % 5) * 72 + (i * 2) / 10;                        // ysf_phase.cpp:103-106
-                        f = (f << 2) | dh_sym_at(pl, fi);
-                        d = (d << 2) | dh_sym_at(pl, di);
-                        if (two) {
-                            f2 = (f2 << 2) | (dh_view_at(syms, pos + 480u + (uint32_t) fi) & 3u);
-                            d2 = (d2 << 2) | (dh_view_at(syms, pos + 480u + (uint32_t) di) & 3u);
-                        }
-                    }
-                    S.vit_in[0][lane] = dh_vit_word(f); S.vit_in[1][lane] = dh_vit_word(d);
-                    if (two) { S.vit_in[2][lane] = dh_vit_word(f2); S.vit_in[3][lane] = dh_vit_word(d2); }
-                }
-            }
-            DH_BARRIER();
-            DH_DCLK(2);
-            {
-                const int sizes1[4] = { 100, 100, two ? 100 : 0, two ? 100 : 0 };
-                dh_viterbi_wave(S, sizes1);
-            }
-            if (two) ahead_pos = pos + 480u;
-        }
+        const uint32_t cw_fich = dh_uniform(S.ysf.res[ahead_i][0][0]), cw_flags = dh_uniform(S.ysf.res[ahead_i][0][1]);
+        const uint8_t* const cw_dch = reinterpret_cast<const uint8_t*>(S.ysf.res[ahead_i][1]);
+        ahead_i++; ahead_pos = pos + 480u;
         DH_DCLK(3);
 
-        // FICH: 4 x Golay(24,12) + CRC16 (fich.cpp:24-49)
-        uint32_t fich = 0; bool fresh = true;
-        {
-            uint32_t g[4];
-            for (int i = 0; i < 4; i++) {
-                g[i] = (uint32_t) S.vit_out[vo][i * 3] << 16 | (uint32_t) S.vit_out[vo][i * 3 + 1] << 8 | S.vit_out[vo][i * 3 + 2];
-                fresh &= dh_block_decode_wave<12>(T.g2412, P.T->lut_g2412, g[i]);
-            }
-            if (fresh) {
-                fich = (g[0] & 0x00FFF000u) << 8 | (g[1] & 0x00FFF000u) >> 4 | (g[2] & 0x00FF0000u) >> 16;
-                const uint32_t checksum = (g[2] & 0x0000F000u) | (g[3] & 0x00FFF000u) >> 12;
-                const uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };
-                fresh = dh_crc16_bytewise(be, 4) == checksum;
-                if (fresh) {
-                    s[DS_FICH] = fich; s[DS_HAS_FICH] = 1;
-                    dh_emit(c, DH_EV_YSF_FICH, 0, 0, be, 4);
-                }
-            }
+        // FICH (fich.cpp:24-49): decoded and checked ahead
+        const uint32_t fich = (cw_flags & 1u) ? cw_fich : 0u; const bool fresh = (cw_flags & 1u) != 0u;
+        if (fresh) {
+            const uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };
+            s[DS_FICH] = fich; s[DS_HAS_FICH] = 1;
+            dh_emit(c, DH_EV_YSF_FICH, 0, 0, be, 4);
         }
 
         DH_DCLK(4);
@@ -2066,22 +2293,27 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                     if (P.out_cap - c.nout < 40) c.overflow = true;
                     else {
                         uint8_t* o = c.out + c.nout;
+#ifndef DH_VD2_SKIP                         // (diagnostic builds leave the voice payload out: results are wrong)
                         DH_FOR_LANES(lane) {
-                            if (lane < 40) {
-                                const int blk = lane >> 3, j = lane & 7;
-#ifdef DH_VD2_SKIP
-                                o[lane] = (uint8_t) data_type;      // timing experiment (results are wrong)
-#else
-                                o[lane] = j == 0 ? (uint8_t) data_type : dh_ysf_v2_voice_byte(pl, 120 + 20 + blk * 72, j - 1);
-#endif
+                            // one block per lane (five of them): mode byte + seven voice bytes
+                            const int blk = lane < 5 ? lane : 0, base = 120 + 20 + blk * 72;
+                            const uint64_t hx = (uint64_t) dh_plane_range(pl.h, base, 32) | (uint64_t) dh_plane_range(pl.h, base + 32, 20) << 32;
+                            const uint64_t lx = (uint64_t) dh_plane_range(pl.l, base, 32) | (uint64_t) dh_plane_range(pl.l, base + 32, 20) << 32;
+                            uint32_t v0, v1;
+                            dh_ysf_v2_block(hx, lx, v0, v1);
+                            if (lane < 5) {
+                                uint8_t* ob = o + 8 * blk;
+                                ob[0] = (uint8_t) data_type;
+                                ob[1] = (uint8_t) v0; ob[2] = (uint8_t) (v0 >> 8); ob[3] = (uint8_t) (v0 >> 16); ob[4] = (uint8_t) (v0 >> 24);
+                                ob[5] = (uint8_t) v1; ob[6] = (uint8_t) (v1 >> 8); ob[7] = (uint8_t) (v1 >> 16);
                             }
                         }
+#endif
                         c.nout += 40;
                     }
                     if (fresh) {                                                    // decodeV2DataChannel (:258-269)
-                        const uint8_t* w = S.vit_out[vo + 1];
-                        const uint32_t checksum = (uint32_t) w[10] << 8 | w[11];
-                        if (dh_crc16_bytewise(w, 10) == checksum) {
+                        const uint8_t* w = cw_dch;
+                        if (cw_flags & 2u) {
                             uint8_t dch[13];
                             dh_whiten_packed(w, dch, 100);
                             dh_emit(c, DH_EV_YSF_DCH, (uint8_t) ((fich >> 19) & 7u), 0, dch, 10);
@@ -2110,9 +2342,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                 }
             } else if (DH_UNLIKELY(frame_type == 0)) {                              // header (:139-161)
                 dh_emit(c, DH_EV_YSF_META_RESET, 0, 1, nullptr, 0);
-                // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333); this pass uses
-                // the slots of a frame decoded ahead, which is then simply decoded again when its turn comes
-                ahead_pos = 0xFFFFFFFFu;
+                // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333)
                 DH_FOR_LANES(lane) {
                     if (lane < 45) {
                         uint32_t a = 0, b = 0;
