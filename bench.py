@@ -107,7 +107,8 @@ def profiled_counters(workload, channels, T, part0=False):
         c = {}
         for line in open(os.path.join(pdir, name)):
             if want(line) and "avg=" in line:
-                for key in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
+                for key in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE",
+                            "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                     if " %s " % key in line and key not in c:
                         c[key] = float(line.split("avg=")[1].split()[0])
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -119,9 +120,13 @@ def profiled_counters(workload, channels, T, part0=False):
                 out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
                 out["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
-            for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA"):
+            for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+                      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                 if k in c:
                     out[k.lower() + "_per_launch"] = c[k] * scale
+            if "GRBM_GUI_ACTIVE" in c:
+                out["gpu_cycles_per_launch_profiled"] = c["GRBM_GUI_ACTIVE"] / 8.0 * scale      # (summed over the 8 XCDs)
+            out["pmc_source"] = "profiles/" + name
             return out
     return {}
 
@@ -454,6 +459,21 @@ class Job:
         taps = {"wide": 81, "narrow": 161, "none": 0}[kw["rrc"]]
         fir_flops = B * T * 2.0 * taps              # one mul + one add per tap and sample, unfused
         pc = profiled_counters(self.workload, p["B"], T, part0=group is not None)
+        if len(self.parts) > 1:
+            # two engines (mixed): the step moves both parts' bytes -- the sum of the parts' profiled traffic, each scaled to its size
+            pcs = [profiled_counters("%s_full" % q["kw"]["proto"], q["B"], q["T"]) for q in self.parts]
+            if all("traffic" in q for q in pcs):
+                pc = dict(pc)
+                pc["traffic"] = sum(q["traffic"] for q in pcs)
+                pc["traffic_source"] = "sum over the step's engines: " + "; ".join(q["traffic_source"] for q in pcs)
+        if group is not None and "traffic" in pc:
+            # the committed passes profiled whole pushes (one launch of all channels); PART 0 of an overlapped push takes `share` of them
+            pc = dict(pc)
+            pc["traffic"] *= share
+            pc["traffic_source"] += "; x%.3f: the first launch's share of the channels" % share
+            for k in list(pc):
+                if k.endswith("_per_launch") or k == "gpu_cycles_per_launch_profiled":
+                    pc[k] *= share
         mean = lambda a: float(np.mean(a)) if len(a) else None
         f16 = (dom_name == "k_chain" or kw.get("one_launch")) and not kw.get("fast_fir") and kw["rrc"] == "wide" and kw["sps"] == 10
         bounded = f16 or (dom_name == "k_chain" and not kw.get("fast_fir") and kw["rrc"] == "narrow")
@@ -470,6 +490,30 @@ class Job:
         for k in ("valu_issue_frac", "mfma_busy_frac", "sq_insts_valu_per_launch", "sq_insts_salu_per_launch", "sq_insts_mfma_per_launch"):
             if k in pc:
                 co[k] = pc[k]
+        if "sq_insts_valu_per_launch" in pc and kw.get("demod", "gfsk") != "none":
+            # What binds (the reported roofline is HBM because the metric asks for it; HBM is idle most of the launch): the instructions a
+            # wavefront issues per RUN of the slicer (one variance block: 100 symbols = 100 x sps samples of one channel), by kind,
+            # from the committed counter passes scaled to this launch, and the SIMD cycles a run costs.
+            runs = B * T / (100.0 * kw["sps"])
+            issue = {"unit": "instructions per run (100 symbols of one channel: %d samples)" % (100 * kw["sps"]), "runs_per_launch": runs}
+            for name_, key in (("vector", "sq_insts_valu_per_launch"), ("scalar", "sq_insts_salu_per_launch"), ("lds", "sq_insts_lds_per_launch"),
+                               ("mfma", "sq_insts_mfma_per_launch"), ("branch", "sq_insts_branch_per_launch"),
+                               ("vmem_read", "sq_insts_vmem_rd_per_launch"), ("vmem_write", "sq_insts_vmem_wr_per_launch"),
+                               ("lds_bank_conflict_cycles", "sq_lds_bank_conflict_per_launch"), ("lds_active_cycles", "sq_lds_idx_active_per_launch")):
+                if key in pc:
+                    issue[name_] = pc[key] / runs
+            # 1 024 SIMDs share the launch: SIMD-cycles per run = launch duration x shader clock x 1 024 / runs
+            clock_ghz = 2.05                                                          # GRBM_GUI_ACTIVE over the launch, chain kernels
+            issue["simd_cycles_per_run"] = dom_ms * 1e-3 * clock_ghz * 1e9 * 1024.0 / runs
+            issue["shader_clock_ghz_assumed"] = clock_ghz
+            if "vector" in issue:
+                issue["simd_cycles_per_vector_instruction"] = issue["simd_cycles_per_run"] / issue["vector"]
+            issue["microbench_floor"] = {"source": "tools/microbench/clock_probe.hip, valu_rate.hip (MI355X, four wavefronts per SIMD)",
+                                         "cycles_per_plain_f32_or_int_vector_instruction": 2.4, "cycles_per_packed_conversion_minmax_dpp_instruction": 4.2,
+                                         "cycles_per_v_fma_mix": 8.2, "cycles_per_mfma_16x16x32_f16": 16.0, "cycles_per_dependent_scalar_pair": 12.75,
+                                         "one_wavefront_cycles_per_instruction_any_kind": 5.3}
+            issue["source"] = pc.get("pmc_source")
+            co["issue"] = issue
         return {"bound": "hbm", "kernel": dom_name + ("<%s>" % kw["proto"] if dom_name == "k_chain" else "") + (" PART 0" if group else ""),
                 "launch_group": group,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

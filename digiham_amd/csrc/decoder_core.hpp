@@ -666,7 +666,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
 #define DH_DCLK_BEGIN() uint64_t dh_clk_t = clock64()
 #define DH_DCLK(i) do { const uint64_t dh_clk_n = clock64(); if (threadIdx.x == 0) S.clk[i] += (uint32_t) (dh_clk_n - dh_clk_t); dh_clk_t = clock64(); } while (0)
 #elif defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#define DH_DCLK_BEGIN() asm volatile("; DH_DPHASE begin" ::: "memory")      // (tools/asm_census.sh: the decoder's regions in the assembly)
+#define DH_DCLK_BEGIN() asm volatile("; DH_DPHASE begin" ::: "memory")      // (tools/asm_census.py: the decoder's regions in the assembly)
 #define DH_DCLK(i) asm volatile("; DH_DPHASE " #i ::: "memory")
 #else
 #define DH_DCLK_BEGIN() ((void) 0)
@@ -692,7 +692,7 @@ DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSym
 // The SyncPhase search (dmr_phase.cpp:35-47) is unchanged.
 // =============================================================================================
 #if defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#define DH_DMARK(text) asm volatile("; DH_DMARK " text ::: "memory")      // (tools/asm_census.sh: the decoder's regions in the assembly)
+#define DH_DMARK(text) asm volatile("; DH_DMARK " text ::: "memory")      // (tools/asm_census.py: the decoder's regions in the assembly)
 #else
 #define DH_DMARK(text) ((void) 0)
 #endif

@@ -85,8 +85,9 @@ struct DhDspParams {
     // stopped; every other workgroup leaves at once.  split_force_fail = k > 0 (tests: DH_TAIL_SPLIT_FORCE_FAIL): the later parts
     // of the channels with ch % k == 1 give up without looking.
     uint32_t split_fixup, split_force_fail;
-    // DH_FLAG_KEEP_FILTERED | DH_FLAG_FAST_FIR on the wide filter at sps 10 (BASELINE configs[1] within its 1e-6): the error-bounded slicer
-    // also delivers the filtered samples of the push it has in LDS anyway -- filt_out[ch][t] for every new sample t -- in ONE launch
+    // DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH on the wide filter at sps 10 (without DH_FLAG_FAST_FIR): the error-bounded slicer also delivers
+    // the filtered samples of the push it has in LDS anyway -- filt_out[ch][t] for every new sample t -- in ONE launch.  They are the split-f16
+    // FIR's: within 2.5e-6 of the reference's (measured 1.0e-6), NOT the 1e-6 of DH_FLAG_FAST_FIR / BASELINE configs[1]
     float* filt_out; size_t filt_stride;
 };
 
@@ -1321,6 +1322,10 @@ DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint
     const uint32_t W = HI - LO;
     const uint32_t STRIDE = ((W > sps ? W : sps) + (uint32_t) NZ + 1u + 3u) & ~3u;
     const uint32_t A = (cap - 80u) / STRIDE;                          // areas in front of 64 result words + 16 words of slot table (A >= 2: area 0 is the window's)
+    // (per_round >= 1 -- or the loop below would never clear its bits -- needs sps + W <= DH_WAVE, W = round(2 sps / 3) - round(sps / 3)
+    // <= sps / 3 + 1, and two areas in `stage`: both hold for every sps up to DH_MAX_SPS with the window blocks of dh_dsp_xf_words().
+    // The staging areas run over S.sum, behind the filtered samples: the slicing phase has consumed it by the time this is called.)
+    static_assert(DH_MAX_SPS + DH_MAX_SPS / 3 + 2 <= DH_WAVE, "a candidate slot's samples and the evaluation window fit one round of lanes");
     uint32_t per_round = dh_min<uint32_t>(A - 1u, (DH_WAVE - W) / sps);
     if (per_round > 8u) per_round = 8u;
     float* scratch = stage + A * STRIDE;

@@ -170,9 +170,16 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
         // everything this workgroup stored is in the XCD's L2 before the flag is
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (threadIdx.x == 0)
-            __hip_atomic_store(flag_end, P.part_epoch | (part_end + 1u) << 24 | (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 28,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            // (a later part that has given up meanwhile set bit 26 with a fetch_or: a plain store would wipe it out and leave the part
+            // behind that one spinning through its whole patience -- compare-and-swap keeps the bit when the word is of this push)
+            const uint32_t mine = P.part_epoch | (part_end + 1u) << 24 | (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 28;
+            uint32_t seen = __hip_atomic_load(flag_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const uint32_t want = mine | (((seen & 0x00FFFFFFu) == P.part_epoch) ? (seen & (1u << 26)) : 0u);
+                if (__hip_atomic_compare_exchange_strong(flag_end, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            }
+        }
     }
 }
 
@@ -604,17 +611,23 @@ struct HipBackend {
         if (device < 0 || device >= 64) return false;
         std::lock_guard<std::mutex> lock(m);
         if (verdict[device]) return verdict[device] > 0;
-        verdict[device] = -1;
+        // (a verdict is only recorded once the placement has actually been looked at: an allocation, launch or copy that fails
+        // here leaves it unknown -- the split stays off for THIS engine, the next engine probes again.  The probe runs on a
+        // stream of its own: the caller's may be capturing, or hold work this must not wait for.)
         Scope on_device(device);
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { (void) hipGetLastError(); return false; }
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void) hipGetLastError(); return false; }
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { verdict[device] = -1; return false; }
         constexpr uint32_t N = 4096;
         uint32_t* d = nullptr; std::vector<uint32_t> h(N, 0xFFu);
-        if (hipMalloc((void**) &d, sizeof(uint32_t) * N) != hipSuccess) { (void) hipGetLastError(); return false; }
-        hipLaunchKernelGGL(k_xcc_probe, dim3(N), dim3(DH_WAVE), 0, stream, d);
-        const bool ran = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess &&
+        hipStream_t probe = nullptr;
+        if (hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return false; }
+        if (hipMalloc((void**) &d, sizeof(uint32_t) * N) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamDestroy(probe); return false; }
+        hipLaunchKernelGGL(k_xcc_probe, dim3(N), dim3(DH_WAVE), 0, probe, d);
+        const bool ran = hipGetLastError() == hipSuccess && hipStreamSynchronize(probe) == hipSuccess &&
                          hipMemcpy(h.data(), d, sizeof(uint32_t) * N, hipMemcpyDeviceToHost) == hipSuccess;
         (void) hipFree(d);
+        (void) hipStreamDestroy(probe);
         if (!ran) { (void) hipGetLastError(); return false; }
         bool ok = true;
         for (uint32_t i = 0; i < N && ok; i++) ok = h[i] < 8u && h[i] == h[i & 7u];

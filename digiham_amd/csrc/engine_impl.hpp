@@ -59,7 +59,9 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     // DH_FLAG_ONE_LAUNCH: the error-bounded slicer kernel filters on the matrix cores, decides every dibit as the reference does and
     // stores the filtered samples it holds in LDS -- one kernel instead of RRC tiles + slicer (8.1 instead of 12.1 bytes per sample
     // through HBM).  Its floats are the split-f16 FIR's: 1.1e-6 of max(|ref|, rms) measured, outside the 1e-6 of BASELINE configs[1].
-    L.fused_keep = (L.flags & DH_FLAG_KEEP_FILTERED) && (L.flags & DH_FLAG_ONE_LAUNCH) && L.rrc == DH_RRC_WIDE && L.demod != DH_DEMOD_NONE && L.sps == 10
+    // (DH_FLAG_FAST_FIR asks for floats within 1e-6: it takes precedence over DH_FLAG_ONE_LAUNCH, whose floats are only within 2.5e-6 -- the two-kernel
+    // FMA pair then runs, as without DH_FLAG_ONE_LAUNCH)
+    L.fused_keep = (L.flags & DH_FLAG_KEEP_FILTERED) && (L.flags & DH_FLAG_ONE_LAUNCH) && !(L.flags & DH_FLAG_FAST_FIR) && L.rrc == DH_RRC_WIDE && L.demod != DH_DEMOD_NONE && L.sps == 10
                    && !(L.flags & DH_FLAG_EXACT_FIR);
     L.fused = L.rrc != DH_RRC_NONE && L.rrc != DH_RRC_CUSTOM && L.demod != DH_DEMOD_NONE && (!(L.flags & DH_FLAG_KEEP_FILTERED) || L.fused_keep);
     // a symbol consumes at least sps-1 samples
@@ -258,7 +260,7 @@ struct Engine {
         last_n = (uint32_t) n;
         int rc = 0;
         const float* demod_in = d_in; size_t demod_stride = stride;
-        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0 && !L.fused_keep;      // (fused_keep: the error-bounded kernel, whose floats are within the fast path's tolerance)
+        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;                        // (never together with fused_keep: layout_for)
         bool decoder_done = false;
         be.timing_mark(0);
         if (L.rrc == DH_RRC_CUSTOM) {

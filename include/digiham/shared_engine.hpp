@@ -144,6 +144,9 @@ namespace Digiham {
                     // not leave rows marked pending, or the next tick would push the same staging rows a second time.
                     for (unsigned int s = 0; s < B; s++) slots[s].pending = 0;
                     pendingCount = 0;
+                    // Every slot that pushed is read, whatever another slot's read returns: the next tick overwrites the engine's buffers, so a
+                    // slot skipped here would have a hole in its byte stream.  The first failure is reported once all of them are through.
+                    int firstRc = DH_OK; const char* firstWhat = "";
                     for (unsigned int s = 0; s < B; s++) {
                         Slot& sl = slots[s];
                         const uint32_t pushed = counts[s];
@@ -156,16 +159,17 @@ namespace Digiham {
                                      : stage == SLICER ? dh_engine_read_symbols(engine.get(), s, sl.out.data() + old, &got)
                                      : dh_engine_read_frames(engine.get(), s, sl.out.data() + old, &got);
                         sl.out.resize(old + (rc == DH_OK ? got : 0) * w);
-                        check(rc, stage == RRC ? "dh_engine_read_filtered" : stage == SLICER ? "dh_engine_read_symbols" : "dh_engine_read_frames");
+                        if (rc != DH_OK && firstRc == DH_OK) { firstRc = rc; firstWhat = stage == RRC ? "dh_engine_read_filtered" : stage == SLICER ? "dh_engine_read_symbols" : "dh_engine_read_frames"; }
                         if (stage == DECODER && sl.wantEvents) {
                             const size_t eold = sl.events.size();
                             size_t ne = chunk / 20 + 64;
                             sl.events.resize(eold + ne);
                             const int rce = dh_engine_read_events(engine.get(), s, sl.events.data() + eold, &ne);
                             sl.events.resize(eold + (rce == DH_OK ? ne : 0));
-                            check(rce, "dh_engine_read_events");
+                            if (rce != DH_OK && firstRc == DH_OK) { firstRc = rce; firstWhat = "dh_engine_read_events"; }
                         }
                     }
+                    check(firstRc, firstWhat);
                 }
 
                 static std::mutex& registryMutex() { static std::mutex m; return m; }

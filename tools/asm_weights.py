@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/asm_weights.py <kernel.s> : vector-issue cycles per phase of a chain kernel, from its assembly (built with -DDH_ASM_MARKERS,
-tools/asm_census.sh) and the per-instruction issue costs measured on an MI355X (tools/microbench/valu_rate.hip, >= 2 wavefronts per
+tools/asm_census.py) and the per-instruction issue costs measured on an MI355X (tools/microbench/valu_rate.hip, >= 2 wavefronts per
 SIMD): 2.4 cycles for plain f32 add / sub / mul / fma and 32-bit integer add / logic / move, 4.2 for everything else on the vector
 ALU (packed f32, conversions, min / max, shifts, compares, selects, DPP, readlane), 8.2 for v_fma_mix*, 16 for v_mfma 16x16x32.
 Counts the instructions in TEXT order between the phase markers of the run loop (rare paths are laid out behind the loop, so the
