@@ -2474,6 +2474,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
     const uint32_t total = syms.nc + syms.nfresh;
     dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
     uint32_t pos = 0, phase = s[DS_PHASE];
+    uint32_t ahead_pos = 0xFFFFFFFFu, ahead_n = 0;                 // SACCH codewords decoded ahead: frames at ahead_pos + 192 j, j < ahead_n (S.colword)
 
     for (;;) {
         const uint32_t avail = total - pos;
@@ -2537,22 +2538,48 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
             const bool f0 = ((option >> 1) & 1u) == 0u, f1 = (option & 1u) == 0u;     // block i is a FACCH1
             // Viterbi inputs: codeword 0 = SACCH (60 -> 72 bits), codewords 1 / 2 = the two FACCH1 blocks (144 -> 192 bits);
             // every lane assembles one byte of an inflated codeword straight from the symbols
-            DH_FOR_LANES(lane) {
-                const int l = lane;
-                if (l < 9) {                                        // sacch.cpp:45-68
-                    uint32_t v = 0;
-                    for (int t = 0; t < 8; t++) {
-                        const int i = l * 8 + t;
-                        uint32_t x = 0;
-                        if ((i + 1) % 6 != 0) {
-                            const int o = i - (i + 1) / 6;          // position among the 60 transmitted bits
-                            const int inpos = (o % 12) * 5 + o / 12;
-                            x = dh_nxdn_bit(syms, pos, 8u, (uint32_t) inpos);
+            // SACCH codewords decoded AHEAD: a voice frame needs one Viterbi pass of 36 steps for its SACCH alone, on the sixteen lanes of
+            // one codeword -- the pass costs the same with four codewords in it.  When this frame's SACCH is not at hand, those of the next
+            // three frames on the grid (pos + 192 j; the descrambler restarts per frame, the decoder starts from state 0: nothing of it
+            // depends on the frames in between) ride along, and their five bytes wait in S.colword until their frame comes -- if it
+            // comes there: a sync loss, a TX_RELEASE or a frame without SACCH simply leaves them unused.
+            const bool sacch_cached = want_sacch && pos >= ahead_pos && pos - ahead_pos < 192u * ahead_n && (pos - ahead_pos) % 192u == 0u;
+            uint32_t sacch_slot = sacch_cached ? (pos - ahead_pos) / 192u : 0u;
+            if (want_sacch && !sacch_cached) {
+                const uint32_t nahead = (f0 || f1) ? 1u : dh_min<uint32_t>(4u, (avail - 1u) / 192u);     // (with a FACCH1 in the pass the other codeword groups are taken)
+                if (nahead > 1u) dh_view_ensure(syms, pos, 192u * nahead);
+                DH_FOR_LANES(lane) {
+                    const int j = lane / 9, l = lane - 9 * j;
+                    if ((uint32_t) j < nahead) {                    // sacch.cpp:45-68
+                        uint32_t v = 0;
+                        for (int t = 0; t < 8; t++) {
+                            const int i = l * 8 + t;
+                            uint32_t x = 0;
+                            if ((i + 1) % 6 != 0) {
+                                const int o = i - (i + 1) / 6;          // position among the 60 transmitted bits
+                                const int inpos = (o % 12) * 5 + o / 12;
+                                x = dh_nxdn_bit(syms, pos + 192u * (uint32_t) j, 8u, (uint32_t) inpos);
+                            }
+                            v = (v << 1) | x;
                         }
-                        v = (v << 1) | x;
+                        S.vit_in[j][l] = dh_vit_word(v);
                     }
-                    S.vit_in[0][l] = dh_vit_word(v);
-                } else if (l >= 16 && l < 64) {                     // facch1.cpp:39-61
+                }
+                if (nahead > 1u) {
+                    DH_BARRIER();
+                    const int sizes[4] = { 36, 36, nahead > 2u ? 36 : 0, nahead > 3u ? 36 : 0 };
+                    dh_viterbi_wave<true, false>(S, sizes);
+                    DH_FOR_LANES(lane) {
+                        if (lane < 8) S.colword[lane] = ((uint32_t) lane >> 1) < nahead ? reinterpret_cast<const uint32_t*>(S.vit_out[lane >> 1])[lane & 1] : 0u;
+                    }
+                    DH_BARRIER();
+                    ahead_pos = pos; ahead_n = nahead; sacch_slot = 0;
+                }
+            }
+            const bool sacch_from_cache = want_sacch && (sacch_cached || !(f0 || f1) && (avail - 1u) / 192u > 1u);
+            if (f0 || f1) DH_FOR_LANES(lane) {
+                const int l = lane;
+                if (l >= 16 && l < 64) {                            // facch1.cpp:39-61
                     const int blk = (l - 16) / 24, by = (l - 16) % 24;
                     uint32_t v = 0;
                     for (int t = 0; t < 8; t++) {
@@ -2570,12 +2597,13 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
             }
             DH_BARRIER();
             {
-                const int sizes[4] = { want_sacch ? 36 : 0, f0 ? 96 : 0, f1 ? 96 : 0, 0 };
+                const bool sacch_here = want_sacch && !sacch_from_cache;
+                const int sizes[4] = { sacch_here ? 36 : 0, f0 ? 96 : 0, f1 ? 96 : 0, 0 };
                 if (f0 || f1) dh_viterbi_wave<true, true>(S, sizes);           // 36 / 96 / 96 steps side by side
-                else if (want_sacch) dh_viterbi_wave<true, false>(S, sizes);   // voice frames: the SACCH alone
+                else if (sacch_here) dh_viterbi_wave<true, false>(S, sizes);   // (the last frame of a push: its SACCH alone)
             }
             if (want_sacch) {
-                const uint8_t* w = S.vit_out[0];
+                const uint8_t* w = sacch_from_cache ? reinterpret_cast<const uint8_t*>(S.colword + 2u * sacch_slot) : S.vit_out[0];
                 uint8_t sacch[5];
                 for (int i = 0; i < 5; i++) sacch[i] = (uint8_t) dh_uniform(w[i]);
                 if (dh_nxdn_crc_ok(sacch, 26, 6, 0x3Fu, 0x13u, sacch[3] & 0x3Fu)) {
