@@ -938,35 +938,40 @@ struct DhDmrMachine {
         s[DS_EMB_OFF0] = (uint32_t) eo0; s[DS_EMB_OFF1] = (uint32_t) eo1;
     }
 };
-#define DH_SEL2(a0, a1, i) ((i) ? (a1) : (a0))
-#define DH_SET2(a0, a1, i, v) do { const int dh_v_ = (v); if (i) (a1) = dh_v_; else (a0) = dh_v_; } while (0)
 
 // pass B: FramePhase::process (dmr_phase.cpp:65-254) for bursts 0 .. n - 1 of the chunk on their summaries.  Returns the number of
 // bursts consumed; `nflag` = bursts that got a flag word (one more when the last one sent the decoder back to its SyncPhase
 // without being consumed, :163-170, :201-204); `to_sync` says so.  `room` = bytes left in the output row.
-// (Two variations were measured and lost, profiles/r05_a_ab_logs.txt: the slot's members picked once and updated by selects
-// instead of branches executes MORE scalar instructions -- 358 instead of 339 per 1 000-sample run of the chain, decoder alone
-// 0.75 -> 0.84 ms; a short cut for data-sync bursts that find their slot's members already in the "data sync held" state -- a
-// fixed point of the machine -- costs the other bursts more than it saves: decoder alone 0.75 -> 0.88 ms.)
+// The machine crosses the burst loop in THREE scalar registers -- g = slot + 1 | (stability + 128) << 2 | sync count << 10 | active
+// slot + 1 << 13; x0 / x1 = sync type + 1 | slot sync count << 2 | superframe << 5 | embedded offset << 8 -- and is unpacked into
+// locals per burst.  (Measured, profiles/r05_a_ab_logs.txt: with its thirteen members as thirteen loop-carried registers every join
+// of the branches copies a dozen of them: 336 -> 323 scalar instructions per 1 000-sample run of the chain, decoder alone 0.75 ->
+// 0.67 ms.  Two other variations lost: the members of the slot picked once and updated by selects instead of branches -- MORE scalar
+// instructions, 0.84 ms -- and a short cut for data-sync bursts that find their slot in the "data sync held" state, a fixed
+// point of the machine: it costs the other bursts more than it saves, 0.88 ms.)
 DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LANE_STRUCT_REF(DhDmrLane, L), uint32_t n, uint32_t& room,
-                             uint32_t& nflag, bool& to_sync, bool& overflow) {
+                                    uint32_t& nflag, bool& to_sync, bool& overflow) {
     to_sync = false;
+    uint32_t g = (uint32_t) (M.slot + 1) | (uint32_t) (M.stab + 128) << 2 | (uint32_t) M.sync_count << 10 | (uint32_t) (M.active + 1) << 13;
+    uint32_t x0 = (uint32_t) (M.st0 + 1) | (uint32_t) M.ss0 << 2 | (uint32_t) M.sf0 << 5 | (uint32_t) M.eo0 << 8;
+    uint32_t x1 = (uint32_t) (M.st1 + 1) | (uint32_t) M.ss1 << 2 | (uint32_t) M.sf1 << 5 | (uint32_t) M.eo1 << 8;
+    const int filter = M.filter;
     uint32_t k = 0;
-    for (; k < n; k++) {
-        DH_DMARK("passB burst");
+    bool stop = false;
+    for (; k < n && !stop; k++) {
         const uint32_t sm = DH_LS_READ(L, summary, k);
         uint32_t fl = 0;
+        int slot = (int) (g & 3u) - 1, stab = (int) ((g >> 2) & 255u) - 128, sync_count = (int) ((g >> 10) & 7u), active = (int) ((g >> 13) & 3u) - 1;
         const int tact_slot = (int) ((sm >> DH_DS_TACT_SLOT_SHIFT) & 1u);
-        int slot = M.slot, stab = M.stab;
         const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
         if (DH_LIKELY(sm & DH_DS_HAS_TACT)) {
             if (DH_UNLIKELY(tact_slot != next)) {
                 if (stab < 5) {
                     stab = 0; slot = tact_slot;
                     const int other = slot ^ 1;
-                    DH_SET2(M.st0, M.st1, other, -1);
+                    if (other) x1 &= ~3u; else x0 &= ~3u;         // syncTypes[other] = -1
                     fl |= DH_DF_RESET_OTHER;                      // the OTHER slot, after a TACT slot switch (:80)
-                    if (M.active == other) M.active = -1;
+                    if (active == other) active = -1;
                 } else {
                     stab--;
                     if (slot != -1) slot = next;
@@ -979,85 +984,79 @@ DH_HD uint32_t dh_dmr_pass_b(DhDmrMachine& M, DhState& s, DhDecShared& S, DH_LAN
             if (stab-- < -100) stab = -100;
             slot = next;
         }
-        M.slot = slot; M.stab = stab;
-        if (DH_UNLIKELY(slot == -1)) { DH_LS_WRITE(L, flags, k, fl); continue; }
-        fl |= slot ? DH_DF_SLOT : 0u;
-
-        const int sync_type = (int) ((sm >> DH_DS_SYNC_SHIFT) & 3u);
-        bool lost = false;
-        if (sync_type > 0) {
-            if (++M.sync_count > 5) M.sync_count = 5;
-            int ssc = DH_SEL2(M.ss0, M.ss1, slot) + 1; if (ssc > 5) ssc = 5;
-            DH_SET2(M.ss0, M.ss1, slot, ssc);
-            if (DH_SEL2(M.st0, M.st1, slot) == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) fl |= DH_DF_SOFT;
-            DH_SET2(M.st0, M.st1, slot, sync_type);
-            fl |= DH_DF_SYNC;
-            DH_SET2(M.sf0, M.sf1, slot, 0);
-            DH_SET2(M.eo0, M.eo1, slot, 0);
-        } else if (DH_SEL2(M.st0, M.st1, slot) == DH_SYNCTYPE_VOICE && DH_SEL2(M.sf0, M.sf1, slot) < 5) {
-            DH_SET2(M.sf0, M.sf1, slot, DH_SEL2(M.sf0, M.sf1, slot) + 1);
-            if (sm & DH_DS_EMB_OK) {
-                if (++M.sync_count > 5) M.sync_count = 5;
-                int ssc = DH_SEL2(M.ss0, M.ss1, slot) + 1; if (ssc > 5) ssc = 5;
-                DH_SET2(M.ss0, M.ss1, slot, ssc);
-                fl |= DH_DF_EMB;
-                const uint32_t lcss = (sm >> DH_DS_LCSS_SHIFT) & 3u;
-                uint32_t off = (uint32_t) DH_SEL2(M.eo0, M.eo1, slot);
-                const uint32_t dbase = slot ? DS_EMB_DATA1 : DS_EMB_DATA0;
-                if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
-                if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
-                    if (off <= 3) { s[dbase + off] = DH_LS_READ(L, frag, k); off++; }
-                }
-                if (lcss == 2) {                                             // LCSS_STOP: pass C decodes what has been collected
-                    if (off >= 3) {
-                        const uint32_t d0 = s[dbase], d1 = s[dbase + 1u], d2 = s[dbase + 2u], d3 = s[dbase + 3u];
-                        DH_FOR_LANES(lane) {
-                            if (DH_IS_LANE0(lane)) { S.dmr.emb_words[k][0] = d0; S.dmr.emb_words[k][1] = d1; S.dmr.emb_words[k][2] = d2; S.dmr.emb_words[k][3] = d3; }
-                        }
-                        fl |= DH_DF_EMB_LC;
+        if (DH_LIKELY(slot != -1)) {
+            const uint32_t x = slot ? x1 : x0;
+            int st = (int) (x & 3u) - 1, ss = (int) ((x >> 2) & 7u), sf = (int) ((x >> 5) & 7u); uint32_t eo = (x >> 8) & 7u;
+            fl |= slot ? DH_DF_SLOT : 0u;
+            const int sync_type = (int) ((sm >> DH_DS_SYNC_SHIFT) & 3u);
+            bool lost = false;
+            if (sync_type > 0) {
+                if (++sync_count > 5) sync_count = 5;
+                if (++ss > 5) ss = 5;
+                if (st == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) fl |= DH_DF_SOFT;
+                st = sync_type;
+                fl |= DH_DF_SYNC;
+                sf = 0; eo = 0;
+            } else if (st == DH_SYNCTYPE_VOICE && sf < 5) {
+                sf++;
+                if (sm & DH_DS_EMB_OK) {
+                    if (++sync_count > 5) sync_count = 5;
+                    if (++ss > 5) ss = 5;
+                    fl |= DH_DF_EMB;
+                    const uint32_t lcss = (sm >> DH_DS_LCSS_SHIFT) & 3u;
+                    const uint32_t dbase = slot ? DS_EMB_DATA1 : DS_EMB_DATA0;
+                    if (lcss == 1) eo = 0;                                       // LCSS_START: reset, then collect
+                    if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
+                        if (eo <= 3) { s[dbase + eo] = DH_LS_READ(L, frag, k); eo++; }
                     }
-                    off = 0;
+                    if (lcss == 2) {                                             // LCSS_STOP: pass C decodes what has been collected
+                        if (eo >= 3) {
+                            const uint32_t d0 = s[dbase], d1 = s[dbase + 1u], d2 = s[dbase + 2u], d3 = s[dbase + 3u];
+                            DH_FOR_LANES(lane) {
+                                if (DH_IS_LANE0(lane)) { S.dmr.emb_words[k][0] = d0; S.dmr.emb_words[k][1] = d1; S.dmr.emb_words[k][2] = d2; S.dmr.emb_words[k][3] = d3; }
+                            }
+                            fl |= DH_DF_EMB_LC;
+                        }
+                        eo = 0;
+                    }
+                } else lost = true;
+            } else {
+                sf = 0; eo = 0;
+                lost = true;
+            }
+            if (lost) {
+                if (--ss < 0) {                                                  // dmr_phase.cpp:175-182 == :194-200
+                    ss = 0; st = -1;
+                    fl |= DH_DF_SLOT_RESET;
+                    if (active == slot) active = -1;
                 }
-                DH_SET2(M.eo0, M.eo1, slot, (int) off);
-            } else lost = true;
-        } else {
-            DH_SET2(M.sf0, M.sf1, slot, 0);
-            DH_SET2(M.eo0, M.eo1, slot, 0);
-            lost = true;
-        }
-        if (lost) {
-            int v = DH_SEL2(M.ss0, M.ss1, slot) - 1;                         // dmr_phase.cpp:175-182 == :194-200
-            if (v < 0) {
-                v = 0;
-                DH_SET2(M.st0, M.st1, slot, -1);
-                fl |= DH_DF_SLOT_RESET;
-                if (M.active == slot) M.active = -1;
+                if (DH_UNLIKELY(--sync_count < 0)) { fl |= DH_DF_META_RESET; to_sync = true; stop = true; sync_count = 0; }
             }
-            DH_SET2(M.ss0, M.ss1, slot, v);
-            if (DH_UNLIKELY(--M.sync_count < 0)) {
-                fl |= DH_DF_META_RESET;
-                DH_LS_WRITE(L, flags, k, fl);
-                to_sync = true; nflag = k + 1u;
-                return k;
+            if (DH_LIKELY(!stop)) {
+                if (st == DH_SYNCTYPE_VOICE) {
+                    if (((slot + 1) & filter) && (active == -1 || active == slot)) {
+                        active = slot;
+                        if (DH_UNLIKELY(room < 27u)) overflow = true; else { fl |= DH_DF_VOICE; room -= 27u; }
+                    }
+                } else {
+                    if (active == slot) active = -1;
+                    if (st == DH_SYNCTYPE_DATA) fl |= (sm >> (DH_DS_DFLAGS_SHIFT - 6)) & (DH_DF_SLOTTYPE | DH_DF_BPTC | DH_DF_BPTC_TAIL);      // (:246-300, from pass A)
+                    else fl |= DH_DF_SLOT_RESET2;
+                }
             }
+            const uint32_t xn = (uint32_t) (st + 1) | (uint32_t) ss << 2 | (uint32_t) sf << 5 | eo << 8;
+            if (slot) x1 = xn; else x0 = xn;
         }
-
-        const int st = DH_SEL2(M.st0, M.st1, slot);
-        if (st == DH_SYNCTYPE_VOICE) {
-            if (((slot + 1) & M.filter) && (M.active == -1 || M.active == slot)) {
-                M.active = slot;
-                if (DH_UNLIKELY(room < 27u)) overflow = true; else { fl |= DH_DF_VOICE; room -= 27u; }
-            }
-        } else {
-            if (M.active == slot) M.active = -1;
-            if (st == DH_SYNCTYPE_DATA) fl |= (sm >> (DH_DS_DFLAGS_SHIFT - 6)) & (DH_DF_SLOTTYPE | DH_DF_BPTC | DH_DF_BPTC_TAIL);      // (:246-300, from pass A)
-            else fl |= DH_DF_SLOT_RESET2;
-        }
+        g = (uint32_t) (slot + 1) | (uint32_t) (stab + 128) << 2 | (uint32_t) sync_count << 10 | (uint32_t) (active + 1) << 13;
         DH_LS_WRITE(L, flags, k, fl);
-        if (DH_UNLIKELY(overflow)) { k++; break; }
+        if (DH_UNLIKELY(overflow)) stop = true;
     }
+    // (k counts the bursts that got a flag word; the one that sent the decoder back to its SyncPhase is not consumed)
+    M.slot = (int) (g & 3u) - 1; M.stab = (int) ((g >> 2) & 255u) - 128; M.sync_count = (int) ((g >> 10) & 7u); M.active = (int) ((g >> 13) & 3u) - 1;
+    M.st0 = (int) (x0 & 3u) - 1; M.ss0 = (int) ((x0 >> 2) & 7u); M.sf0 = (int) ((x0 >> 5) & 7u); M.eo0 = (int) ((x0 >> 8) & 7u);
+    M.st1 = (int) (x1 & 3u) - 1; M.ss1 = (int) ((x1 >> 2) & 7u); M.sf1 = (int) ((x1 >> 5) & 7u); M.eo1 = (int) ((x1 >> 8) & 7u);
     nflag = k;
-    return k;
+    return to_sync ? k - 1u : k;
 }
 
 // exclusive prefix sum over the lanes of a small per-lane count (< 16), by votes
