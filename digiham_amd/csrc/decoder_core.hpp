@@ -109,21 +109,8 @@ DH_HD uint32_t dh_spread16(uint32_t x) {      // abcd -> 0a0b0c0d
     return x;
 }
 
-// cnt (<= 16) symbols starting at `start`, packed MSB-first 2 bits per symbol -- what the
-// reference's `(v << 2) | raw[i]` loops build (e.g. dmr_phase.cpp:123-132, :236-245)
-DH_HD uint32_t dh_syms_msb(const DhPlanes& p, int start, int cnt) {
-    const uint32_t hr = dh_brev32(dh_plane_range(p.h, start, cnt)) >> (32 - cnt);
-    const uint32_t lr = dh_brev32(dh_plane_range(p.l, start, cnt)) >> (32 - cnt);
-    return (dh_spread16(hr) << 1) | dh_spread16(lr);
-}
-
 DH_HD uint32_t dh_sym_at(const DhPlanes& p, int j) {
     return (uint32_t) ((((p.h[j >> 6] >> (j & 63)) & 1ull) << 1) | ((p.l[j >> 6] >> (j & 63)) & 1ull));
-}
-
-// Hamming distance between 24 (or 20) symbols at `start` and a pattern given as planes
-DH_HD int dh_sync_distance(const DhPlanes& p, int start, int cnt, uint32_t pat_h, uint32_t pat_l) {
-    return dh_popc32(dh_plane_range(p.h, start, cnt) ^ pat_h) + dh_popc32(dh_plane_range(p.l, start, cnt) ^ pat_l);
 }
 
 // sync words as planes (symbol i in bit i), derived from the ETSI TS 102 361-1 table 9.2 / YSF spec hex
@@ -210,9 +197,6 @@ struct DhDecCtx {
 };
 
 DH_HD void dh_emit(DhDecCtx& c, uint8_t type, uint8_t a, uint8_t b, const uint8_t* payload, int len) {
-#ifdef DH_SKIP_EVENTS                       // diagnostic builds (no events come out): what does writing them cost?
-    if (type != 255) return;
-#endif
     if (c.ev == nullptr) return;
     if (c.nev >= c.P->ev_cap) { c.overflow = true; return; }
     if (c.writer) {
@@ -237,9 +221,7 @@ DH_HD void dh_dmr_enter_frame_phase(DhState& s) {
 }
 
 // ------------------------------------------------------------------------------------------
-#ifndef DH_SYMWIN
 #define DH_SYMWIN 1024               // fresh symbols staged in LDS per refill (a DMR burst is 144, a YSF frame 480)
-#endif
 // Frame-parallel DMR (dh_dmr_channel): the bit planes of a chunk of up to 64 bursts (dibit j of the chunk: bit j & 31 of
 // word j >> 5; plane_h bit 1, plane_l bit 0 of the dibit), and a block that first holds the collected embedded-signalling words of
 // the bursts that close an embedded LC (pass B -> pass C), then the voice payloads on their way out (pass C).
@@ -283,9 +265,6 @@ struct DhDecShared {
         };
         DhDmrChunkShared dmr;                 // the frame-parallel DMR decoder's chunk (no Viterbi in DMR)
     };
-#ifdef DH_PHASE_CLOCKS
-    uint32_t clk[8];
-#endif
 };
 
 // virtual symbol stream of a channel for this push: carried symbols, then the fresh ones
@@ -337,58 +316,6 @@ DH_HD uint32_t dh_pack_msb(uint32_t h, uint32_t l, int cnt) {
     return (dh_spread16(dh_brev32(h) >> (32 - cnt)) << 1) | dh_spread16(dh_brev32(l) >> (32 - cnt));
 }
 
-// EmbeddedCollector::getLc (embedded.cpp:32-94) on the 16 collected bytes (4 big-endian words).
-// The 16 x 8 bit transpose and the seven Hamming(16,11) rows run one row per lane: row k collects bit 7-k of
-// every byte (a multiply gathers the four bytes of a word into a nibble).
-DH_HD bool dh_dmr_embedded_lc(const DhFecTables& T, const uint32_t* data, uint32_t off, DhDecShared& S, uint8_t* lc) {
-    if (off < 3) return false;
-    uint64_t okmask = 0;
-    DH_FOR_LANES(lane) {
-        bool ok = true;
-        if (lane < 8) {
-            uint32_t row = 0;
-            for (int j = 0; j < 4; j++) {
-                const uint32_t x = (data[j] >> (7 - lane)) & 0x01010101u;
-                row |= ((x * 0x10204080u) >> 28) << (12 - 4 * j);
-            }
-            if (lane < 7) ok = dh_block_decode_rows<5>(T.h1611, T.lut_h1611, row);
-            S.colword[lane] = row;
-        }
-        DH_BALLOT_ACC(okmask, ok, lane);
-    }
-    DH_BARRIER();
-    uint32_t m[8];
-    for (int k = 0; k < 8; k++) m[k] = dh_uniform(S.colword[k]);
-    DH_BARRIER();
-    if (okmask != ~0ull) return false;
-    uint32_t parity = 0;
-    for (int i = 0; i < 8; i++) parity ^= m[i];
-    if (parity != 0) return false;
-    // 72 LC bits: 11 from rows 0,1 and 10 from rows 2..6 (ETSI B.2.1); 5 checksum bits = bit 5 of rows 2..6
-    uint64_t acc = 0; int nacc = 0, ob = 0; uint32_t received = 0, sum = 0;
-    for (int r = 0; r < 7; r++) {
-        const int nb = r < 2 ? 11 : 10;
-        acc = (acc << nb) | ((m[r] >> (16 - nb)) & ((1u << nb) - 1)); nacc += nb;
-        while (nacc >= 8) { lc[ob] = (uint8_t) (acc >> (nacc - 8)); sum += lc[ob]; ob++; nacc -= 8; }
-        if (r >= 2) received |= ((m[r] >> 5) & 1u) << (4 - (r - 2));
-    }
-    return (sum % 31u) == received;
-}
-
-DH_HD void dh_dmr_slot_sync_lost(DhDecCtx& c, int slot) {     // dmr_phase.cpp:175-182 == :194-200
-    DhState& s = *c.st;
-    int v = (int) s[DS_SLOT_SYNC0 + slot] - 1;
-    if (v < 0) {
-        v = 0;
-        s[DS_SYNC_TYPE0 + slot] = (uint32_t) -1;
-        dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
-        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
-    }
-    s[DS_SLOT_SYNC0 + slot] = (uint32_t) v;
-}
-
-struct DhDmrFrameResult { bool to_sync; bool voice_out; bool want_bptc; uint8_t data_type; };
-
 // dmr_phase.cpp:18-33 on the sync slot given as bit masks (dibit 66+i in bit i)
 DH_HD int dh_dmr_sync_type_bits(uint32_t h, uint32_t l) {
     constexpr uint32_t SL = DH_DMR_SYNC_L, BD = DH_DMR_BS_DATA_H, BV = DH_DMR_BS_VOICE_H,
@@ -400,149 +327,6 @@ DH_HD int dh_dmr_sync_type_bits(uint32_t h, uint32_t l) {
     if (dh_popc32(h ^ MV) + dl <= 3) return DH_SYNCTYPE_VOICE;
     return -1;
 }
-
-// FramePhase::process up to (not including) the payload stores and the BPTC, which the caller runs
-// lane-parallel (dmr_phase.cpp:65-254).  The burst starts at symbol `pos` of the view.
-// Every field of the burst head comes out of ONE vote: lanes 0..23 present bit 1 of the 24 dibits of the sync
-// slot (66..89), lanes 24..47 their bit 0, lanes 48..54 bit 1 of the seven TACT dibits; sync correlation, EMB
-// and the embedded-signalling fragment are then scalar bit arithmetic on that 55-bit word.
-DH_HD DhDmrFrameResult dh_dmr_frame_head(DhDecCtx& c, const DhSymView& syms, uint32_t pos, DhDecShared& S) {
-    uint64_t headvote = 0;
-    DH_FOR_LANES(lane) {
-        const uint32_t l = (uint32_t) lane;
-        uint32_t at, sh;
-        if (l < 24) { at = 66u + l; sh = 1u; }
-        else if (l < 48) { at = 66u + (l - 24u); sh = 0u; }
-        else { const uint32_t i = l - 48u; at = 2u * i - (i > 3u ? 1u : 0u); sh = 1u; }   // dibits 0,2,4,6,7,9,11 (cach.cpp:7)
-        bool b = false;
-        if (l < 55u) b = ((dh_view_at(syms, pos + at) >> sh) & 1u) != 0;
-        DH_BALLOT_ACC(headvote, b, lane);
-    }
-    const uint32_t sync_h = (uint32_t) headvote & 0xFFFFFFu, sync_l = (uint32_t) (headvote >> 24) & 0xFFFFFFu;
-    const DhFecTables& T = *c.T;          // LDS copy (codes + small LUTs); Golay LUTs via c.P->T
-    DhState& s = *c.st;
-    DhDmrFrameResult R; R.to_sync = false; R.voice_out = false; R.want_bptc = false; R.data_type = 0;
-
-    // CACH: the 7 TACT bits, first one in the MSB (cach.cpp:7,11-19)
-    uint32_t tact = dh_brev32((uint32_t) (headvote >> 48) & 0x7Fu) >> 25;
-    const bool has_tact = dh_block_decode_wave<3>(T.h74, T.lut_h74, tact);
-    const int tact_slot = (int) ((tact >> 5) & 1u);
-
-    int slot = (int) s[DS_SLOT], stab = (int) s[DS_SLOT_STABILITY];
-    const int next = (slot ^ 1) & 0xFF;                      // unsigned char next = slot ^ 1  (:69)
-    if (DH_LIKELY(has_tact)) {
-        if (DH_UNLIKELY(tact_slot != next)) {
-            if (stab < 5) {
-                stab = 0; slot = tact_slot;
-                const int other = slot ^ 1;
-                s[DS_SYNC_TYPE0 + other] = (uint32_t) -1;
-                dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) other, 1, nullptr, 0);      // b = 1: the OTHER slot, after a TACT slot switch (:80)
-                if ((int) s[DS_ACTIVE_SLOT] == other) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
-            } else {
-                stab--;
-                if (slot != -1) slot = next;
-            }
-        } else {
-            if (++stab > 100) stab = 100;
-            slot = next;
-        }
-    } else if (slot != -1) {
-        if (stab-- < -100) stab = -100;
-        slot = next;
-    }
-    s[DS_SLOT] = (uint32_t) slot; s[DS_SLOT_STABILITY] = (uint32_t) stab;
-    if (DH_UNLIKELY(slot == -1)) return R;
-
-    int sync_count = (int) s[DS_SYNC_COUNT];
-    const int sync_type = dh_dmr_sync_type_bits(sync_h, sync_l);
-    if (sync_type > 0) {
-        if (++sync_count > 5) sync_count = 5;
-        int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
-        s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
-        uint8_t soft = ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && sync_type != DH_SYNCTYPE_VOICE) ? 1 : 0;
-        s[DS_SYNC_TYPE0 + slot] = (uint32_t) sync_type;
-        dh_emit(c, DH_EV_DMR_SYNC, (uint8_t) slot, (uint8_t) sync_type, &soft, 1);
-        s[DS_SUPERFRAME0 + slot] = 0;
-        s[DS_EMB_OFF0 + slot] = 0;
-    } else if ((int) s[DS_SYNC_TYPE0 + slot] == DH_SYNCTYPE_VOICE && s[DS_SUPERFRAME0 + slot] < 5) {
-        s[DS_SUPERFRAME0 + slot]++;
-        // EMB: dibits 66..69 and 86..89 (:123-132), QR(16,7)
-        uint32_t emb = (dh_pack_msb(sync_h & 15u, sync_l & 15u, 4) << 8) | dh_pack_msb(sync_h >> 20, sync_l >> 20, 4);
-        if (dh_block_decode_wave<9>(T.qr, T.lut_qr, emb)) {
-            if (++sync_count > 5) sync_count = 5;
-            int ssc = (int) s[DS_SLOT_SYNC0 + slot] + 1; if (ssc > 5) ssc = 5;
-            s[DS_SLOT_SYNC0 + slot] = (uint32_t) ssc;
-            const uint32_t frag = dh_pack_msb((sync_h >> 4) & 0xFFFFu, (sync_l >> 4) & 0xFFFFu, 16);   // 32 embedded bits (:141-145)
-            const uint32_t lcss = (emb >> 9) & 3u; uint8_t cc = (uint8_t) ((emb >> 12) & 15u);
-            dh_emit(c, DH_EV_DMR_EMB, (uint8_t) slot, (uint8_t) lcss, &cc, 1);
-            uint32_t off = s[DS_EMB_OFF0 + slot];
-            const uint32_t dbase = slot ? DS_EMB_DATA1 : DS_EMB_DATA0;
-            if (lcss == 1) off = 0;                                      // LCSS_START: reset, then collect
-            if (lcss != 0) {                                             // START / CONTINUATION / STOP collect
-                if (off <= 3) { s[dbase + off] = frag; off++; }
-            }
-            if (lcss == 2) {                                             // LCSS_STOP
-                uint8_t lc[9];
-                const uint32_t data[4] = { s[dbase], s[dbase + 1u], s[dbase + 2u], s[dbase + 3u] };
-                if (dh_dmr_embedded_lc(T, data, off, S, lc)) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 1, lc, 9);
-                off = 0;
-            }
-            s[DS_EMB_OFF0 + slot] = off;
-        } else {
-            dh_dmr_slot_sync_lost(c, slot);
-            if (DH_UNLIKELY(--sync_count < 0)) {
-                dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
-                R.to_sync = true; return R;
-            }
-        }
-    } else {
-        s[DS_SUPERFRAME0 + slot] = 0;
-        s[DS_EMB_OFF0 + slot] = 0;
-        dh_dmr_slot_sync_lost(c, slot);
-        if (DH_UNLIKELY(--sync_count < 0)) {
-            dh_emit(c, DH_EV_DMR_META_RESET, 0, 0, nullptr, 0);
-            R.to_sync = true; return R;
-        }
-    }
-    s[DS_SYNC_COUNT] = (uint32_t) sync_count;
-
-    const int st = (int) s[DS_SYNC_TYPE0 + slot];
-    if (st == DH_SYNCTYPE_VOICE) {
-        const int active = (int) s[DS_ACTIVE_SLOT];
-        if (((slot + 1) & (int) s[DS_SLOT_FILTER]) && (active == -1 || active == slot)) {
-            s[DS_ACTIVE_SLOT] = (uint32_t) slot;
-            if (c.P->out_cap - c.nout < 27) c.overflow = true; else R.voice_out = true;
-        }
-    } else {
-        if ((int) s[DS_ACTIVE_SLOT] == slot) s[DS_ACTIVE_SLOT] = (uint32_t) -1;
-        if (st == DH_SYNCTYPE_DATA) {
-            // slot type: dibits 61..65 and 90..94 (:236-245); lanes 0..9 vote their bit 1, lanes 10..19 their bit 0
-            uint64_t stvote = 0;
-            DH_FOR_LANES(lane) {
-                const uint32_t l = (uint32_t) lane, k = l < 10u ? l : l - 10u;
-                bool b = false;
-                if (l < 20u) b = ((dh_view_at(syms, pos + (k < 5u ? 61u + k : 85u + k)) >> (l < 10u ? 1u : 0u)) & 1u) != 0;
-                DH_BALLOT_ACC(stvote, b, lane);
-            }
-            const uint32_t st_h = (uint32_t) stvote & 0x3FFu, st_l = (uint32_t) (stvote >> 10) & 0x3FFu;
-            uint32_t slot_type = (dh_pack_msb(st_h & 31u, st_l & 31u, 5) << 10) | dh_pack_msb(st_h >> 5, st_l >> 5, 5);
-            if (dh_block_decode_wave<12>(T.g208, c.P->T->lut_g208, slot_type)) {
-                uint8_t cc = (uint8_t) ((slot_type >> 16) & 15u);
-                R.data_type = (uint8_t) ((slot_type >> 12) & 15u);
-                dh_emit(c, DH_EV_DMR_SLOTTYPE, (uint8_t) slot, R.data_type, &cc, 1);
-                if (R.data_type != 8) R.want_bptc = true;               // rate 3/4 data is not decoded (:251-253)
-            }
-        } else {
-            dh_emit(c, DH_EV_DMR_SLOT_RESET, (uint8_t) slot, 0, nullptr, 0);
-        }
-    }
-    return R;
-}
-
-// position (symbol index in the burst) of info dibit d (0..97) of a data burst (:256-269)
-DH_HD int dh_dmr_info_dibit_pos(int d) { return d < 49 ? 12 + d : 12 + 54 + 24 + 5 + (d - 49); }
-// position of voice payload dibit d (0..107) (:215-225)
-DH_HD int dh_dmr_voice_dibit_pos(int d) { return d < 54 ? 12 + d : 12 + 54 + 24 + (d - 54); }
 
 DH_HD void dh_load_planes(const DhSymView& syms, uint32_t pos, uint32_t total, DhPlanes& pl, int nwords) {
     for (int w = 0; w < DH_PLANE_WORDS; w++) { pl.h[w] = 0; pl.l[w] = 0; }
@@ -569,109 +353,6 @@ DH_HD void dh_stage_decoder_lds(const DhDecParams& P, DhDecShared& S, const uint
 }
 // the LDS copy viewed as a DhFecTables: valid for the codes and the small LUTs only (not lut_g208 / lut_g2412)
 DH_HD const DhFecTables& dh_lds_tables(const DhDecShared& S) { return *reinterpret_cast<const DhFecTables*>(S.fec_small); }
-
-// BPTC(196,96) of a data burst, columns on lanes (bptc_196_96.c:5-59 on the dibits of dmr_phase.cpp:256-269)
-#ifndef DH_BPTC_MODE
-#define DH_BPTC_MODE 2       // 0: 15 lanes gather 13 bits each from the bit planes; 1: four groups of 15 lanes, 4 bits each, from the planes; 2: the same from the symbol window (no planes)
-#endif
-DH_HD bool dh_dmr_bptc_wave(const DhFecTables& T, const DhPlanes& p, const DhSymView& syms, uint32_t pos0, uint8_t* out12) {
-    uint64_t okmask = 0;
-    DH_LANE_VALUE(uint32_t, colw);
-#if DH_BPTC_MODE == 0
-    // 15 columns on 15 lanes: gather through the interleave from the bit planes, Hamming(13,9); the corrected column words
-    // stay in registers
-    (void) syms; (void) pos0;
-    DH_FOR_LANES(lane) {
-        bool ok = true;
-        uint32_t w = 0;
-        if (lane < 15) {
-            const int d_lane = (lane * 181) % 196;
-            for (int k = 0; k < 13; k++) {
-                int r = ((k * 15 + 1) * 181) % 196 + d_lane;        // ((k*15 + lane + 1) * 181) mod 196
-                if (r >= 196) r -= 196;
-                const int pos = dh_dmr_info_dibit_pos(r >> 1);
-                const uint64_t* plane = (r & 1) ? p.l : p.h;        // even bit of a dibit = its bit1
-                w |= (uint32_t) ((plane[pos >> 6] >> (pos & 63)) & 1ull) << (12 - k);
-            }
-            ok = dh_block_decode_rows<4>(T.h139, T.lut_h139, w);
-        }
-        DH_BALLOT_ACC(okmask, ok, lane);
-        DH_LV(colw, lane) = w;
-    }
-#else
-    // The 13 x 15 gather costs one instruction per bit whatever the number of lanes that execute it: four groups of 15 lanes
-    // take rows k = g, g + 4, g + 8 (and 12) of their column -- four bits per lane instead of thirteen -- and the partial words
-    // meet in the lanes of the first group.  Source bit of (row k, column c): r = ((15 k + c + 1) 181) mod 196 (bptc_196_96.c:
-    // 8-16), which advances by 4 * 15 * 181 mod 196 = 80 from one of a lane's rows to the next.  With idle bursts on a quiet
-    // slot, a BPTC block per burst, this decoder was a tenth of the whole chain kernel's instructions.
-    DH_LANE_VALUE(uint32_t, part);
-    DH_FOR_LANES(lane) {
-        const uint32_t g = (uint32_t) lane >> 4, cidx = (uint32_t) lane & 15u;
-        uint32_t r = ((15u * g + cidx + 1u) * 181u) % 196u;
-        uint32_t w = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; q++) {
-            const uint32_t k = g + 4u * q;
-            const uint32_t d = r >> 1;
-            const uint32_t spos = d < 49u ? 12u + d : 46u + d;                      // dh_dmr_info_dibit_pos
-            uint32_t bit;
-            if (DH_BPTC_MODE == 2) bit = (dh_view_at(syms, pos0 + spos) >> (1u - (r & 1u))) & 1u;    // even bit of a dibit = its bit 1
-            else { const uint64_t* plane = (r & 1u) ? p.l : p.h; bit = (uint32_t) ((plane[spos >> 6] >> (spos & 63u)) & 1ull); }
-            if (cidx < 15u && k < 13u) w |= bit << (12u - k);
-            r += 80u; if (r >= 196u) r -= 196u;
-        }
-        DH_LV(part, lane) = w;
-    }
-    DH_FOR_LANES(lane) {
-        uint32_t w = DH_LV(part, lane) | DH_LV_DOWN(part, lane, 16) | DH_LV_DOWN(part, lane, 32) | DH_LV_DOWN(part, lane, 48);
-        bool ok = true;
-        if (lane < 15) ok = dh_block_decode_rows<4>(T.h139, T.lut_h139, w);
-        DH_BALLOT_ACC(okmask, ok, lane);
-        DH_LV(colw, lane) = w;
-    }
-#endif
-    if (okmask != ~0ull) return false;
-    // the 9 data rows: row i is bit 12-i of every column word -- one vote per row (column k in bit k, the row word wants
-    // it in bit 14-k); then the rows on 9 lanes for Hamming(15,11)
-    uint32_t rows[9];
-    for (int i = 0; i < 9; i++) {
-        uint64_t m = 0;
-        DH_FOR_LANES(lane) { DH_BALLOT_ACC(m, lane < 15 && ((DH_LV(colw, lane) >> (12 - i)) & 1u) != 0u, lane); }
-        rows[i] = dh_brev32((uint32_t) m) >> 17;
-    }
-    uint64_t rowok = 0;
-    DH_LANE_VALUE(uint32_t, roww);
-    DH_FOR_LANES(lane) {
-        bool ok = true;
-        uint32_t w = 0;
-        if (lane < 9) {
-            for (int i = 0; i < 9; i++) if (lane == i) w = rows[i];
-            ok = dh_block_decode_rows<4>(T.h1511, T.lut_h1511, w);
-        }
-        DH_BALLOT_ACC(rowok, ok, lane);
-        DH_LV(roww, lane) = w;
-    }
-    if (rowok != ~0ull) return false;
-    uint64_t acc = 0; int nacc = 0, ob = 0;
-    for (int r = 0; r < 9; r++) {
-        const int nb = r == 0 ? 8 : 11;
-        acc = (acc << nb) | ((DH_LV_READ(roww, r) >> 4) & ((1u << nb) - 1)); nacc += nb;
-        while (nacc >= 8) { out12[ob++] = (uint8_t) (acc >> (nacc - 8)); nacc -= 8; }
-    }
-    return true;
-}
-
-// One DMR channel, one push.
-#if defined(DH_PHASE_CLOCKS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#define DH_DCLK_BEGIN() uint64_t dh_clk_t = clock64()
-#define DH_DCLK(i) do { const uint64_t dh_clk_n = clock64(); if (threadIdx.x == 0) S.clk[i] += (uint32_t) (dh_clk_n - dh_clk_t); dh_clk_t = clock64(); } while (0)
-#elif defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#define DH_DCLK_BEGIN() asm volatile("; DH_DPHASE begin" ::: "memory")      // (tools/asm_census.py: the decoder's regions in the assembly)
-#define DH_DCLK(i) asm volatile("; DH_DPHASE " #i ::: "memory")
-#else
-#define DH_DCLK_BEGIN() ((void) 0)
-#define DH_DCLK(i) ((void) 0)
-#endif
 
 // =============================================================================================
 // Frame-parallel DMR decoder (round 5).
@@ -1287,121 +968,6 @@ DH_HD void dh_dmr_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     DH_BARRIER();
 }
 
-#if 0      // the burst-serial form of round 1-4 (kept until the frame-parallel one has been measured against it)
-DH_HD void dh_dmr_channel_serial(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
-#ifdef DH_PHASE_CLOCKS
-    DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
-#endif
-    DH_DCLK_BEGIN();
-    DhDecCtx c;
-    c.P = &P; c.T = &dh_lds_tables(S);
-    uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
-    DhState s; s.load(st_global);
-    c.st = &s;
-    c.out = P.out + (size_t) ch * P.out_stride;
-    c.ev = P.events ? P.events + (size_t) ch * P.ev_stride : nullptr;
-    c.nout = append ? P.out_count[ch] : 0u; c.nev = append && P.ev_count ? P.ev_count[ch] : 0u; c.overflow = false;      // (append: the second part of a split push, k_chain)
-    c.consumed = s[DS_CONSUMED];
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-    c.writer = threadIdx.x == 0;
-#else
-    c.writer = true;
-#endif
-    uint8_t* const carry_buf = P.carry + (size_t) ch * P.carry_stride;
-    DhSymView syms; syms.carry = S.carry; syms.nc = s[DS_CARRY]; syms.fresh = P.syms + (size_t) ch * P.sym_stride + sym_base;
-    syms.nfresh = P.sym_count[ch] - sym_base; syms.win = S.symwin; syms.wbase = 0; syms.wlen = 0;
-    const uint32_t total = syms.nc + syms.nfresh;
-    dh_stage_decoder_lds(P, S, carry_buf, syms.nc);
-    uint32_t pos = 0;
-    uint32_t phase = s[DS_PHASE];
-    DH_DCLK(0);
-
-    for (;;) {
-        const uint32_t avail = total - pos;
-        DhPlanes& pl = S.planes;
-        if (DH_UNLIKELY(phase == 0)) {                                 // SyncPhase (dmr_phase.cpp:35-47)
-            if (!(avail > 90)) break;
-            dh_view_ensure(syms, pos, 192);
-            dh_load_planes(syms, pos, total, pl, 3);
-            uint64_t hits = 0;
-            DH_FOR_LANES(lane) {
-                const bool valid = avail - (uint32_t) lane > 90 && avail > (uint32_t) lane;
-                const bool hit = valid && dh_dmr_sync_type(pl, 66 + lane) > 0;
-                DH_BALLOT_ACC(hits, hit, lane);
-            }
-            if (hits) {
-                const uint32_t l = (uint32_t) dh_ffs64(hits);
-                pos += l; c.consumed += l;
-                phase = 1; dh_dmr_enter_frame_phase(s);
-            } else {
-                const uint32_t adv = dh_min<uint32_t>(64u, avail - 90u);
-                pos += adv; c.consumed += adv;
-            }
-        } else {                                                       // FramePhase (dmr_phase.cpp:61-302)
-            if (!(avail > 144)) break;
-            dh_view_ensure(syms, pos, 192);
-            DH_DCLK(1);
-            const DhDmrFrameResult R = dh_dmr_frame_head(c, syms, pos, S);
-            DH_DCLK(2);
-            if (DH_UNLIKELY(R.to_sync)) { phase = 0; continue; }
-#ifdef DH_DMR_SKIP_VOICE
-            if (false) {        // timing experiment (results are wrong)
-#else
-            if (R.voice_out) {
-#endif
-                uint8_t* o = c.out + c.nout;
-                DH_FOR_LANES(lane) {
-                    if (lane < 27) {
-                        uint32_t v = 0;
-                        for (int i = 0; i < 4; i++) v = (v << 2) | dh_view_at(syms, pos + (uint32_t) dh_dmr_voice_dibit_pos(lane * 4 + i));
-                        o[lane] = (uint8_t) v;
-                    }
-                }
-                c.nout += 27;
-            }
-#ifdef DH_DMR_SKIP_BPTC
-            if (false) {        // timing experiment (results are wrong)
-#else
-            if (R.want_bptc) {
-#endif
-                if (DH_BPTC_MODE != 2) dh_load_planes(syms, pos, total, pl, 3);
-                uint8_t lc[12];
-                for (int i = 0; i < 12; i++) lc[i] = 0;
-                const int slot = (int) s[DS_SLOT];
-                if (dh_dmr_bptc_wave(dh_lds_tables(S), pl, syms, pos, lc)) {
-                    dh_emit(c, DH_EV_DMR_BPTC, (uint8_t) slot, R.data_type, lc, 12);
-                    if (R.data_type == 1) dh_emit(c, DH_EV_DMR_LC, (uint8_t) slot, 0, lc, 9);
-                    else if (R.data_type == 2 || R.data_type == 9) dh_emit(c, DH_EV_DMR_SOFT_RESET, (uint8_t) slot, R.data_type, nullptr, 0);
-                }
-            }
-            pos += 144; c.consumed += 144;
-            DH_DCLK(3);
-        }
-        if (c.overflow) break;
-    }
-
-    // carry the unread symbols to the front of the buffer
-    const uint32_t rem = total - pos;
-    dh_view_ensure(syms, pos, rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX);
-    DH_FOR_LANES(lane) {
-        // sources are LDS (carried part / window), destination is the global carry row: no overlap to worry about
-        for (uint32_t j = lane; j < rem && j < DH_SYM_CARRY_MAX; j += DH_WAVE) carry_buf[j] = (uint8_t) dh_view_at(syms, pos + j);
-        if (DH_IS_LANE0(lane)) {
-            P.out_count[ch] = c.nout;
-            if (P.ev_count) P.ev_count[ch] = c.nev;
-            if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
-        }
-    }
-    s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
-    s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
-#ifdef DH_PHASE_CLOCKS
-    for (int i = 0; i < 4; i++) s[28 + i] = (uint32_t) s[28 + i] + (dh_uniform(S.clk[i]) >> 6);
-#endif
-    s.store(st_global);
-    DH_BARRIER();
-}
-
-#endif
 
 // =============================================================================================
 // YSF
@@ -1471,288 +1037,20 @@ DH_HD void dh_viterbi_finish(DhDecShared& S, const int* sizes, int fin) {
 //     metric 0 and the message bits of that path, whatever its tie rules would do elsewhere;
 //   * the message comes straight out of the dibits: D^2 = (1 + D + D^2) G1 + (1 + D^2) G2, so u_t = h_(t+2) + h_(t+1) + h_t + l_(t+2) + l_t
 //     for t <= N - 3, and the last two bits from G1: u_t = h_t + u_(t-3) + u_(t-4).
-// Bit vectors of up to 192 bits in three 64-bit scalars per stream (lane l takes dibits l, l + 64, l + 128: one vote per word and bit):
-// ~150 scalar instructions per codeword instead of ~10 vector instructions per trellis step and lane group plus the trace-back.  Returns
-// false (nothing written) unless EVERY codeword of the pass is clean; tests/test_fec.py checks it against the reference compiled in
-// place for every start state, and that one flipped bit anywhere falls through to the full decoder.
-// MEASURED AND OFF (round 4, profiles/r04_b_ab_logs.txt): the batch kernel (dh_trellis) gains 28 % on clean words and loses nothing on
-// dirty ones, but the YSF pipe does not: the reference's own demodulator leaves about one wrong dibit per two hundred even on a noiseless
-// channel of the bench (57 % of the FICH codewords and half of the DCH ones arrive clean), a pass holds four codewords, and 8 % of the
-// passes qualify -- the checks cost the decoder more than the shortcut saves (YSF decoder 3.03 -> 3.17 ms, chain 7.10 -> 7.2).
-#ifndef DH_VIT_CLEAN
-#define DH_VIT_CLEAN 0
-#endif
-#ifndef DH_VIT_CLEAN_CALL
-#define DH_VIT_CLEAN_CALL 0
-#endif
-struct DhBits192 { uint64_t w0, w1, w2; };        // (three named words: nothing here may be indexed at run time -- a private array would live in scratch memory)
-DH_HD DhBits192 dh_b192_shl(const DhBits192& x, int k) {          // bit t of the result = bit t - k (0 < k < 64)
-    DhBits192 r;
-    r.w0 = x.w0 << k; r.w1 = (x.w1 << k) | (x.w0 >> (64 - k)); r.w2 = (x.w2 << k) | (x.w1 >> (64 - k));
-    return r;
-}
-DH_HD DhBits192 dh_b192_shr(const DhBits192& x, int k) {          // bit t of the result = bit t + k
-    DhBits192 r;
-    r.w0 = (x.w0 >> k) | (x.w1 << (64 - k)); r.w1 = (x.w1 >> k) | (x.w2 << (64 - k)); r.w2 = x.w2 >> k;
-    return r;
-}
-DH_HD DhBits192 dh_b192_xor(const DhBits192& a, const DhBits192& b) { DhBits192 r; r.w0 = a.w0 ^ b.w0; r.w1 = a.w1 ^ b.w1; r.w2 = a.w2 ^ b.w2; return r; }
-DH_HD DhBits192 dh_b192_and(const DhBits192& a, const DhBits192& b) { DhBits192 r; r.w0 = a.w0 & b.w0; r.w1 = a.w1 & b.w1; r.w2 = a.w2 & b.w2; return r; }
-DH_HD uint64_t dh_mask_below64(int n) { return n >= 64 ? ~0ull : n <= 0 ? 0ull : (~0ull >> (64 - n)); }
-DH_HD DhBits192 dh_b192_below(int n) { DhBits192 r; r.w0 = dh_mask_below64(n); r.w1 = dh_mask_below64(n - 64); r.w2 = dh_mask_below64(n - 128); return r; }      // bits 0 .. n - 1
-// the two bit streams of codeword g as votes: lane l takes dibits l, l + 64, l + 128 (one dibit per byte in S.vit_in[g])
-DH_HD void dh_clean_streams(const DhDecShared& S, int g, int N, DhBits192& H, DhBits192& L) {
-    const uint8_t* dib = reinterpret_cast<const uint8_t*>(S.vit_in[g]);
-    uint64_t h0 = 0, l0 = 0, h1 = 0, l1 = 0, h2 = 0, l2 = 0;
-    DH_FOR_LANES(lane) {
-        const uint32_t d = lane < N ? dib[lane] : 0u;
-        DH_BALLOT_ACC(h0, (d & 2u) != 0u, lane); DH_BALLOT_ACC(l0, (d & 1u) != 0u, lane);
-    }
-    if (N > 64) {
-        DH_FOR_LANES(lane) {
-            const uint32_t d = 64 + lane < N ? dib[64 + lane] : 0u;
-            DH_BALLOT_ACC(h1, (d & 2u) != 0u, lane); DH_BALLOT_ACC(l1, (d & 1u) != 0u, lane);
-        }
-    }
-    if (N > 128) {
-        DH_FOR_LANES(lane) {
-            const uint32_t d = 128 + lane < N ? dib[128 + lane] : 0u;
-            DH_BALLOT_ACC(h2, (d & 2u) != 0u, lane); DH_BALLOT_ACC(l2, (d & 1u) != 0u, lane);
-        }
-    }
-    H.w0 = h0; H.w1 = h1; H.w2 = h2; L.w0 = l0; L.w1 = l1; L.w2 = l2;
-}
-// one codeword: false when it is not exactly a codeword (or too short for the argument above); otherwise its message bits
-DH_HD bool dh_clean_one(const DhDecShared& S, int g, int N, DhBits192& U) {
-    U.w0 = U.w1 = U.w2 = 0;
-    if (N == 0) return true;
-    if (N < 8 || N > 192) return false;
-    DhBits192 H, L;
-    dh_clean_streams(S, g, N, H, L);
-    // syndrome, checks t = 4 .. N - 1
-    DhBits192 syn = dh_b192_xor(dh_b192_xor(dh_b192_xor(H, dh_b192_shl(H, 1)), dh_b192_xor(dh_b192_shl(H, 2), dh_b192_shl(H, 4))),
-                                dh_b192_xor(dh_b192_xor(L, dh_b192_shl(L, 3)), dh_b192_shl(L, 4)));
-    DhBits192 chk = dh_b192_below(N); chk.w0 &= ~0xFull;
-    syn = dh_b192_and(syn, chk);
-    if ((syn.w0 | syn.w1 | syn.w2) != 0) return false;
-    // message bits 0 .. N - 3 by the inverse, N - 2 and N - 1 from G1 on bits that are then known
-    U = dh_b192_and(dh_b192_xor(dh_b192_xor(dh_b192_xor(dh_b192_shr(H, 2), dh_b192_shr(H, 1)), H), dh_b192_xor(dh_b192_shr(L, 2), L)), dh_b192_below(N - 2));
-    const DhBits192 tailbits = dh_b192_xor(H, dh_b192_xor(dh_b192_shl(U, 3), dh_b192_shl(U, 4)));
-    DhBits192 last = dh_b192_xor(dh_b192_below(N), dh_b192_below(N - 2));        // bits N - 2, N - 1
-    const DhBits192 t2 = dh_b192_and(tailbits, last);
-    U.w0 |= t2.w0; U.w1 |= t2.w1; U.w2 |= t2.w2;
-    return true;
-}
-// message bytes MSB first (trellis.c:55-56, 84), zeros behind them, metric 0 -- written as soon as a codeword has passed: if a later
-// one of the pass does not, the full decoder overwrites all of them (keeping four messages in scalar registers until the end cost the
-// YSF decoder kernel its register budget)
-DH_HD void dh_clean_store(DhDecShared& S, int g, const DhBits192& U) {
-    DH_FOR_LANES(lane) {
-        if (lane < 24) {
-            const int q = lane >> 3;
-            const uint64_t w = q == 0 ? U.w0 : q == 1 ? U.w1 : U.w2;
-            S.vit_out[g][lane] = (uint8_t) (dh_brev32((uint32_t) ((w >> (8 * (lane & 7))) & 0xFFull)) >> 24);
-        }
-        if (lane == 24) S.vit_best_metric[g] = 0;
-    }
-}
-// (a REAL function on the device -- noinline: inlined into the YSF decoder, which already sits on its 128-register budget, the four checks
-// cost it 76 more bytes of spills and the decoder ran slower than without the shortcut; a call per Viterbi pass -- every other frame --
-// costs nothing, and the callee has its own register allocation.  Its arguments are values and one LDS pointer.)
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_VIT_CLEAN_CALL
-__device__ __attribute__((noinline)) bool dh_viterbi_clean_sizes(DhDecShared* Sp, int n0, int n1, int n2, int n3) {
-    DhDecShared& S = *Sp;
-#else
-DH_HD bool dh_viterbi_clean_sizes(DhDecShared* Sp, int n0, int n1, int n2, int n3) {
-    DhDecShared& S = *Sp;
-#endif
-#if DH_VIT_CLEAN
-    DhBits192 U;
-    if (!dh_clean_one(S, 0, n0, U)) return false;
-    if (n0 > 0) dh_clean_store(S, 0, U);
-    if (!dh_clean_one(S, 1, n1, U)) return false;
-    if (n1 > 0) dh_clean_store(S, 1, U);
-    if (!dh_clean_one(S, 2, n2, U)) return false;
-    if (n2 > 0) dh_clean_store(S, 2, U);
-    if (!dh_clean_one(S, 3, n3, U)) return false;
-    if (n3 > 0) dh_clean_store(S, 3, U);
-    DH_BARRIER();
-    return true;
-#else
-    (void) S; (void) n0; (void) n1; (void) n2; (void) n3;
-    return false;
-#endif
-}
-DH_HD bool dh_viterbi_clean(DhDecShared& S, const int* sizes /*[4]*/) { return dh_viterbi_clean_sizes(&S, sizes[0], sizes[1], sizes[2], sizes[3]); }      // (static indices only)      // (static indices only)
+// Used lane-locally, one codeword per lane, by the YSF decoder (dh_ysf_clean100 / dh_ysf_decode_ahead) and by the batch entry dh_trellis for
+// 100-dibit codewords; tests/test_fec.py checks it there against the reference compiled in place for every start state, and that one
+// flipped bit anywhere falls through to the full decoder.  (Round 4's wave-level form -- ~150 scalar instructions per codeword, all
+// four codewords of a pass clean or nothing -- lost in the YSF pipe: 8 % of the passes qualified.  profiles/r04_b_ab_logs.txt.)
 
-#ifndef DH_VIT_DPP
-#define DH_VIT_DPP 0                 // 1: the in-place forward pass below (measured: no gain alone, a loss inside the chain kernels -- DESIGN.md section 5)
-#endif
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_VIT_DPP
-// gfx950 forward pass, in-place form.  The 16 path metrics of a codeword never leave their lanes: the butterfly that takes
-// the states (2j, 2j+1) to (j, j+8) writes the new metrics over the old ones, so after t steps lane L (of the row of 16)
-// holds state ror4^t(L), and the two predecessors of the state a lane computes in step t are its own metric and the one of
-// lane L ^ (1 << (t & 3)): one DPP move inside the row (quad_perm / row_shr+row_shl / row_ror) instead of two ds_bpermute
-// round trips per step.  MEASURED AND NOT USED: the forward pass is 1.1 ms of the 7.7 ms YSF chain and 0.9 ms of the 11.1 ms
-// NXDN chain (-DDH_VIT_SKIP=0 builds), but it is bound by vector issue, not by LDS latency: this form has ten vector
-// instructions per step where the ds_bpermute form has six (the LDS pipe did the exchange for free), and the YSF decoder
-// alone stays at 3.15 ms, the YSF chain goes 7.7 -> 8.3 ms, NXDN 11.1 -> 11.5 (profiles/r03_d_ab_logs.txt).  Same decisions as the reference's decoder
-// (src/ysf_decoder/trellis.c:32-109, src/nxdn_decoder/trellis.cpp:35-60): uint8 metrics that wrap, the k = 0 predecessor
-// wins ties.  Which of the two is "own" depends on bit (t & 3) of the lane number (HI lanes hold the odd predecessor), so
-//   take_other = other < own + hi        (one v_subb_co_u32: the borrow, with the HI lanes as carry-in)
-//   decision k = take_other ^ hi         (a scalar XOR of the vote with a constant mask)
-// Branch metrics: the expected dibits of a lane's two transitions in the four rotation phases sit in the four bytes of
-// two registers; XOR with the input word (one dibit per byte, four steps) and a 2-bit population count per byte give the
-// metrics of four steps at once.  Decisions are stored per LANE (bit 16 g + L of word t), and the trace-back walks lanes:
-// the predecessor of lane L in step t is L with bit (t & 3) replaced by the decision, and the decoded bit of step t is the
-// bit that gets replaced -- two dependent operations per step where the state-indexed form needed four.
-__device__ __forceinline__ uint32_t dh_ror4(uint32_t x, uint32_t r) { r &= 3u; return ((x >> r) | (x << (4u - r))) & 15u; }
-template <int Q> __device__ __forceinline__ uint32_t dh_row_xor_lane(uint32_t v) {
-    const int x = (int) v;
-    if constexpr (Q == 0) return (uint32_t) __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);            // quad_perm:[1,0,3,2]
-    else if constexpr (Q == 1) return (uint32_t) __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);       // quad_perm:[2,3,0,1]
-    else if constexpr (Q == 2) {
-        const int up = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xA, false);                                // row_shr:4 into lanes 4-7, 12-15
-        return (uint32_t) __builtin_amdgcn_update_dpp(up, x, 0x104, 0xF, 0x5, false);                            // row_shl:4 into lanes 0-3, 8-11
-    } else return (uint32_t) __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);                          // row_ror:8
-}
-// the lanes whose number has bit Q set
-template <int Q> __device__ __forceinline__ constexpr uint64_t dh_hi_lanes() {
-    return Q == 0 ? 0xAAAAAAAAAAAAAAAAull : Q == 1 ? 0xCCCCCCCCCCCCCCCCull : Q == 2 ? 0xF0F0F0F0F0F0F0F0ull : 0xFF00FF00FF00FF00ull;
-}
-// one trellis step: C = step & 63 = the lane of the decision registers that takes this step's vote, Q = C & 3 = which lane
-// bit pairs the butterfly; GENERIC: some lanes may be held (`active`, ragged codewords) or restricted to their k = 0 predecessor
-// (`allow`, the first four steps of the NXDN flavour)
-template <int C, bool GENERIC>
-__device__ __forceinline__ void dh_vit_step(uint32_t& m, uint32_t pc_own, uint32_t pc_oth, uint32_t& dlo, uint32_t& dhi,
-                                            uint64_t allow, uint64_t active) {
-    constexpr int Q = C & 3;
-    const uint32_t oth = dh_row_xor_lane<Q>(m);
-    const uint32_t c_own = (m + ((pc_own >> (8 * Q)) & 0xFFu)) & 0xFFu;
-    const uint32_t c_oth = (oth + ((pc_oth >> (8 * Q)) & 0xFFu)) & 0xFFu;
-    uint64_t take_oth; uint32_t diff;
-    const uint64_t hi = dh_hi_lanes<Q>();
-    asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(diff), "=s"(take_oth) : "v"(c_oth), "v"(c_own), "s"(hi));
-    uint64_t dec = take_oth ^ hi;                                                   // k = 1 predecessor taken
-    if (GENERIC) {
-        dec &= allow & active;
-        const uint64_t sel_oth = dec ^ hi;
-        uint32_t nm;
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nm) : "v"(c_own), "v"(c_oth), "s"(sel_oth));
-        { uint32_t keep_ = m; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(m) : "v"(keep_), "v"(nm), "s"(active)); }
-    } else {
-        m = c_oth < c_own ? c_oth : c_own;
-    }
-    // (v_writelane takes one scalar register and an inline constant as the lane: C is a template parameter for that)
-    asm("v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(dlo), "+v"(dhi) : "s"((uint32_t) dec), "s"((uint32_t) (dec >> 32)), "n"(C));
-}
-template <bool NXDN = false, bool RAGGED = NXDN>
-__device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
-    if (!NXDN && dh_viterbi_clean(S, sizes)) return;
-    const int lane = (int) threadIdx.x, g = lane >> 4;
-    const uint32_t L = (uint32_t) lane & 15u;
-    int steps = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) steps = sizes[q] > steps ? sizes[q] : steps;
-#ifdef DH_VIT_SKIP
-    steps = DH_VIT_SKIP;            // timing experiment: forward pass cut short (results are wrong)
-#endif
-    const int mysize = g == 0 ? sizes[0] : g == 1 ? sizes[1] : g == 2 ? sizes[2] : sizes[3];   // static indices only
-    // expected dibits of this lane's two transitions in the four phases, phase b in byte b
-    uint32_t t_own = 0, t_oth = 0;
-    uint64_t allow4[4];
-#pragma unroll
-    for (uint32_t b = 0; b < 4; b++) {
-        const uint32_t sig = dh_ror4(L, b), n = dh_ror4(L, b + 1u), outbit = n >> 3;       // own predecessor, new state
-        t_own |= dh_trellis_out(sig, outbit) << (8 * b);
-        t_oth |= dh_trellis_out(sig ^ 1u, outbit) << (8 * b);
-        // NXDN: in the first four steps a state that overlaps the shifting `blocked` mask only looks at its k = 0 predecessor
-        allow4[b] = NXDN ? __builtin_amdgcn_ballot_w64((n & ((0xFu << b) & 0xFu)) == 0u) : ~0ull;
-    }
-    const uint32_t* inw = S.vit_in[g];                  // one dibit per byte, four steps per word
-    uint32_t m = 0;
-    for (int blk = 0; blk * 64 < steps; blk++) {
-        // decisions of 64 steps collect in one register pair, step (64 blk + c) in lane c, written with v_writelane
-        uint32_t dlo = 0, dhi = 0;
-#define DH_VIT_WORD(WQ) \
-        if (blk * 64 + (WQ) * 4 < steps) { \
-            const uint32_t w = inw[blk * 16 + (WQ)]; \
-            const uint32_t x_own = w ^ t_own, x_oth = w ^ t_oth; \
-            const uint32_t pc_own = (x_own & 0x01010101u) + ((x_own >> 1) & 0x01010101u); \
-            const uint32_t pc_oth = (x_oth & 0x01010101u) + ((x_oth >> 1) & 0x01010101u); \
-            /* (codeword lengths are multiples of four on every ragged path: `active` is taken once per word) */ \
-            const uint64_t active = RAGGED ? __builtin_amdgcn_ballot_w64(blk * 64 + (WQ) * 4 < mysize) : ~0ull; \
-            const int pos0 = blk * 64 + (WQ) * 4; \
-            if (RAGGED || (NXDN && (WQ) == 0 && blk == 0)) { \
-                const bool first = NXDN && (WQ) == 0 && blk == 0; \
-                if (pos0 + 0 < steps) dh_vit_step<(WQ) * 4 + 0, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[0] : ~0ull, active); \
-                if (pos0 + 1 < steps) dh_vit_step<(WQ) * 4 + 1, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[1] : ~0ull, active); \
-                if (pos0 + 2 < steps) dh_vit_step<(WQ) * 4 + 2, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[2] : ~0ull, active); \
-                if (pos0 + 3 < steps) dh_vit_step<(WQ) * 4 + 3, true>(m, pc_own, pc_oth, dlo, dhi, first ? allow4[3] : ~0ull, active); \
-            } else { \
-                if (pos0 + 0 < steps) dh_vit_step<(WQ) * 4 + 0, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
-                if (pos0 + 1 < steps) dh_vit_step<(WQ) * 4 + 1, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
-                if (pos0 + 2 < steps) dh_vit_step<(WQ) * 4 + 2, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
-                if (pos0 + 3 < steps) dh_vit_step<(WQ) * 4 + 3, false>(m, pc_own, pc_oth, dlo, dhi, ~0ull, ~0ull); \
-            } \
-        }
-        DH_VIT_WORD(0) DH_VIT_WORD(1) DH_VIT_WORD(2) DH_VIT_WORD(3) DH_VIT_WORD(4) DH_VIT_WORD(5) DH_VIT_WORD(6) DH_VIT_WORD(7)
-        DH_VIT_WORD(8) DH_VIT_WORD(9) DH_VIT_WORD(10) DH_VIT_WORD(11) DH_VIT_WORD(12) DH_VIT_WORD(13) DH_VIT_WORD(14) DH_VIT_WORD(15)
-#undef DH_VIT_WORD
-        S.vit_dec[blk * 64 + lane] = (uint64_t) dhi << 32 | dlo;
-    }
-    S.vit_metric[0][lane] = m;
-    __syncthreads();
-    // best end state of every codeword (lowest STATE index among the minimum metric, trellis.c:94-98; state i sits in lane
-    // rol4^size(i)) and the trace-back over lanes
-    if ((lane & 15) == 0) {
-        const int size = mysize;
-        if (size > 0) {
-            const uint32_t r = (uint32_t) size & 3u;
-            uint32_t bestl = 0, bm = S.vit_metric[0][g * 16];
-            for (uint32_t i = 1; i < 16; i++) {
-                const uint32_t li = dh_ror4(i, 4u - r);
-                const uint32_t mi = S.vit_metric[0][g * 16 + li];
-                if (mi < bm) { bm = mi; bestl = li; }
-            }
-            S.vit_best_metric[g] = (uint8_t) bm;
-            const int nbytes = (size + 7) >> 3;
-            for (int b = nbytes; b < 24; b++) S.vit_out[g][b] = 0;
-            uint32_t Lc = bestl;
-            const uint16_t* dec16 = reinterpret_cast<const uint16_t*>(S.vit_dec) + g;
-            for (int b = nbytes - 1; b >= 0; b--) {
-                uint32_t d[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) d[j] = (uint32_t) dec16[4 * ((b * 8 + j) < 192 ? (b * 8 + j) : 191)] << (j & 3);
-                // steps 8b+7 .. 8b+4, then 8b+3 .. 8b: the four decoded bits of a group are the four bits of the lane number
-                // the group starts from (bit j & 3 belongs to step j and is replaced by that step's decision)
-                const int va = size - (b * 8 + 4), vb = size - b * 8;
-                const uint32_t mask_a = va >= 4 ? 15u : va <= 0 ? 0u : (1u << va) - 1u, mask_b = vb >= 4 ? 15u : (1u << vb) - 1u;
-                const uint32_t la = Lc & mask_a;
-#pragma unroll
-                for (int j = 7; j >= 4; j--)
-                    if (b * 8 + j < size) Lc = (Lc & ~(1u << (j & 3))) | ((d[j] >> Lc) & (1u << (j & 3)));
-                const uint32_t lb = Lc & mask_b;
-#pragma unroll
-                for (int j = 3; j >= 0; j--)
-                    if (b * 8 + j < size) Lc = (Lc & ~(1u << (j & 3))) | ((d[j] >> Lc) & (1u << (j & 3)));
-                // byte bit 7 - j = decoded bit of step 8b + j: the bit reversal of (la << 4 | lb) ... la bit 3 = step 7 -> bit 0
-                S.vit_out[g][b] = (uint8_t) (dh_brev32((la << 4) | lb) >> 24);
-            }
-        }
-    }
-    DH_BARRIER();
-}
-#elif DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // One trellis step of the forward pass below; C = step & 63 = the lane of the decision registers that takes its vote, an
 // IMMEDIATE of v_writelane (the steps are spelled out, not looped over: as a loop variable the lane went through m0 --
 // three scalar moves per step and 64 scalar registers of constants, which the decoders then spilled).  The vote comes
 // straight out of a vector compare: v_writelane may not read a scalar register a vector instruction wrote less than four
 // wait states ago -- without the s_nop the YSF decoder ran 2.2 times SLOWER (3.1 -> 7.0 ms), with it 3 % faster than the
 // m0 form (profiles/r03_d_ab_logs.txt); inline asm gets no hazard handling from the compiler.
-#ifndef DH_VIT_IMM_NOP
 #define DH_VIT_IMM_NOP "s_nop 3\n\t"
-#endif
 template <bool NXDN, bool RAGGED, int C>
 __device__ __forceinline__ void dh_vitb_step(uint32_t& m, uint32_t h0, uint32_t h1, int src0, int src1, uint32_t i, int blk, int steps, int mysize,
                                              uint32_t& dlo, uint32_t& dhi) {
@@ -1786,14 +1084,10 @@ __device__ __forceinline__ void dh_vitb_step(uint32_t& m, uint32_t h0, uint32_t 
 // ignored.
 template <bool NXDN = false, bool RAGGED = NXDN>
 __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes) {
-    if (!NXDN && dh_viterbi_clean(S, sizes)) return;
     const int lane = (int) threadIdx.x, g = lane >> 4, i = lane & 15;
     int steps = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) steps = sizes[q] > steps ? sizes[q] : steps;
-#ifdef DH_VIT_SKIP
-    steps = DH_VIT_SKIP;            // timing experiment: forward pass cut short (results are wrong)
-#endif
     const int mysize = g == 0 ? sizes[0] : g == 1 ? sizes[1] : g == 2 ? sizes[2] : sizes[3];   // static indices only
     const uint32_t outbit = (uint32_t) i >> 3;
     const uint32_t p0 = ((uint32_t) i << 1) & 0xEu, p1 = p0 | 1u;
@@ -1830,7 +1124,6 @@ __device__ __forceinline__ void dh_viterbi_wave(DhDecShared& S, const int* sizes
 // plain statement of the same recursion for the CPU harness: metrics exchanged through the LDS arrays
 template <bool NXDN = false, bool RAGGED = NXDN>
 inline void dh_viterbi_wave(DhDecShared& S, const int* sizes /*[4]*/) {
-    if (!NXDN && dh_viterbi_clean(S, sizes)) return;
     int steps = 0;
     for (int g = 0; g < 4; g++) steps = sizes[g] > steps ? sizes[g] : steps;
     DH_FOR_LANES(lane) { S.vit_metric[0][lane] = 0; }
@@ -1894,37 +1187,6 @@ constexpr bool dh_v2_check() {
            dh_v2_forward(36) == 2 && dh_v2_forward(48) == 38;
 }
 static_assert(dh_v2_check(), "v2 voice mapping closed form");
-
-// whitened/interleaved VCH bit k (0..103) of the 52-dibit voice block at symbol `base`
-DH_HD uint32_t dh_ysf_vch_bit(const DhPlanes& p, int base, int k) {
-    const int t = (k * 4) % 104 + (k * 4) / 104;           // 26 x 4 de-interleave (ysf_phase.cpp:188-197)
-    const int pos = base + (t >> 1);
-    const uint64_t* plane = (t & 1) ? p.l : p.h;
-    constexpr uint64_t PN0 = dh_pn9_word(0), PN1 = dh_pn9_word(64);
-    const uint64_t pn = k < 64 ? PN0 : PN1;
-    const uint32_t wb = (uint32_t) ((pn >> (k & 63)) & 1ull);
-    return (uint32_t) ((plane[pos >> 6] >> (pos & 63)) & 1ull) ^ wb;
-}
-
-// one output byte (0..6) of decodeV2VoicePayload (ysf_phase.cpp:180-256)
-DH_HD uint8_t dh_ysf_v2_voice_byte(const DhPlanes& p, int base, int byte) {
-    uint32_t v = 0;
-    for (int b = 0; b < 8; b++) {
-        const int ob = byte * 8 + b;
-        uint32_t bit = 0;
-        if (ob < 49) {
-            const int ib = dh_v2_inverse(ob);          // the voice bit the mapping sends to output bit `ob`
-            if (ib < 27) {
-                const uint32_t t = dh_ysf_vch_bit(p, base, 3 * ib) + dh_ysf_vch_bit(p, base, 3 * ib + 1) + dh_ysf_vch_bit(p, base, 3 * ib + 2);
-                bit = t >= 2 ? 1u : 0u;                     // tribit majority (ysf_phase.hpp:45)
-            } else {
-                bit = dh_ysf_vch_bit(p, base, 81 + (ib - 27));
-            }
-        }
-        v = (v << 1) | bit;
-    }
-    return (uint8_t) v;
-}
 
 // decodeV2VoicePayload (ysf_phase.cpp:180-256) of one 52-dibit voice block, lane-local, on the block's two bit masks (dibit j of the
 // block in bit j of `hx` / `lx`).  The 26 x 4 de-interleave (:188-197) sends de[26 r + c] = bit (r & 1 ? 0 : 1) of dibit 2 c + (r >> 1):
@@ -2188,10 +1450,6 @@ DH_HD void dh_ysf_decode_ahead(const DhDecParams& P, const DhFecTables& T, const
 
 // One YSF channel, one push.
 DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
-#ifdef DH_PHASE_CLOCKS
-    DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
-#endif
-    DH_DCLK_BEGIN();
     const DhFecTables& T = dh_lds_tables(S);
     DhDecCtx c;
     c.P = &P; c.T = &T;
@@ -2239,7 +1497,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         }
         // FramePhase (ysf_phase.cpp:41-172)
         if (!(avail > 480)) break;
-        DH_DCLK(0);
         if (!(ahead_pos == pos && ahead_i < ahead_n)) {
             // the codewords of every frame of the push that is complete (up to DH_YSF_CHUNK), on the grid this frame starts
             const uint32_t n = dh_min<uint32_t>((avail - 1u) / 480u, (uint32_t) DH_YSF_CHUNK);
@@ -2248,7 +1505,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         }
         dh_view_ensure(syms, pos, 512);
         dh_load_planes(syms, pos, total, pl, 8);
-        DH_DCLK(1);
         int sync_count = (int) s[DS_SYNC_COUNT];
         if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
         else if (DH_UNLIKELY(--sync_count < 0)) {
@@ -2259,7 +1515,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         const uint32_t cw_fich = dh_uniform(S.ysf.res[ahead_i][0][0]), cw_flags = dh_uniform(S.ysf.res[ahead_i][0][1]);
         const uint8_t* const cw_dch = reinterpret_cast<const uint8_t*>(S.ysf.res[ahead_i][1]);
         ahead_i++; ahead_pos = pos + 480u;
-        DH_DCLK(3);
 
         // FICH (fich.cpp:24-49): decoded and checked ahead
         const uint32_t fich = (cw_flags & 1u) ? cw_fich : 0u; const bool fresh = (cw_flags & 1u) != 0u;
@@ -2269,7 +1524,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             dh_emit(c, DH_EV_YSF_FICH, 0, 0, be, 4);
         }
 
-        DH_DCLK(4);
         if (s[DS_HAS_FICH]) {
             const uint32_t rf = s[DS_FICH];
             const uint32_t frame_type = (rf >> 30) & 3u, data_type = (rf >> 8) & 3u;
@@ -2292,7 +1546,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                     if (P.out_cap - c.nout < 40) c.overflow = true;
                     else {
                         uint8_t* o = c.out + c.nout;
-#ifndef DH_VD2_SKIP                         // (diagnostic builds leave the voice payload out: results are wrong)
                         DH_FOR_LANES(lane) {
                             // one block per lane (five of them): mode byte + seven voice bytes
                             const int blk = lane < 5 ? lane : 0, base = 120 + 20 + blk * 72;
@@ -2307,7 +1560,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                                 ob[5] = (uint8_t) v1; ob[6] = (uint8_t) (v1 >> 8); ob[7] = (uint8_t) (v1 >> 16);
                             }
                         }
-#endif
                         c.nout += 40;
                     }
                     if (fresh) {                                                    // decodeV2DataChannel (:258-269)
@@ -2375,7 +1627,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             }
         }
         DH_BARRIER();
-        DH_DCLK(5);
         pos += 480; c.consumed += 480;
         if (c.overflow) break;
     }
@@ -2393,9 +1644,6 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     }
     s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
     s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
-#ifdef DH_PHASE_CLOCKS
-    for (int i = 0; i < 4; i++) s[28 + i] = (uint32_t) s[28 + i] + (dh_uniform(S.clk[2 * i]) >> 6) + ((dh_uniform(S.clk[2 * i + 1]) >> 6) << 16);
-#endif
     s.store(st_global);
     DH_BARRIER();
 }
@@ -3105,10 +2353,6 @@ DH_HD bool dh_dstar_is_terminator(uint32_t d0, uint32_t d1) {
 #define DH_DSTAR_BATCH 5          // data frames handled per round on the fast path (5 x 96 + 24 bits <= 512)
 
 DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uint32_t sym_base = 0, bool append = false) {
-#ifdef DH_PHASE_CLOCKS
-    DH_FOR_LANES(lane) { if (lane < 8) S.clk[lane] = 0; }
-#endif
-    DH_DCLK_BEGIN();
     DhDecCtx c;
     c.P = &P; c.T = &dh_lds_tables(S);
     uint32_t* const st_global = P.state + (size_t) ch * P.state_stride;
@@ -3134,7 +2378,6 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
     DH_BARRIER();
     uint32_t pos = 0, phase = s[DS_PHASE];
     DhBits128 bits;
-    DH_DCLK(0);
 
     for (;;) {
         const uint32_t avail = total - pos;
@@ -3160,14 +2403,12 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
                 const uint32_t adv = dh_min<uint32_t>(64u, avail - 24u);
                 pos += adv; c.consumed += adv;
             }
-            DH_DCLK(1);
             continue;
         }
         if (phase == 2) {                                          // HeaderPhase (dstar_phase.cpp:36-57)
             if (!(avail > 660)) break;
             dh_view_ensure(syms, pos, 660);
             const bool parsed = dh_dstar_header_parse(syms, pos, X);
-            DH_DCLK(2);
             if (!parsed) { pos += 1u; c.consumed += 1u; phase = 0; continue; }
             pos += 660u; c.consumed += 660u;
             if (!((X.out[0] >> 7) & 1u)) {                         // isVoice (header.cpp:150-152)
@@ -3233,7 +2474,6 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
                             pos += 96u; c.consumed += 96u;
                         }
                         s[DS_DT_FRAME] = fc0 + n;
-                        DH_DCLK(5);
                         if (c.overflow) break;
                         continue;
                     }
@@ -3242,7 +2482,6 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
         }
         dh_view_ensure(syms, pos, 128);
         dh_dstar_take128(syms, pos, total, bits);
-        DH_DCLK(3);
         if (sync_count >= 1) {
             if (c.P->out_cap - c.nout < 9u) { c.overflow = true; break; }
             uint8_t* o = c.out + c.nout;
@@ -3258,7 +2497,6 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
             if (c.overflow) break;
             continue;
         }
-        DH_DCLK(4);
         uint32_t frame_count = s[DS_DT_FRAME];
         if (frame_count >= 20u) {                                  // isSyncDue
             bool lost = false;
@@ -3297,7 +2535,6 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
             s[DS_DT_FRAME] = frame_count + 1u;
         }
         pos += 96u; c.consumed += 96u;
-        DH_DCLK(5);
         if (c.overflow) break;
     }
 
@@ -3313,10 +2550,6 @@ DH_HD void dh_dstar_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, u
     }
     s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
     s[DS_CARRY] = rem < DH_DSTAR_CARRY_MAX ? rem : DH_DSTAR_CARRY_MAX;
-#ifdef DH_PHASE_CLOCKS
-    DH_DCLK(6);
-    for (int i = 0; i < 4; i++) s[28 + i] = (dh_uniform(S.clk[2 * i]) >> 6) + ((dh_uniform(S.clk[2 * i + 1]) >> 6) << 16);
-#endif
     s.store(st_global);
     DH_BARRIER();
 }

@@ -27,9 +27,6 @@
 #define DH_FIR_L 16                  // consecutive outputs per lane
 #define DH_PF_N 5                    // 16-byte prefetch loads per lane covering 1024 + 160 samples
 #define DH_PF_SINK 512               // word offset inside the window block where the L2-touch loads drop their dwords (64 words)
-#ifndef DH_PF_L2
-#define DH_PF_L2 1                   // 1: prefetch the next window into L2 only (no registers held across P4-P6); 0: into registers
-#endif
 #define DH_MAX_NZ 160
 #define DH_MAX_SPS 40
 // raw samples kept BEHIND the read position by the error-bounded kernels (see DH_BOUNDED_FIR): the 100 symbols of the
@@ -91,7 +88,7 @@ struct DhDspParams {
     float* filt_out; size_t filt_stride;
 };
 
-// (behind the tail: the per-phase partial sums of the ring-less kernels, see DH_RINGLESS)
+// (behind the tail: two words per phase that round 4's ring-less experiment kept there; the layout is unchanged)
 #define DH_PART_WORDS(sps) ((2u * (sps) + 4u + 3u) & ~3u)
 DH_HD uint32_t dh_state_part_offset(uint32_t sps) { return DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps + dh_tail_max(sps); }
 DH_HD uint32_t dh_state_words(uint32_t sps) { return dh_state_part_offset(sps) + DH_PART_WORDS(sps); }
@@ -127,41 +124,25 @@ struct DhDspShared {
     uint32_t* clk;                                     // DH_PHASE_CLOCKS builds only
     float* tapsf;                                      // FIR taps (first half + centre; the wide filter: all of them, see above)
     float* var_rb;
-    float* part;                                       // ring-less kernels: per-phase sums of the current variance block, [sps] sum x then [sps] sum x^2
     float* bound;                                      // bookkeeping of the error-bounded kernels (DhBoundState, 16 words)
 };
 
 #define DH_TAP_LEAD 15                                 // zeros in front of (and behind) the wide filter's tap table
-#ifdef DH_PHASE_CLOCKS
-#define DH_LDS_CLK_WORDS 8u
-#else
 #define DH_LDS_CLK_WORDS 0u
-#endif
 // words in front of the variance ring (a multiple of 4: keeps var_rb 16-byte aligned)
 DH_HD uint32_t dh_lds_fixed_words(uint32_t nz) { return nz > 80u ? 352u + 16u : 384u + DH_LDS_CLK_WORDS; }
 DH_HD uint32_t dh_dsp_xf_words(uint32_t nz) {
     const uint32_t padded = DH_XPAD(DH_FTILE + nz) + 1u, with_sums = DH_FTILE + 4u + DH_SCAN_N;
     return ((padded > with_sums ? padded : with_sums) + 3u) & ~3u;
 }
-#ifdef DH_NO_RING                           // diagnostic builds (WRONG timing decisions): the variance ring aliases the window block -- what would a smaller LDS block buy?
-#define DH_RING_WORDS(sps) 0u
-#else
 #define DH_RING_WORDS(sps) (DH_VARIANCE_SYMBOLS * (sps))
-#endif
-// Ring-less kernels (DH_RINGLESS; the split-f16 kernels of the DMR / YSF and NXDN48 pipes).  The variance ring -- the last hundred
-// symbols' samples, 4 000 bytes of LDS at sps 10 and 8 000 at sps 20 -- only feeds the per-phase variance estimate at the end of a
-// block.  These kernels add up sum x and sum x^2 per phase while the run's filtered samples are still in the window block (P3)
-// and carry 2 sps floats instead: 6.3 KB of LDS per wavefront, which no longer limits how many wavefronts a CU holds.  The rare
-// blocks the estimate cannot decide recompute their samples from the raw history anyway (exactly); they use the ring's place in
-// the channel's state block in HBM as their scratch.
-#ifndef DH_RINGLESS
-#define DH_RINGLESS 0                        // (measured, round 4: the sums cost the window phase more than the ring cost P3 + P6 -- DMR chain +4 % -- and a 96-register
-#endif                                       //  budget for a fifth wavefront per SIMD spills across the FIR: off; tools/build_variant.sh <name> -DDH_RINGLESS=1 builds it)
-DH_HD bool dh_is_ringless(uint32_t nz, uint32_t sps_template, bool fast);
-DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz, bool ringless = false) {
-    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + (ringless ? DH_PART_WORDS(sps) : DH_RING_WORDS(sps)) + dh_dsp_xf_words(nz));
+// (Round 4 measured kernels WITHOUT the variance ring in LDS -- per-phase sums carried instead, 6.3 KB per wavefront: the sums cost the window
+// phase more than the ring costs, +4 % on the DMR chain, and a fifth wavefront per SIMD at 96 registers spills across the FIR.  Removed in
+// round 5; profiles/r04_b_ab_logs.txt.)
+DH_HD size_t dh_dsp_shared_bytes(uint32_t sps, uint32_t nz) {
+    return sizeof(float) * (size_t) (dh_lds_fixed_words(nz) + DH_RING_WORDS(sps) + dh_dsp_xf_words(nz));
 }
-DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0, bool ringless = false) {          // base: 16-byte aligned
+DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {          // base: 16-byte aligned
     float* f = reinterpret_cast<float*>(base);
     DhDspShared S;
     S.vol_old = f; S.vol_new = f + 128;
@@ -175,8 +156,7 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0, bool r
         S.stats = reinterpret_cast<uint32_t*>(f + 256 + 124); S.clk = reinterpret_cast<uint32_t*>(f + 384);
     }
     S.var_rb = f + dh_lds_fixed_words(nz);
-    S.part = S.var_rb;                                 // (ring-less: the sums sit where the ring would start, and var_rb is pointed at scratch in HBM by the kernel body)
-    S.xf = S.var_rb + (ringless ? DH_PART_WORDS(sps) : DH_RING_WORDS(sps));
+    S.xf = S.var_rb + DH_RING_WORDS(sps);
     S.mn = S.xf; S.mx = S.xf + DH_SCAN_N;
     S.variance = reinterpret_cast<double*>(S.xf + 2 * DH_SCAN_N);
     S.sum = S.xf + DH_FTILE + 4;
@@ -186,10 +166,7 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0, bool r
 // Diagnostic build (-DDH_PHASE_CLOCKS, tools/build_variant.sh): per-phase shader-clock totals of each channel's
 // wavefront, accumulated in LDS and added to header words 6.. of the channel state (units of 64 cycles);
 // read them with dh_engine_debug_header().  Not compiled into the product library.
-#if defined(DH_PHASE_CLOCKS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#define DH_CLK_BEGIN() uint64_t dh_clk_t = clock64()
-#define DH_CLK(i) do { const uint64_t dh_clk_n = clock64(); if (threadIdx.x == 0) S.clk[i] += (uint32_t) (dh_clk_n - dh_clk_t); dh_clk_t = clock64(); } while (0)
-#elif defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#if defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // (static census of the phases in the assembly: tools/asm_census.py counts the instructions between these comments)
 #define DH_CLK_BEGIN() asm volatile("; DH_PHASE begin" ::: "memory")
 #define DH_CLK(i) asm volatile("; DH_PHASE " #i ::: "memory")
@@ -198,21 +175,8 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0, bool r
 #define DH_CLK(i) ((void) 0)
 #endif
 
-// Wave priority (s_setprio 0..3) around the FIR: the instruction arbiter of a SIMD serves its oldest wavefront first,
-// so left alone a young wavefront makes little progress until the older ones are gone.
-// DH_PRIO_MODE selects the policy (measured with tools/lib_ab.py): 0 = hardware default;
-// 3 (shipped) = priority 3 outside the FIR and in the decoder half (the short, latency-bound stretches get their few
-// instructions issued at once), inside the FIR 2 / 1 / 0 / 0 by the quarter of the push the wavefront has reached, so a
-// young wavefront catches up with its elders and the last ones of a launch finish closer together (DMR chain -1.8 %,
-// slicer alone -2.7 %; 1 = only FIR low, 2 = only progress, 6 / 7 = progress for the last 4 096 / 8 192 channels: worse).
-#ifndef DH_PRIO_MODE
-#define DH_PRIO_MODE 0
-#endif
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && DH_PRIO_MODE
-#define DH_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define DH_SETPRIO(n) ((void) 0)
-#endif
+// (Wave priorities -- s_setprio around the FIR and in the decoder half -- were worth 2 % in round 2 and nothing since the FIR moved to
+// the matrix cores: removed in round 5; the policies and their A/B logs are in git history and profiles/r03_b_ab_logs.txt.)
 
 // per-lane values that must survive a barrier: registers on the GPU, [lane] arrays in the harness
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -428,9 +392,6 @@ template <int O0, int O1> __device__ __forceinline__ dh_f2 dh_lds_read2(uint32_t
 }
 // pair i of the slide sequence: (x[8 + i], x[16 + i]), consumed when tap i has been accumulated
 template <int NZ, int I> __device__ __forceinline__ void dh_fir_issue_one(uint32_t addr, dh_f2& d) {
-#ifdef DH_FIR_EXTRA_READS                   // diagnostic builds: every DH_FIR_EXTRA_READS-th window read is issued twice (how much does LDS traffic cost?)
-    if constexpr (I < NZ && I % DH_FIR_EXTRA_READS == 0) { dh_f2 extra = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr); asm volatile("" :: "v"(extra)); }
-#endif
     if constexpr (I < NZ) d = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr);
     else d = dh_f2_make(0.0f, 0.0f);
 }
@@ -575,18 +536,7 @@ struct __attribute__((aligned(4))) dh_f4 { float x, y, z, w; };
 struct alignas(16) dh_f4a { float x, y, z, w; };     // 16-byte aligned: one ds_read_b128
 DH_HD dh_f4 dh_load4_unaligned(const float* p) { dh_f4 v; __builtin_memcpy(&v, p, sizeof(v)); return v; }
 // the same for the one-touch input stream: DH_NT_INPUT=1 marks the loads non-temporal (A/B: see DESIGN.md section 5)
-#ifndef DH_NT_INPUT
-#define DH_NT_INPUT 0
-#endif
-#if DH_NT_INPUT && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-typedef float dh_f4nt __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ dh_f4 dh_load4_stream(const float* p) {
-    const dh_f4nt t = __builtin_nontemporal_load(reinterpret_cast<const dh_f4nt*>(p));
-    dh_f4 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v;
-}
-#else
 DH_HD dh_f4 dh_load4_stream(const float* p) { return dh_load4_unaligned(p); }
-#endif
 DH_HD void dh_store4(float* q, const dh_f4& v) { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
 DH_HD void dh_store4_unaligned(float* q, const dh_f4& v) { __builtin_memcpy(q, &v, sizeof(v)); }   // global_store_dwordx4
 
@@ -610,9 +560,7 @@ DH_HD void dh_store4_unaligned(float* q, const dh_f4& v) { __builtin_memcpy(q, &
 // slice s + 4 of the even one: 28 window reads serve the 48 MFMAs of a tile pair.  Results go back unpadded (sample o at
 // word o): sixteen ds_write_b32 at compile-time offsets from one per-lane base (2-way bank conflicts, which a 4-byte
 // store hides behind its own issue time).
-#ifndef DH_MFMA_FIR
 #define DH_MFMA_FIR 1
-#endif
 #define DH_MF_OUT(T, r, g, n) (128u * (uint32_t) (g) + (uint32_t) (n) + 32u * (uint32_t) (r) + 16u * ((uint32_t) (T) & 1u) + 512u * ((uint32_t) (T) >> 1))
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 typedef float dh_f32x4 __attribute__((ext_vector_type(4)));
@@ -681,39 +629,12 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 //   B: lane (n = l & 15, q = l >> 4) holds g[32 s + 8 q + j - n]: per-lane fragments precomputed on the host (6 x 1 KiB,
 //      dh_f16_tap_fragments), fetched with the samples
 //   D: lane (n, g), register r holds y[256 T + 64 g + 16 r + n]
-#ifndef DH_FIR_F16
 #define DH_FIR_F16 1
-#endif
-#ifndef DH_P3_PAIRED
-#define DH_P3_PAIRED 1                       // sps-10 kernels: the window phase takes two symbols per lane (packed adds), one pass per run
-#endif
-#ifndef DH_P5_PAIRED
-#define DH_P5_PAIRED 1                       // ... and so does the slicing phase
-#endif
-#ifndef DH_P345_MERGED
-#define DH_P345_MERGED 0                     // split-f16 sps-10 kernels: window, AGC and slicing phases as ONE phase on runs that start a variance block (see "P3 - P5 merged"; measured, round 4: five LDS round trips less per run and no faster -- the twenty-word lane stride doubles the bank conflicts of the sample reads -- off)
-#endif
-#ifndef DH_P5_SHORT_STORES
-#define DH_P5_SHORT_STORES 1                 // paired slicing phase: a lane's two dibits leave as one 16-bit store
-#endif
-#ifndef DH_PLAN_FAST
 #define DH_PLAN_FAST 1                       // sps-10 kernels: the run planning of a whole-block run in three compares
-#endif
-#ifndef DH_P6_LEAN
-#define DH_P6_LEAN 1                         // sps-10 timing estimate: partial sums meet through DPP instead of LDS, two votes (see P6)
-#endif
-#ifndef DH_EXACT_BATCH
 #define DH_EXACT_BATCH 2                     // exact evaluations of the 81-tap kernels: this many products at a time, their LDS reads in flight together (the 161-tap ones: 8)
-#endif
-#ifndef DH_EXACT_STAGED
 #define DH_EXACT_STAGED 1                    // the exact re-evaluations of the sps-10 kernels stage their raw samples through LDS, like the generic-sps ones
-#endif
-#ifndef DH_PF_REG
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
-#endif
-#ifndef DH_F16_EDGE_WINDOWS
 #define DH_F16_EDGE_WINDOWS 1                // split-f16 kernels: the first / last windows of a push take the split-f16 FIR too (0: the reference-order FIR, as before)
-#endif
 // K = taps + 15 rounded up to whole MFMAs of 32: three for the wide filter (96), six for the narrow one (192; taps beyond the
 // response are zeros in the fragments, and the halves beyond the window are stored as zeros)
 #define DH_F16_KSTEPS_OF(nz) (((nz) + 16 + 31) / 32)
@@ -1091,21 +1012,11 @@ __device__ __forceinline__ float dh_row_min_to_lane15(float v) {
 // an average and a threshold computed from values with radii <= e differ from the reference's difference by at most
 // (1 + 2.25) 167/240 e + 62/240 e < 2.53 e; a comparison is DECIDED when they are further apart than T = 3.5 e.
 // e of a ring entry is the e of the run that produced it: kept as two maxima over >= 100-symbol buckets (DH_ST_E_*).
-#ifndef DH_BOUNDED_FIR
 #define DH_BOUNDED_FIR 1
-#endif
-#ifndef DH_BOUNDED_NARROW
 #define DH_BOUNDED_NARROW 1                 // the same for the narrow filter at a run-time samples-per-symbol (the NXDN pipe)
-#endif
 template <int NZ, bool FAST, int SPS> struct DhIsBounded {
     static constexpr bool value = DH_BOUNDED_FIR && !FAST && ((NZ == 80 && SPS == 10) || (DH_BOUNDED_NARROW && NZ == 160 && SPS != 10));
 };
-template <int NZ, bool FAST, int SPS> struct DhIsRingless {
-    static constexpr bool value = DH_RINGLESS && DH_FIR_F16 && DhIsBounded<NZ, FAST, SPS>::value && ((NZ == 80 && SPS == 10) || (NZ == 160 && SPS == 20));
-};
-DH_HD bool dh_is_ringless(uint32_t nz, uint32_t sps_template, bool fast) {
-    return DH_RINGLESS && DH_FIR_F16 && DH_BOUNDED_FIR && !fast && ((nz == 80u && sps_template == 10u) || (DH_BOUNDED_NARROW && nz == 160u && sps_template == 20u));
-}
 // Diagnostic builds only (tools/phase_budget.sh): -DDH_STOP_AFTER=n leaves out the phases after Pn of every run (the
 // results are then wrong; the instruction counters of such builds, subtracted from each other, give the per-phase budget)
 #ifndef DH_STOP_AFTER
@@ -1493,29 +1404,6 @@ DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps
 }
 
 
-// Diagnostic builds (results unchanged): DH_PROBE_AT=<place> adds DH_PROBE_N independent v_add_f32 (or, with DH_PROBE_SALU, dependent
-// s_add_u32) at one place of the run loop -- 0: in front of the FIR, 1: behind the FIR's write-back, 2: behind the window phase,
-// 3: in front of the slicing phase, 4: in front of the timing phase, 5: in front of the commit, 6: at the end of the iteration.
-// Same instructions, different places: where does the step time respond?  (tools/README.md)
-#if defined(DH_PROBE_AT) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#ifndef DH_PROBE_N
-#define DH_PROBE_N 128
-#endif
-__device__ __forceinline__ void dh_probe_body() {
-#ifdef DH_PROBE_SALU
-#pragma unroll
-    for (int u = 0; u < DH_PROBE_N; u++) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
-#else
-    float xv[8]; for (int j = 0; j < 8; j++) xv[j] = (float) j;
-#pragma unroll
-    for (int u = 0; u < DH_PROBE_N; u++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xv[u & 7]));
-    asm volatile("" :: "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(xv[4]), "v"(xv[5]), "v"(xv[6]), "v"(xv[7]));
-#endif
-}
-#define DH_PROBE(place) do { if ((place) == DH_PROBE_AT) dh_probe_body(); } while (0)
-#else
-#define DH_PROBE(place) ((void) 0)
-#endif
 // ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
 // once (host harness; the DH_FOR_LANES loops then iterate the lanes).
@@ -1532,11 +1420,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
-    constexpr bool RINGLESS = DhIsRingless<NZ, FAST, SPS>::value;                                     // no variance ring in LDS: per-phase sums instead (see DH_RINGLESS)
-    // P3 - P5 merged (below): the filtered samples of a run then start FOFF words into the window block, so that the copy of symbol 0
-    // one word in front of its place (a pending step of -1) stays inside the block
-    constexpr bool CAN_MERGE = DH_P345_MERGED && MF16 && SPS == 10 && !RINGLESS && NZ == 80 && DH_STOP_AFTER >= 99 && !KEEPF;
-    constexpr uint32_t FOFF = CAN_MERGE ? 4u : 0u;
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -1544,11 +1427,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const uint32_t ev_lo = SPS == 10 ? 3u : P.lo, ev_hi = SPS == 10 ? 7u : P.hi;
     const float sps_rcp = 1.0f / (float) sps;           // correctly rounded (IEEE division, once per push)
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
-#ifdef DH_SAME_ROW                          // diagnostic builds: every channel reads the rows of the first 64 (the input then lives in L2: what does HBM cost?)
-    const float* in = P.in + (size_t) (ch & 63u) * P.in_stride;
-#else
     const float* in = P.in + (size_t) ch * P.in_stride + part_lo;
-#endif
     uint8_t* syms = P.syms + (size_t) ch * P.sym_stride;
     const float* in_end = P.in + (size_t) (P.n_channels - 1u) * P.in_stride + P.n;    // end of the readable input
 
@@ -1556,13 +1435,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // (the samples are then used where they were staged, and the window sums sit right behind them)
 #define DH_XP(e) (NZ > 0 ? DH_XPAD(e) : (e))
     DH_CLK_BEGIN();
-#if defined(DH_WAVE_TIMELINE) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t dh_t_start = (uint32_t) wall_clock64();        // diagnostic build: when this channel's wavefront ran (100 MHz)
-#endif
-#if defined(DH_STAGGER) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-    // diagnostic builds: wavefronts start up to DH_STAGGER x 64 cycles apart (do the wavefronts of the chip move in lock-step?)
-    for (uint32_t w = (ch * 37u) % (uint32_t) DH_STAGGER; w >= 8u; w -= 8u) __builtin_amdgcn_s_sleep(8);
-#endif
     // ---- load carried state
     uint32_t k0 = sth[DH_ST_K];
     int32_t off = (int32_t) sth[DH_ST_OFF];
@@ -1576,10 +1448,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             S.vol_old[j] = j < DH_VOLUME_RB_SIZE ? st[DH_ST_VOL + j] : 0.0f;
             S.vol_new[j] = 0.0f;
         }
-        if (!RINGLESS) { for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) S.var_rb[j] = st[DH_ST_VAR + j]; }
-        else { for (uint32_t j = lane; j < 2u * sps; j += DH_WAVE) S.part[j] = st[dh_state_part_offset(sps) + j]; }
+        for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) S.var_rb[j] = st[DH_ST_VAR + j];
     }
-    if (RINGLESS) S.var_rb = st + DH_ST_VAR;            // the rare exact recomputations of a block use the ring's place in the state block as scratch
     DH_BARRIER();
 
     // FIR taps are parked in LDS and pulled into VGPRs at the start of every FIR pass (see P2): their live range
@@ -1599,9 +1469,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         if (lane < 2) S.stats[lane] = 0;
-#ifdef DH_PHASE_CLOCKS
-        if (lane < 8) S.clk[lane] = 0;
-#endif
     }
 
     // error-bounded mode (see DH_BOUNDED_FIR above): the tail then starts with DH_ST_P0 samples of HISTORY, so that the
@@ -1707,12 +1574,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     dh_u4 tapfrag_regs[2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80)];
 #define DH_TAPFRAG_LOAD() do { if constexpr (MF16) { const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(P.tapfrag) + dh_fresh_lane_id_(); \
         _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
-#ifndef DH_TAPFRAG_LATE
-#define DH_TAPFRAG_LATE 0                    // 1: the fragments are requested at the start of every FIR pass instead of one iteration ahead (24 registers less across the loop's back edge; their L1 / L2 latency is then exposed)
-#endif
-#if !DH_TAPFRAG_LATE
     DH_TAPFRAG_LOAD();
-#endif
     // Every path through P2 must leave these loads landed, also the rare ones that never look at the fragments: otherwise the
     // compiler's wait-count bookkeeping still sees them in flight further down, and the first instruction that reuses one of
     // their registers -- in the slicing phase -- gets an s_waitcnt vmcnt(0), which also waits for the NEXT window's loads,
@@ -1760,7 +1622,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const uint32_t last_start = p + (m - 1) * sps + (m > 1 ? (uint32_t) step_off : 0u);
         const uint32_t need = last_start + sps - p;     // filtered samples [p, p+need) feed this run
         const uint32_t need_fir = KEEPF ? (uint32_t) DH_FTILE : need;      // (a kernel that also delivers the filtered samples wants the whole pass)
-        const bool merged = CAN_MERGE && DH_LIKELY(k0 == 0);     // a run that starts a variance block: ring slot == symbol index
         // (bits 2.. of blk_flags, ring-less kernels: 4 = some run of the current block had a non-zero window, bits 8..15 = runs the block has been cut into)
         if (BOUNDED && k0 == 0) { BS->cur_start = (int32_t) p; BS->cur_off = step_off; BS->blk_flags = (BS->blk_flags & 3u) | 1u; BS->e_blk = 0.0f; }   // symbol k of this block sits at cur_start + k sps + (k ? cur_off : 0)
         bool use_exact = BOUNDED && P.exact_mode == 2;  // this run through the exact FIR (odd samples, odd staging path)
@@ -1774,7 +1635,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
         // From the second run on, the window was already put there by the previous iteration's prefetch.
         if (DH_LIKELY(staged && staged_p == p)) {
-            static_assert(DH_PF_L2 || !BOUNDED, "the register-prefetch build does not compute max |x| of a prefetched window: error-bounded kernels need DH_PF_L2");
             if (PF_REG) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; }      // (put there by P7 of the previous run)
         } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
             // whole window inside the input buffer: unconditional loads (all in flight together, see the prefetch
@@ -1905,7 +1765,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else use_exact = true;                      // tiny, huge or infinite samples: outside the bound's assumptions
         }
         DH_CLK(0);
-        DH_PROBE(0);
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
         // The filtered samples go back UNPADDED (element n at word n, four 16-byte stores per lane): the symbol
@@ -1914,28 +1773,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // only, and the LDS pipe has slack.  Without an RRC stage the staged (padded) samples are used as they are.
         if (NZ > 0 && DH_STOP_AFTER >= 2) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
-#if DH_PRIO_MODE == 1
-            DH_SETPRIO(0);
-#elif DH_PRIO_MODE == 8 || DH_PRIO_MODE == 9
-            DH_SETPRIO(DH_PRIO_MODE == 8 ? 3 : 1);     // the matrix-pipe FIR first: its MFMAs must not wait behind other wavefronts' vector work
-#elif DH_PRIO_MODE >= 2
-            {
-#if DH_PRIO_MODE >= 6
-                const bool dh_prio_on = ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels;     // the wavefronts dispatched last
-#else
-                const bool dh_prio_on = true;
-#endif
-                if (dh_prio_on) {
-                    const uint32_t quarter = nf / 4u + 1u; const uint32_t done = p / quarter;      // 0..3
-                    if (done == 0) DH_SETPRIO(DH_PRIO_MODE == 2 ? 3 : 2); else if (done == 1) DH_SETPRIO(DH_PRIO_MODE == 2 ? 2 : 1);
-                    else if (done == 2) DH_SETPRIO(DH_PRIO_MODE == 2 ? 1 : 0); else DH_SETPRIO(0);
-                }
-            }
-#endif
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
-#if DH_TAPFRAG_LATE
-            DH_TAPFRAG_LOAD();
-#endif
             // (taps from the LDS copy into vector registers: as scalar operands they free 40 VGPRs but cost this kernel 5 %,
             // see DhFirBatch)
             constexpr bool MFMA = DH_MFMA_FIR && NZ > 0 && NZ <= 80 && (BOUNDED || FAST) && !MF16;      // the fused FIR as f32 MFMAs (dh_fir_mfma)
@@ -2013,19 +1851,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_BARRIER();
             if (MF16 && mf_layout == 2) {
                 DH_FOR_LANES_FRESH(lane) {
-                    float* dst = S.xf + FOFF + DH_F16_OUT(0, 0, lane >> 4, lane & 15);
+                    float* dst = S.xf + DH_F16_OUT(0, 0, lane >> 4, lane & 15);
 #pragma unroll
                     for (int T = 0; T < 4; T++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) dst[DH_F16_OUT(T, r, 0, 0)] = DH_LA(fo, lane)[4 * T + r];
-                }
-                // P3 - P5 merged: symbol 0 sits in FRONT of the pending step, every other symbol behind it; a second copy of
-                // its ten samples `step_off` words further (lanes 0..9 hold them: sample n of the run is register 0 of lane n)
-                // puts the whole run on one grid of ten words.  The words it overwrites belong to symbol 0 alone (and the one
-                // skipped sample); LDS stores of a wavefront land in program order, so this one, issued after every lane's
-                // sixteen, wins.
-                if (CAN_MERGE && merged && step_off != 0) {
-                    DH_FOR_LANES_FRESH(lane) { if (lane < 10) S.xf[(int32_t) (FOFF + (uint32_t) lane) + step_off] = DH_LA(fo, lane)[0]; }
                 }
             } else if (MFMA && mf_layout == 1) {
                 // sample DH_MF_OUT(T, r, g, n) of the run from register 4 T + r of lane 16 g + n: compile-time offsets
@@ -2039,7 +1869,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             } else {
                 DH_FOR_LANES_FRESH(lane) {
                     if ((uint32_t) (lane * DH_FIR_L) < need_fir) {
-                        dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + FOFF + DH_FIR_L * lane);
+                        dh_f4a* dst = reinterpret_cast<dh_f4a*>(S.xf + DH_FIR_L * lane);
 #pragma unroll
                         for (int j = 0; j < DH_FIR_L / 4; j++) {
                             dh_f4a v; v.x = DH_LA(fo, lane)[4 * j]; v.y = DH_LA(fo, lane)[4 * j + 1];
@@ -2048,27 +1878,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         }
                     }
                 }
-                if (CAN_MERGE && merged && step_off != 0) {        // (the reference-order FIR of a split-f16 kernel, a rare run: symbol 0 copied as above, from LDS)
-                    DH_BARRIER();
-                    DH_LANE_ARRAY(float, s0, 1);
-                    DH_FOR_LANES_FRESH(lane) { DH_LA(s0, lane)[0] = S.xf[FOFF + (uint32_t) (lane < 10 ? lane : 0)]; }
-                    DH_BARRIER();
-                    DH_FOR_LANES_FRESH(lane) { if (lane < 10) S.xf[(int32_t) (FOFF + (uint32_t) lane) + step_off] = DH_LA(s0, lane)[0]; }
-                }
             }
             DH_BARRIER();
-#if DH_PRIO_MODE == 1 || DH_PRIO_MODE == 3
-            DH_SETPRIO(3);
-#elif DH_PRIO_MODE == 8 || DH_PRIO_MODE == 9
-            DH_SETPRIO(0);
-#elif DH_PRIO_MODE >= 6
-            if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
-#endif
         }
         DH_TAPFRAG_SETTLE();
         DH_CLK(1);
-        DH_PROBE(1);
-        const float* fbuf = S.xf + FOFF;
+        const float* fbuf = S.xf;
 #define DH_FB(n) fbuf[n]
 
         // ---- prefetch: the raw window of the NEXT run.  Its start is already known (the timing decision of this
@@ -2078,9 +1893,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const uint32_t p_next = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
         const bool pf_ok = p_next >= tc && p_next < nv;
         const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
-#if !DH_PF_L2
-        DH_LANE_ARRAY(dh_f4, pf, DH_PF_N);
-#endif
         DH_LANE_ARRAY(dh_f4, pfr, PF_REG ? DH_PF_N : 1);  // split-f16 kernels: the next window, parked in registers through P4 - P6
         // Only when the whole window lies inside the input buffer (every run but the last ones of the last
         // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
@@ -2114,7 +1926,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_stream(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
             }
         } else {
-#if DH_PF_L2
         // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
         // lines into L2; the next iteration's P1 then stages from L2 instead of HBM.  The dwords themselves are not
         // wanted: global_load_lds_dword drops them (lane l -> m0 + 4 l) into a part of the window block that is dead
@@ -2132,28 +1943,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                              : "=&s"(keep_m0) : "s"(sink), "v"(line) : "memory");
 #endif
         }
-#else
-        if (pf_plain) {
-            const float* src = in + (p_next - tc);
-            DH_FOR_LANES_FRESH(lane) {
-#pragma unroll
-                for (int r = 0; r < DH_PF_N; r++) {
-                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                    DH_LA(pf, lane)[r] = dh_load4_unaligned(src + dh_min<uint32_t>(e, DH_FTILE + NZ - 4u));
-                }
-            }
-        }
-#endif
         }
         };
 
         DH_COMPILER_FENCE();                            // the bookkeeping in LDS is read here, not carried across the FIR
         float e_blk = 0.0f;
         if (BOUNDED) { e_blk = dh_uniform_f(__builtin_fmaxf(BS->e_blk, e_run)); BS->e_blk = e_blk; }
-        if (RINGLESS) {                                 // one more piece of the current block; did its window hold anything but zeros?
-            const uint32_t f = dh_uniform(BS->blk_flags), pieces = dh_min<uint32_t>(((f >> 8) & 255u) + 1u, 255u);
-            BS->blk_flags = (f & ~0xFF00u) | (pieces << 8) | ((use_exact || e_run > 0.0f) ? 4u : 0u);
-        }
         const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
         const float T = DH_BOUND_T_FACTOR * e_eff;
         uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
@@ -2170,154 +1965,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
         const bool pair_store = ((uint32_t) (uintptr_t) syms + nsym) % 2u == 0u;      // (paired slicing phases: symbols 2 l, 2 l + 1 of the run as one 16-bit store)
 
-        // ---- P3 - P5 merged (split-f16 sps-10 kernels, runs that start a variance block: ring slot == symbol index).
-        // As three phases, symbol windows -> AGC scans -> slicing hand the sums, the volumes and the extremes of every symbol from
-        // one lane mapping to the next through LDS: six dependent LDS round trips per run on a wavefront that has three others to
-        // hide behind, and a step that follows the latency of a run.  Here lane l owns symbols 2 l and 2 l + 1 from the samples
-        // to the dibits: their samples are twenty consecutive words from ONE base (the copy of symbol 0 made behind the FIR put
-        // the whole run on one grid), a ds_read2_b32 delivers sample i of both, the sums are packed additions, the two volumes are
-        // this lane's entries of the prefix scans as they stand, and the extremes never leave the registers.  Only the suffix
-        // extremes of the OLD ring pass through LDS (read backwards, scanned forwards, handed to the owning lanes -- as in
-        // dh_agc_scan), and they depend on nothing this run computes: that exchange runs beside the sample reads.  Every
-        // operation is the one the three-phase form performs on the same operands in the same order (sums in sample order,
-        // dh_div_const2, v_min / v_max scans, one FMA per threshold), so dibits and doubts are the same; the old form still
-        // takes every run that starts inside a block (the first of a push).
-        DH_LANE_ARRAY(dh_f2, mg_volume, 1); DH_LANE_ARRAY(dh_f2, mg_mn, 1); DH_LANE_ARRAY(dh_f2, mg_mx, 1);
-        if (CAN_MERGE && merged) {
-            float* const xch_mn = S.vol_new;            // suffix extremes of the old ring per slot (S.vol_new is otherwise unused on this path)
-            float* const xch_mx = S.sum;                // (behind the last filtered sample)
-            DH_LANE_ARRAY(dh_f2, mg_mid, 1);
-            (void) xch_mn; (void) xch_mx;
-            DH_FOR_LANES_FRESH(lane) {
-                const uint32_t l = (uint32_t) lane, lc = l < 50u ? l : 49u;          // (lanes beyond the run repeat lane 49's reads and store nothing)
-                const bool va = 2u * l < m, vb = 2u * l + 1u < m;
-                const float* src = fbuf + step_off + (int32_t) (20u * lc);
-                dh_f2 v[10];
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                {
-                    // Issue order: the lane's two entries of the OLD ring read backwards (slots 126 - 2 l and 127 - 2 l), then the
-                    // twenty samples.  LDS answers in order, so the ring entries are there while the samples are still on their
-                    // way (lgkmcnt(10)): the suffix scan and its exchange stores run inside the samples' latency.
-                    const uint32_t r0 = 126u - 2u * l, r1 = r0 + 1u;
-                    const uint32_t ao = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (S.vol_old + r0);
-                    const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
-                    dh_f2 o;
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(o) : "v"(ao) : "memory");
-                    v[0] = dh_lds_read2<0, 10>(a); v[1] = dh_lds_read2<1, 11>(a); v[2] = dh_lds_read2<2, 12>(a); v[3] = dh_lds_read2<3, 13>(a);
-                    v[4] = dh_lds_read2<4, 14>(a); v[5] = dh_lds_read2<5, 15>(a); v[6] = dh_lds_read2<6, 16>(a); v[7] = dh_lds_read2<7, 17>(a);
-                    v[8] = dh_lds_read2<8, 18>(a); v[9] = dh_lds_read2<9, 19>(a);
-                    asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(o) :: "memory");
-                    const float omn0 = r0 < DH_VOLUME_RB_SIZE ? o.x : DH_FLT_MAX, omn1 = r1 < DH_VOLUME_RB_SIZE ? o.y : DH_FLT_MAX;
-                    const float omx0 = r0 < DH_VOLUME_RB_SIZE ? o.x : DH_FLT_MIN, omx1 = r1 < DH_VOLUME_RB_SIZE ? o.y : DH_FLT_MIN;
-                    float smn = dh_vmin(omn0, omn1), smx = dh_vmax(omx0, omx1);
-                    dh_wave_prefix_minmax(smn, smx);
-                    const float esmn = dh_wave_prev(smn, DH_FLT_MAX), esmx = dh_wave_prev(smx, DH_FLT_MIN);
-                    // exclusive suffix of slot r1, then of slot r0 (= r1's, and r1 itself)
-                    xch_mn[r1] = esmn; xch_mx[r1] = esmx;
-                    xch_mn[r0] = dh_vmin(omn1, esmn); xch_mx[r0] = dh_vmax(omx1, esmx);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]) :: "memory");
-                }
-#else
-                for (int i = 0; i < 10; i++) v[i] = dh_f2_make(src[i], src[10 + i]);
-#endif
-                dh_f2 vol = v[0];
-#pragma unroll
-                for (int i = 1; i < 10; i++) vol = dh_f2_add(vol, v[i]);
-                const dh_f2 mid = dh_f2_add(dh_f2_add(dh_f2_add(v[3], v[4]), v[5]), v[6]);          // samples ev_lo .. ev_hi - 1 = 3 .. 6
-                const dh_f2 volume = dh_div_const2(vol, 10.0f, sps_rcp);
-                float* ring = S.var_rb + 2u * lc;                                                     // transposed ring: phase-major
-                if (vb) {
-                    dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);
-                    dh_lds_store_row10<1>(ring, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y);
-                } else if (va) dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);
-                DH_LA(mg_volume, lane)[0] = volume; DH_LA(mg_mid, lane)[0] = mid;
-#if !(DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__))
-                if (va) { S.vol_new[2u * l] = volume.x; }          // harness: the scans below are dh_agc_scan's sequential statement
-                if (vb) { S.vol_new[2u * l + 1u] = volume.y; }
-#endif
-            }
-            DH_CLK(2);
-            issue_next_window();
-            // the AGC extremes of the lane's two symbols
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            {
-                const uint32_t l = (uint32_t) dh_fresh_lane_id_();
-                const bool va = 2u * l < m, vb = 2u * l + 1u < m;
-                const dh_f2 sn = *reinterpret_cast<const dh_f2*>(xch_mn + 2u * l), sx = *reinterpret_cast<const dh_f2*>(xch_mx + 2u * l);
-                const float c0 = mg_volume[0].x, c1 = mg_volume[0].y;
-                const float pmn0 = va ? c0 : DH_FLT_MAX, pmn1 = vb ? c1 : DH_FLT_MAX;
-                const float pmx0 = va ? c0 : DH_FLT_MIN, pmx1 = vb ? c1 : DH_FLT_MIN;
-                float pmn = dh_vmin(pmn0, pmn1), pmx = dh_vmax(pmx0, pmx1);
-                dh_wave_prefix_minmax(pmn, pmx);
-                const float epmn = dh_wave_prev(pmn, DH_FLT_MAX), epmx = dh_wave_prev(pmx, DH_FLT_MIN);
-                mg_mn[0] = dh_f2_make(dh_vmin(dh_vmin(epmn, pmn0), sn.x), dh_vmin(pmn, sn.y));
-                mg_mx[0] = dh_f2_make(dh_vmax(dh_vmax(epmx, pmx0), sx.x), dh_vmax(pmx, sx.y));
-            }
-#else
-            dh_agc_scan(S, 0, m);                       // (S.mn / S.mx alias the filtered samples, which every lane has consumed by now)
-            DH_FOR_LANES_FRESH(lane) {
-                const uint32_t k = 2u * (uint32_t) lane < m ? 2u * (uint32_t) lane : 0u;
-                DH_LA(mg_mn, lane)[0] = dh_f2_make(S.mn[k], S.mn[k + 1u]); DH_LA(mg_mx, lane)[0] = dh_f2_make(S.mx[k], S.mx[k + 1u]);
-            }
-#endif
-            DH_CLK(3);
-            // thresholds + slice (gfsk_demodulator.cpp:88-106): the two-symbols-per-lane form of P5 below, operands from registers
-            uint64_t vote_a = 0, vote_b = 0;
-            DH_FOR_LANES_FRESH(lane) {
-                const uint32_t qa = 2u * (uint32_t) lane;
-                const bool va = qa < m, vb = qa + 1u < m;
-                const dh_f2 mn = DH_LA(mg_mn, lane)[0], mx = DH_LA(mg_mx, lane)[0], sumq = DH_LA(mg_mid, lane)[0];
-                const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);
-                const dh_f2 average = dh_f2_scale(sumq, inv_width);                  // (ev_hi - ev_lo = 4: the product is the division)
-                const dh_f2 c625 = dh_f2_make(0.625f, 0.625f);
-                const dh_f2 umid = dh_f2_fma(dh_f2_sub(mx, center), c625, center);
-                const dh_f2 lmid = dh_f2_fma(dh_f2_sub(mn, center), c625, center);
-                const bool above_a = average.x > center.x, above_b = average.y > center.y;
-                const uint8_t sym4a = above_a ? (average.x > umid.x ? 1 : 0) : (average.x < lmid.x ? 3 : 2);
-                const uint8_t sym4b = above_b ? (average.y > umid.y ? 1 : 0) : (average.y < lmid.y ? 3 : 2);
-                const uint8_t sym2a = LV == 4 ? (uint8_t) 0 : above_a ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
-                const uint8_t sym2b = LV == 4 ? (uint8_t) 0 : above_b ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
-                const uint8_t sa = four_levels ? sym4a : sym2a, sb = four_levels ? sym4b : sym2b;
-                bool doubt_a = false, doubt_b = false;
-                if (BOUNDED) {
-                    const dh_f2 du = dh_f2_sub(average, umid), dl = dh_f2_sub(average, lmid), dc = dh_f2_sub(average, center);
-                    const float da = dh_min3_abs(four_levels ? du.x : DH_FLT_MAX, four_levels ? dl.x : DH_FLT_MAX, dc.x);
-                    const float db = dh_min3_abs(four_levels ? du.y : DH_FLT_MAX, four_levels ? dl.y : DH_FLT_MAX, dc.y);
-                    doubt_a = va && e_pos && !(da > T_eff);
-                    doubt_b = vb && e_pos && !(db > T_eff);
-                }
-#ifdef DH_IGNORE_DOUBT
-                doubt_a = false; doubt_b = false;
-#endif
-#if DH_P5_SHORT_STORES
-                if (pair_store && va && !doubt_a && vb && !doubt_b) *reinterpret_cast<uint16_t*>(syms + nsym + qa) = (uint16_t) ((uint32_t) sa | ((uint32_t) sb << 8));
-                else
-#endif
-                {
-                    if (va && !doubt_a) syms[nsym + qa] = sa;
-                    if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
-                }
-                DH_BALLOT_ACC(vote_a, doubt_a, lane);
-                DH_BALLOT_ACC(vote_b, doubt_b, lane);
-            }
-            if (DH_UNLIKELY((vote_a | vote_b) != 0)) {
-                for (uint32_t l = 0; l < 50u; l++) {
-                    if ((vote_a >> l) & 1ull) unsure[(2u * l) >> 6] |= 1ull << ((2u * l) & 63u);
-                    if ((vote_b >> l) & 1ull) unsure[(2u * l + 1u) >> 6] |= 1ull << ((2u * l + 1u) & 63u);
-                }
-                // what the exact evaluation of a symbol looks at: the extremes and this run's volumes, per slot
-                DH_BARRIER();
-                DH_FOR_LANES_FRESH(lane) {
-                    const uint32_t qa = 2u * (uint32_t) lane;
-                    if (qa < m) { S.mn[qa] = DH_LA(mg_mn, lane)[0].x; S.mx[qa] = DH_LA(mg_mx, lane)[0].x; S.vol_new[qa] = DH_LA(mg_volume, lane)[0].x; }
-                    if (qa + 1u < m) { S.mn[qa + 1u] = DH_LA(mg_mn, lane)[0].y; S.mx[qa + 1u] = DH_LA(mg_mx, lane)[0].y; S.vol_new[qa + 1u] = DH_LA(mg_volume, lane)[0].y; }
-                }
-                DH_BARRIER();
-            }
-        }
-
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
-#if DH_P3_PAIRED
         // sps 10: TWO symbols per lane, the whole run in one pass of straight-line code.  A lane's symbols q and q + 24 both lie
         // behind the pending timing step, so their samples sit at compile-time offsets (i and 240 + i words) from ONE per-lane
         // base and a single ds_read2_b32 delivers sample i of both as a register pair:
@@ -2328,7 +1976,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // as the reference's do) and the division; loads and stores carry their offsets as immediates, so the phase costs ~35
         // vector instructions instead of the ~85 of two passes of one symbol per lane.  Lanes beyond the run read words of the
         // window block that nothing will look at (possibly halves of the staged arrays) and store nothing.
-        if (SPS == 10 && DH_STOP_AFTER >= 3 && !merged) DH_FOR_LANES_FRESH(lane) {
+        if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
             const uint32_t l = (uint32_t) lane;
             const uint32_t qa = l < 51u ? l + 1u + (l >= 24u ? 24u : 0u) : 0u, qb = qa + 24u;
             const bool va = (l < 48u || l == 51u) && qa < m, vb = l < 51u && qb < m;
@@ -2353,23 +2001,16 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             const uint32_t ka = k0 + qa;
             float* ring = S.var_rb + ka;
             if (va) {
-#ifndef DH_NO_RING
-                if (!RINGLESS) dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);      // transposed ring: phase-major
-#endif
+                dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);      // transposed ring: phase-major
                 S.sum[qa] = mid.x; S.vol_new[ka] = volume.x;
             }
             if (vb) {
-#ifndef DH_NO_RING
-                if (!RINGLESS) dh_lds_store_row10<24>(ring, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y);
-#endif
+                dh_lds_store_row10<24>(ring, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y);
                 S.sum[qb] = mid.y; S.vol_new[ka + 24u] = volume.y;
             }
             dh_lds_stores_done();
         }
         if (SPS != 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
-#else
-        if (DH_STOP_AFTER >= 3 && !merged) DH_FOR_LANES_FRESH(lane) {
-#endif
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
@@ -2384,9 +2025,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     for (uint32_t i = 0; i < (SPS ? SPS : 1); i++) {
                         if (i >= ev_lo && i < ev_hi) sum += value[i];
                         volume_sum += value[i];
-#ifndef DH_NO_RING
-                        if (!RINGLESS) S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
-#endif
+                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
                     }
                 } else {
                     // four samples at a time, all four requested before the first is used (see above); sums in sample order
@@ -2399,141 +2038,38 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         for (uint32_t j = 0; j < 4u; j++) {
                             if (i + j >= ev_lo && i + j < ev_hi) sum += value[j];
                             volume_sum += value[j];
-#ifndef DH_NO_RING
-                            if (!RINGLESS) S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
-#endif
+                            S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
                         }
                     }
                     for (; i < sps; i++) {
                         const float value = DH_FB(s + i);
                         if (i >= ev_lo && i < ev_hi) sum += value;
                         volume_sum += value;
-#ifndef DH_NO_RING
-                        if (!RINGLESS) S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
-#endif
+                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
                     }
                 }
                 S.sum[q] = sum;
                 S.vol_new[k] = dh_div_const(volume_sum, (float) sps, sps_rcp);
             }
         }
-        // ---- P3b (ring-less kernels): this run's share of the per-phase sums behind the timing estimate of P6, taken while the
-        // filtered samples are still in the window block.  Lane G i + g adds up phase i (sample i of every symbol) over the g-th
-        // chunk of the run's symbols -- two interleaved chains, the squares by FMA -- the G lanes of a phase meet through a DPP
-        // quad permute, and the first of them folds the result into the block's sums (S.part).  Same phase as the windows above:
-        // both only read the filtered samples.
-        if constexpr (RINGLESS) {
-            constexpr uint32_t G = SPS == 10 ? 4u : 2u, FULL = SPS == 10 ? 100u : 51u, C = (FULL + G - 1u) / G, NL = G * (uint32_t) SPS;
-            static_assert(NL <= DH_WAVE && G * C >= FULL && (G * C - 1u) * SPS + SPS + 1u <= DH_FTILE + 64u, "one lane per phase and chunk; every read stays inside the window block");
-            const bool full_run = m == FULL;
-            DH_LANE_ARRAY(float, psx, 1); DH_LANE_ARRAY(float, psq, 1);
-            if (DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
-                const uint32_t l = (uint32_t) lane < NL ? (uint32_t) lane : 0u;          // (lanes beyond the set repeat lane 0's reads and are not looked at)
-                const uint32_t i = l / G, g = l - G * i;
-                const float* col = fbuf + i;
-                const float* src = col + (int32_t) (g * C * (uint32_t) SPS) + step_off;
-                float s0 = 0.0f, s1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
-#pragma unroll
-                for (uint32_t j = 0; j < C; j++) {
-                    float x = src[j * (uint32_t) SPS];
-                    if (j == 0) x = g == 0u ? col[0] : x;                               // symbol 0 sits in front of the pending step
-                    if (G * C > FULL && j == C - 1u) x = g * C + j < m ? x : 0.0f;      // (the last chunk's spare slot)
-                    else if (!full_run) x = g * C + j < m ? x : 0.0f;
-                    if (j & 1u) { s1 += x; q1 = __builtin_fmaf(x, x, q1); } else { s0 += x; q0 = __builtin_fmaf(x, x, q0); }
-                }
-                DH_LA(psx, lane)[0] = s0 + s1; DH_LA(psq, lane)[0] = q0 + q1;
-            }
-            if (DH_STOP_AFTER >= 3) {
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                float sx = psx[0], sq = psq[0];
-                sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0xB1, 0xF, 0xF, true));      // quad_perm:[1,0,3,2]
-                sq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xB1, 0xF, 0xF, true));
-                if (G == 4) {
-                    sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
-                    sq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x4E, 0xF, 0xF, true));
-                }
-                const uint32_t l = (uint32_t) dh_fresh_lane_id_();
-                if (l < NL && l % G == 0u) {
-                    const uint32_t i = l / G;
-                    S.part[i] = (k0 == 0u ? 0.0f : S.part[i]) + sx;
-                    S.part[(uint32_t) SPS + i] = (k0 == 0u ? 0.0f : S.part[(uint32_t) SPS + i]) + sq;
-                }
-#else
-                for (uint32_t i = 0; i < (uint32_t) SPS; i++) {
-                    float sx, sq;
-                    if (G == 4) {      // what every lane of the quad holds after the two exchanges: (a0 + a1) + (a2 + a3)
-                        sx = (psx[G * i][0] + psx[G * i + 1][0]) + (psx[G * i + 2][0] + psx[G * i + 3][0]);
-                        sq = (psq[G * i][0] + psq[G * i + 1][0]) + (psq[G * i + 2][0] + psq[G * i + 3][0]);
-                    } else { sx = psx[G * i][0] + psx[G * i + 1][0]; sq = psq[G * i][0] + psq[G * i + 1][0]; }
-                    S.part[i] = (k0 == 0u ? 0.0f : S.part[i]) + sx;
-                    S.part[(uint32_t) SPS + i] = (k0 == 0u ? 0.0f : S.part[(uint32_t) SPS + i]) + sq;
-                }
-#endif
-            }
-        }
         DH_BARRIER();
         DH_CLK(2);
-        DH_PROBE(2);
 
-        if (!merged) issue_next_window();
+        issue_next_window();
 
         // ---- P4: sliding AGC min/max as two wave scans
-        if (DH_STOP_AFTER >= 4 && !merged) dh_agc_scan(S, k0, k0 + m);
+        if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
         DH_BARRIER();
         DH_CLK(3);
-        DH_PROBE(3);
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__) && (defined(DH_EXTRA_VALU) || defined(DH_EXTRA_CVT) || defined(DH_EXTRA_LDS) || defined(DH_EXTRA_MFMA) || defined(DH_EXTRA_SALU) || defined(DH_EXTRA_SLEEP))
-        // Diagnostic builds (results unchanged): what does the step time respond to?  n extra instructions of one kind per run,
-        // in independent chains, between the AGC scans and the slicing phase (tools/sensitivity.sh).
-        {
-            float xv[8]; for (int j = 0; j < 8; j++) xv[j] = (float) j;
-#ifdef DH_EXTRA_VALU
-#pragma unroll
-            for (int u = 0; u < DH_EXTRA_VALU; u++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xv[u & 7]));
-#endif
-#ifdef DH_EXTRA_CVT
-#pragma unroll
-            for (int u = 0; u < DH_EXTRA_CVT; u++) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(xv[u & 7]));
-#endif
-#ifdef DH_EXTRA_SALU
-#pragma unroll
-            for (int u = 0; u < DH_EXTRA_SALU; u++) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
-#endif
-#ifdef DH_EXTRA_SLEEP
-            asm volatile("s_sleep %0" :: "n"(DH_EXTRA_SLEEP));        // units of 64 cycles: pure latency, no issue
-#endif
-#ifdef DH_EXTRA_LDS
-            {
-                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) S.xf + 16u * (uint32_t) dh_fresh_lane_id_();
-                dh_u4 sink[4];
-#pragma unroll
-                for (int u = 0; u < DH_EXTRA_LDS; u++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink[u & 3]) : "v"(a), "n"(1024 * (u & 3)));
-                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(sink[0]), "v"(sink[1]), "v"(sink[2]), "v"(sink[3]));
-            }
-#endif
-#ifdef DH_EXTRA_MFMA
-            {
-                dh_f32x4 acc[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-                dh_h8 za = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-                for (int u = 0; u < DH_EXTRA_MFMA; u++) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(za, za, acc[u & 3], 0, 0, 0);
-                asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
-            }
-#endif
-            asm volatile("" :: "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(xv[4]), "v"(xv[5]), "v"(xv[6]), "v"(xv[7]));
-        }
-#endif
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
         // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
         // reference's; those symbols are not stored here but decided exactly below
-#if DH_P5_PAIRED
-        // (runs that start inside a variance block; the others were sliced by the merged phase above)
         // TWO symbols per lane, q = 2 lane and 2 lane + 1 (a run has at most 100): their AGC extremes, window sums and everything
         // derived from them are pairs, so centre, average, the two thresholds and the three distances are packed operations for
         // both symbols -- one pass of ~40 vector instructions instead of two of ~37.  Every operation is the one the one-symbol
         // form performs (same operands, same order), so the dibits and the doubts are the same.
-        if (DH_STOP_AFTER >= 5 && !merged) {
+        if (DH_STOP_AFTER >= 5) {
         uint64_t vote_a = 0, vote_b = 0;
         DH_FOR_LANES_FRESH(lane) {
             const uint32_t qa = 2u * (uint32_t) lane;
@@ -2563,20 +2099,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #ifdef DH_IGNORE_DOUBT
             doubt_a = false; doubt_b = false;
 #endif
-#ifdef DH_P5_NOSTORE
-            if (va && !doubt_a && sa == 77) syms[nsym + qa] = sa;
-            if (vb && !doubt_b && sb == 77) syms[nsym + qa + 1u] = sb;
-#elif DH_P5_SHORT_STORES
             // the lane's two dibits are neighbours: one 16-bit store when the row position is even (wave-uniform) and both are decided
             if (pair_store && va && !doubt_a && vb && !doubt_b) *reinterpret_cast<uint16_t*>(syms + nsym + qa) = (uint16_t) ((uint32_t) sa | ((uint32_t) sb << 8));
             else {
                 if (va && !doubt_a) syms[nsym + qa] = sa;
                 if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
             }
-#else
-            if (va && !doubt_a) syms[nsym + qa] = sa;
-            if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
-#endif
             DH_BALLOT_ACC(vote_a, doubt_a, lane);
             DH_BALLOT_ACC(vote_b, doubt_b, lane);
         }
@@ -2588,51 +2116,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         }
-#else
-#pragma unroll
-        for (uint32_t h = 0; h < 2; h++) {
-        if (h * DH_WAVE < m && DH_STOP_AFTER >= 5 && !merged) {
-        uint64_t vote_unsure = 0;
-        DH_FOR_LANES_FRESH(lane) {
-            const uint32_t q = h * DH_WAVE + (uint32_t) lane;
-            const bool valid = q < m;
-            const uint32_t qq = valid ? q : 0u, k = k0 + qq;                         // (lanes beyond the run recompute symbol 0: in-range reads, no store)
-            const float mn = S.mn[k], mx = S.mx[k];
-            const float center = (mx + mn) / 2.0f;
-            const float sumq = S.sum[qq];
-            const float average = width_pow2 ? sumq * inv_width : sumq / (float) (ev_hi - ev_lo);
-            // (float)((double)(max - center) * 0.625 + center), gfsk_demodulator.cpp:117-118: the product is exact
-            // in double (24 x 3 bits) and the sum is either exact there too or so lopsided that the small term
-            // cannot reach a float rounding boundary (|center| >= 2^-25 |max - center| unless it is 0), so the
-            // double-rounded result equals the single rounding of the exact value: one float FMA.
-            const float umid = __builtin_fmaf(mx - center, 0.625f, center);
-            const float lmid = __builtin_fmaf(mn - center, 0.625f, center);
-            const bool above = average > center;
-            const uint8_t sym4 = above ? (average > umid ? 1 : 0) : (average < lmid ? 3 : 2);
-            const uint8_t sym2 = LV == 4 ? (uint8_t) 0 : above ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
-            const uint8_t sym = four_levels ? sym4 : sym2;
-            bool doubt = false;
-            if (BOUNDED) {
-                // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
-                // reference's; those symbols are not stored here but decided exactly below
-                const float d_mid = __builtin_fminf(__builtin_fabsf(average - umid), __builtin_fabsf(average - lmid));
-                const float d_all = __builtin_fminf(four_levels ? d_mid : DH_FLT_MAX, __builtin_fabsf(average - center));
-                doubt = valid && e_pos && !(d_all > T_eff);                            // (!(d > T): a NaN distance is a doubt)
-            }
-#ifdef DH_IGNORE_DOUBT                      // diagnostic builds: undecided symbols are NOT re-evaluated (wrong in a few symbols per 100 000; what do the exact evaluations cost?)
-            doubt = false;
-#endif
-#ifdef DH_P5_NOSTORE                        // diagnostic builds: the dibits are computed but (practically) never stored -- what do the byte stores cost?
-            if (valid && !doubt && sym == 77) syms[nsym + q] = sym;
-#else
-            if (valid && !doubt) syms[nsym + q] = sym;
-#endif
-            DH_BALLOT_ACC(vote_unsure, doubt, lane);
-        }
-        unsure[h] = vote_unsure;
-        }
-        }
-#endif
         if (BOUNDED && DH_UNLIKELY((unsure[0] | unsure[1]) != 0)) {
             DhExactCtx C;
             C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
@@ -2655,15 +2138,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
 
-        if (CAN_MERGE && merged) {                     // the merged phase's volumes into the ring (the exact evaluations above still saw the old entries)
-            DH_FOR_LANES_FRESH(lane) {
-                const uint32_t qa = 2u * (uint32_t) lane;
-                if (qa < m) S.vol_old[qa] = DH_LA(mg_volume, lane)[0].x;
-                if (qa + 1u < m) S.vol_old[qa + 1u] = DH_LA(mg_volume, lane)[0].y;
-            }
-        }
         DH_CLK(4);
-        DH_PROBE(4);
         // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
         // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
         // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
@@ -2690,60 +2165,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             // kernels, the exact recomputation of the ring in front of it) only has to look at these rows.  All rows when no
             // valid set of intervals exists (no estimate, NaN / overflow, an estimate of exactly 0).
             uint64_t chain_rows = ~0ull;
-            if constexpr (RINGLESS) {
-                // The estimate from the block's per-phase sums (P3b): V' = Q' / 100 - mean'^2 as in the ring kernels' one-pass form
-                // below, whose derivation carries over with longer chains -- 13 fused terms per chain, one addition of the two
-                // chains, two (sps 10) or one (sps 20) in the quad, and one per further piece when the block was cut by the end of
-                // a run or push (at most 4 pieces are admitted): 21.4 u on Q' and on the sum, hence |V' - sigma^2| <= (3 x 21.4 + 1) u m2
-                // = 3.9e-6 m2, taken as 5e-6.  A block whose windows were all zeros has vmin = 0 exactly.  Everything else -- more
-                // pieces, ties, an estimate of exactly 0, NaN / overflow -- goes to the chain, which recomputes the block's samples.
-                const uint32_t bf = dh_uniform(BS->blk_flags), pieces = (bf >> 8) & 255u;
-                if (P.ordered_timing) {
-                } else if (!(bf & 4u)) {
-                    ordered = false;                            // a hundred symbols of exact zeros: vmin == 0, no step
-                } else if (pieces <= 4u) {
-                    DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
-                    uint64_t vote_guard = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
-                    DH_FOR_LANES_FRESH(lane) {
-                        float l = DH_FLT_MAX, h = DH_FLT_MAX;
-                        bool guard = true;
-                        if (lane < SPS) {
-                            const float total = S.part[lane], e = S.part[SPS + lane] * 0.01f;      // e = mean x^2
-                            const float mean = total * 0.01f;
-                            const float v = __builtin_fmaf(-mean, mean, e);
-                            float tol = __builtin_fmaf(e, 5e-6f, 1e-42f);
-                            if (e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;      // (see the ring kernels' estimate)
-                            guard = e < 1e30f && v != 0.0f;      // false for NaN / overflow, and for an estimate of exactly 0 (which proves nothing)
-                            l = v - tol; h = v + tol;
-                        }
-                        DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
-                        DH_BALLOT_ACC(vote_guard, guard, lane);
-                        DH_BALLOT_ACC(vote_pos, l > 0.0f, lane);
-                        DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
-                    }
-                    float hmin;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                    hmin = SPS <= 16 ? dh_row_min_to_lane15(hi[0]) : -dh_wave_max(-hi[0]);
-#else
-                    hmin = DH_FLT_MAX;
-                    for (int q = 0; q < SPS; q++) hmin = dh_fmin_(hmin, hi[q][0]);
-#endif
-                    DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
-                    const uint64_t phases = (1ull << SPS) - 1ull;
-                    const uint64_t cand = ~vote_above & phases;         // phases whose interval reaches below the smallest upper end
-                    if ((vote_guard & phases) != phases) {
-                    } else if (dh_popc64(cand) == 1 && (vote_pos & cand) && (vote_small & cand)) {
-                        ordered = false;
-                        const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
-                        if (vmin_pos > 0 && vmin_pos < (uint32_t) SPS / 2u) new_off = +1;
-                        else if (vmin_pos >= (uint32_t) SPS / 2u && vmin_pos < (uint32_t) SPS - 1u) new_off = -1;
-                    } else if (SPS != 10 && cand != 0) {
-                        chain_rows = cand;                      // (sps 10: not handed on -- one more live value costs that kernel scratch accesses in its hot loop)
-                    }
-                }
-            }
             bool est_done = false;
-#if DH_P6_LEAN
             // The same estimate without its LDS exchange and with two votes instead of six.  Lane 16 r + 5 j + g takes piece g (20
             // symbols) of phase i = 3 r + j -- three phases per DPP row, so that the five partial sums of a phase are five neighbouring
             // lanes of one row and meet through row_shr (lane g = 4 of each group: ((s4 + s3) + (s2 + s1)) + s0, three roundings
@@ -2752,7 +2174,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             // lane is either ruled out or positive and below 5e6) are the only votes: one candidate and every lane fine is the case
             // decided here -- everything else (an estimate of exactly 0, NaN / overflow, ties) is left to the full form below, which
             // starts over.  ~100 instructions instead of ~260 per block.
-            if (!RINGLESS && SPS == 10 && !P.ordered_timing) {
+            if (SPS == 10 && !P.ordered_timing) {
                 DH_LANE_ARRAY(float, gs, 1); DH_LANE_ARRAY(float, gq, 1);
                 DH_FOR_LANES_FRESH(lane) {
                     const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
@@ -2831,11 +2253,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                     else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
                 }
             }
-#endif
-            if (!RINGLESS && SPS == 10 && !P.ordered_timing && !est_done) {
-#ifdef DH_DBG_P6_COUNT
-                if (BOUNDED) BS->n_exact_runs++;              // diagnostic builds: how often does the lean estimate hand over?  (header word 17)
-#endif
+            if (SPS == 10 && !P.ordered_timing && !est_done) {
                 DH_BARRIER();                                   // mn / mx are dead from here: scratch
                 float* psum = S.mn; float* pd = S.mx;
                 // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
@@ -2934,7 +2352,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // (the candidates are not handed on here: one more live value costs the 81-tap kernels four scratch accesses in
                 // their hot loop, and they reach this point in 0.02 % of the blocks -- the 161-tap, sps-20 kernel in 1.3 %)
             }
-            if (!RINGLESS && ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
+            if (ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
                 // (sps 33 .. 64, e.g. POCSAG's 40: one lane per phase, chains of 100 + 1 fused terms -- (1 + u)^102 - 1 < 6.1e-6, still
                 // inside the 8e-6 V' below; the float mean is then the reference's own chain, within 100.1 u A of the true one.  The
                 // in-order double chain cost that slicer a fifth of its time, every block.)
@@ -3037,7 +2455,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 // by |2 cov(x, d) + var(d)| <= 2 e sigma + e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken
                 // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
                 // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
-                const bool approx_ring = BOUNDED && (e_blk > 0.0f || RINGLESS);      // (ring-less: there is no ring at all -- the block's samples are always recomputed)
+                const bool approx_ring = BOUNDED && e_blk > 0.0f;
                 for (int attempt = (approx_ring && SPS != 10 && sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
                     DH_BARRIER();
                     if (approx_ring && attempt == 1) {
@@ -3053,7 +2471,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         BS->n_exact_blocks++;
                         DH_BARRIER();
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                        if (RINGLESS) __syncthreads();          // the recomputed samples went to scratch in HBM: the chain below reads them back
 #endif
                     }
                     DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1); DH_LANE_ARRAY(uint32_t, iv_ok, 1);
@@ -3134,47 +2551,16 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
 
         DH_CLK(5);
-        DH_PROBE(5);
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
         DH_FOR_LANES_FRESH(lane) {
-            if (!merged) {                              // (the merged phase committed its volumes from registers)
-                // a run has at most 100 symbols: two predicated copies per lane, both loads in flight together (as a loop this was
-                // two trips of exec-mask bookkeeping with a wait in each)
-                const uint32_t ka = k0 + (uint32_t) lane, kb = ka + DH_WAVE, ke = k0 + m;
-                const float va_ = S.vol_new[ka < ke ? ka : k0], vb_ = S.vol_new[kb < ke ? kb : k0];
-                if (ka < ke) S.vol_old[ka] = va_;
-                if (kb < ke) S.vol_old[kb] = vb_;
-            }
-#if DH_PF_L2
-            (void) pf_have;
-#else
-            if (pf_plain && pf_have >= DH_FTILE + NZ) {         // the usual case: a full window, stored as loaded
-#pragma unroll
-                for (int r = 0; r < DH_PF_N; r++) {
-                    const uint32_t e = 4u * (uint32_t) lane + 4u * DH_WAVE * (uint32_t) r;
-                    if (e < DH_FTILE + NZ) dh_store4(&S.xf[DH_XP(e)], DH_LA(pf, lane)[r]);
-                }
-            } else if (pf_plain) {                              // last window of the push: zeros beyond the input
-                uint32_t l4 = 4u * (uint32_t) lane;
-                DH_TO_VGPR(l4);                                 // recomputed here, not hoisted (and spilled) across the FIR
-#pragma unroll
-                for (int r = 0; r < DH_PF_N; r++) {
-                    const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
-                    if (e < DH_FTILE + NZ) {
-                        dh_f4 v = DH_LA(pf, lane)[r];
-                        v.x = e + 0u < pf_have ? v.x : 0.0f; v.y = e + 1u < pf_have ? v.y : 0.0f;
-                        v.z = e + 2u < pf_have ? v.z : 0.0f; v.w = e + 3u < pf_have ? v.w : 0.0f;
-                        dh_store4(&S.xf[DH_XP(e)], v);
-                    }
-                }
-            }
-#endif
+            // a run has at most 100 symbols: two predicated copies per lane, both loads in flight together (as a loop this was
+            // two trips of exec-mask bookkeeping with a wait in each)
+            const uint32_t ka = k0 + (uint32_t) lane, kb = ka + DH_WAVE, ke = k0 + m;
+            const float va_ = S.vol_new[ka < ke ? ka : k0], vb_ = S.vol_new[kb < ke ? kb : k0];
+            if (ka < ke) S.vol_old[ka] = va_;
+            if (kb < ke) S.vol_old[kb] = vb_;
         }
-#if DH_PF_L2
         staged = false;
-#else
-        staged = pf_plain; staged_p = p_next;
-#endif
         if (DH_LIKELY(pf_reg)) {
             if constexpr (PF_REG) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = p_next; }
         }
@@ -3192,14 +2578,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else { BS->e_cur = ec; BS->e_count = cnt; }
             if (block_done) { BS->prev_start = BS->cur_start; BS->prev_off = BS->cur_off; BS->blk_flags = (BS->blk_flags & 1u) ? 2u : 0u; }
         }
-#if !DH_TAPFRAG_LATE
         DH_TAPFRAG_LOAD();                              // for the next run
-#endif
         DH_CLK(6);
-        DH_PROBE(6);
     }
 
-#if DH_PF_L2 && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // a last L2-touch load may still be writing into the window block
 #endif
     if constexpr (KEEPF) {
@@ -3220,8 +2603,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const uint32_t new_tc = nv - base;                 // = history + unread filtered samples + NZ
     DH_FOR_LANES(lane) {
         for (uint32_t j = lane; j < DH_VOLUME_RB_SIZE; j += DH_WAVE) st[DH_ST_VOL + j] = S.vol_old[j];
-        if (!RINGLESS) { for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) st[DH_ST_VAR + j] = S.var_rb[j]; }
-        else { for (uint32_t j = lane; j < 2u * sps; j += DH_WAVE) st[dh_state_part_offset(sps) + j] = S.part[j]; }
+        for (uint32_t j = lane; j < DH_VARIANCE_SYMBOLS * sps; j += DH_WAVE) st[DH_ST_VAR + j] = S.var_rb[j];
     }
     // the tail may overlap its own source when base < tc: in chunks through LDS (a chunk is read completely before any of
     // it is written, and later chunks only read further ahead)
@@ -3254,14 +2636,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 st[DH_ST_E_CUR] = BS->e_cur; st[DH_ST_E_PREV] = BS->e_prev; st[DH_ST_E_BLOCK] = BS->e_blk;
                 sth[DH_ST_UNCERTAIN] += BS->n_uncertain; sth[DH_ST_EXACT_RUNS] += BS->n_exact_runs; sth[DH_ST_EXACT_BLOCKS] += BS->n_exact_blocks;
             }
-#ifdef DH_PHASE_CLOCKS
-            for (int i = 0; i < 8; i++) sth[DH_ST_DIAG + i] += S.clk[i] >> 6;
-#endif
-#if defined(DH_WAVE_TIMELINE) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            sth[DH_ST_DIAG + 10] = dh_t_start; sth[DH_ST_DIAG + 11] = (uint32_t) wall_clock64();
-            sth[DH_ST_DIAG + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
-            sth[DH_ST_DIAG + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
-#endif
 
             sth[DH_ST_ORDERED] += S.stats[1];
             P.sym_count[ch] = nsym;

@@ -32,40 +32,22 @@ int hip_fail(hipError_t e, const char* what) {
 #define DH_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))        // an opaque copy: the compiler must not tie it to an earlier computation of the same value
 #define HIP_TRY(expr) do { if (hip_fail((expr), #expr)) return DH_EDEVICE; } while (0)
 
-#ifndef DH_TILE_LB
 #define DH_TILE_LB 3
-#endif
-#ifndef DH_TILES_PER_WG
 #define DH_TILES_PER_WG 4
-#endif
-#ifndef DH_LB_NARROW
 #define DH_LB_NARROW 3   // the 161-tap kernels: 168 VGPRs (their fused FIR fits; the rounded one, now the rare path, spills a little)
-#endif
-#ifndef DH_SPLIT_MIN_CHANNELS
 #define DH_SPLIT_MIN_CHANNELS 8192   // DH_FLAG_OVERLAP_PUSHES takes effect for engines at least this large (HipBackend::go_chain)
-#endif
-#ifndef DH_TAIL_SPLIT_PCT
 #define DH_TAIL_SPLIT_PCT 80
-#endif
-#ifndef DH_TAIL_SPLIT_PCT2
 #define DH_TAIL_SPLIT_PCT2 0       // a third workgroup per channel from this percentage on (0 = two parts)
-#endif
-#ifndef DH_TAIL_SPLIT_MIN_CHANNELS
 #define DH_TAIL_SPLIT_MIN_CHANNELS 8192     // the tail split of the chain kernels (HipBackend::go_chain) takes effect for launches at least this wide ...
-#endif
-#ifndef DH_TAIL_SPLIT_MIN_SAMPLES
 #define DH_TAIL_SPLIT_MIN_SAMPLES 65536     // ... and pushes at least this long
-#endif
-#ifndef DH_LB
 #define DH_LB 4          // minimum waves per SIMD the wide-filter kernels are register-budgeted for (128 VGPRs)
-#endif
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
 // KEEPF: the launch also delivers the filtered samples (DhDspParams::filt_out; BASELINE configs[1] in one kernel)
 template <int NZ, bool FAST, int SPS, bool KEEPF = false>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
-    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
+    DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
     dh_rrc_demod_channel<NZ, FAST, SPS, 0, KEEPF>(P, blockIdx.x, S);
 }
 
@@ -139,18 +121,13 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
         sym_base = dh_uniform(__hip_atomic_load(P.sym_count + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     {
-        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
+        DhDspShared L = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
         dh_rrc_demod_channel<NZ, FAST, SPS, (PROTO == DH_PROTO_DSTAR ? 2 : 4)>(P, ch, L, part_lo, part_hi, sym_base);      // (launch_chain checked P.levels)
     }
     // This wavefront's symbol / count stores are read back by its own decoder half below: a WORKGROUP-scope fence (part of
     // __syncthreads) orders them.  A device-scope __threadfence() here made every wavefront write back its XCD's L2 --
     // 16 384 times per launch, 0.7 ms of a push of 4 752 samples (tools/push_size.py).
     __syncthreads();
-#if DH_PRIO_MODE >= 1 && DH_PRIO_MODE <= 5
-    DH_SETPRIO(3);
-#elif DH_PRIO_MODE >= 6 && DH_PRIO_MODE <= 7
-    if (ch + (DH_PRIO_MODE == 6 ? 4096u : 8192u) >= P.n_channels) DH_SETPRIO(3);
-#endif
     DhDecShared& S = *reinterpret_cast<DhDecShared*>(dh_smem);
 #ifdef DH_SKIP_DECODER                      // diagnostic builds (tools/phase_budget.sh): the slicer half alone (the hand-over of the tail split still takes place)
     if (!P.n_channels)
@@ -224,9 +201,7 @@ __global__ __launch_bounds__(DH_WAVE) void k_pocsag(const DhDecParams P) {
     dh_pocsag_channel(P, blockIdx.x, S);
 }
 
-#ifndef DH_DSTAR_LB
 #define DH_DSTAR_LB 4
-#endif
 __global__ __launch_bounds__(DH_WAVE, DH_DSTAR_LB) void k_dstar(const DhDecParams P) {
     __shared__ DhDecShared S;
     dh_dstar_channel(P, blockIdx.x, S);
@@ -294,45 +269,6 @@ __global__ void k_dvfilter(const int16_t* in, int16_t* out, float* state, size_t
     if (ch < B) dh_dvfilter_channel(in + ch * stride, out + ch * stride, state + ch * 22, n);
 }
 
-// Front-end in two launches: the conversion / discriminator has no dependence between samples (every sample looks at its
-// predecessor's I / Q only) and runs one sample per lane over the whole batch; only the DC blocker is a recurrence, one
-// channel per lane, four samples per load and store.  Same arithmetic as dh_frontend_channel (the CPU harness runs that).
-__global__ __launch_bounds__(256) void k_fe_convert(const int16_t* in, size_t in_stride, float* out, size_t out_stride, const float* state, size_t n, int mode) {
-    const size_t ch = blockIdx.y;
-    const int16_t* row = in + ch * in_stride;
-    const int32_t ip0 = (int32_t) state[ch * DH_FE_STATE_WORDS + 2], qp0 = (int32_t) state[ch * DH_FE_STATE_WORDS + 3];
-    for (size_t t = blockIdx.x * (size_t) blockDim.x + threadIdx.x; t < n; t += (size_t) gridDim.x * blockDim.x)
-        out[ch * out_stride + t] = dh_fe_convert(row, t, mode, ip0, qp0);
-}
-__global__ __launch_bounds__(64) void k_fe_dcblock(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock) {
-    const size_t ch = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
-    if (ch >= B) return;
-    float* row = out + ch * out_stride;
-    float* st = state + ch * DH_FE_STATE_WORDS;
-    float xp = st[0], yp = st[1];
-    size_t t = 0;
-    if (dcblock) {
-#define DH_FE_STEP(c) do { const float d_ = (c) - xp; const float f_ = 0.995f * yp; yp = d_ + f_; xp = (c); (c) = yp; } while (0)
-        // 32 samples per trip, their eight loads in flight together, and the next trip's loads issued before this
-        // trip's arithmetic: a lane walks its own row (nothing coalesces across lanes), so latency is what has to be hidden
-        constexpr int U = 8;
-        dh_f4 cur[U], nxt[U];
-        if (n >= 4 * U) for (int u = 0; u < U; u++) cur[u] = dh_load4_unaligned(row + 4 * u);
-        for (; t + 4 * U <= n; t += 4 * U) {
-            const bool more = t + 8 * U <= n;
-            if (more) for (int u = 0; u < U; u++) nxt[u] = dh_load4_unaligned(row + t + 4 * U + 4 * u);
-            for (int u = 0; u < U; u++) {
-                DH_FE_STEP(cur[u].x); DH_FE_STEP(cur[u].y); DH_FE_STEP(cur[u].z); DH_FE_STEP(cur[u].w);
-                dh_store4_unaligned(row + t + 4 * u, cur[u]);
-            }
-            if (more) for (int u = 0; u < U; u++) cur[u] = nxt[u];
-        }
-        for (; t < n; t++) { const float x = row[t]; const float d = x - xp; const float f = 0.995f * yp; yp = d + f; xp = x; row[t] = yp; }
-    } else if (n) { xp = row[n - 1]; yp = xp; }
-    st[0] = xp; st[1] = yp;
-    if (mode == DH_FE_IQ_S16 && n) { st[2] = (float) in[ch * in_stride + 2 * n - 2]; st[3] = (float) in[ch * in_stride + 2 * n - 1]; }
-}
-
 // The front-end in ONE launch (round 3): a workgroup of five wavefronts takes DH_FE_CH channels through tiles of DH_FE_TS
 // samples, double-buffered.  Per tile: every thread of wavefronts 1..4 converts DH_FE_SPT consecutive samples of one channel (int16 audio, or I / Q pairs through the
 // polar discriminator -- 16-byte loads, 128 contiguous bytes per channel and instruction) into an LDS tile; the first
@@ -340,12 +276,8 @@ __global__ __launch_bounds__(64) void k_fe_dcblock(const int16_t* in, size_t in_
 // and writing the result back in place; every thread stores four floats of one channel (coalesced 512-byte rows).  No float
 // round trip through HBM, int16 in -> float out: 4 + 4 bytes per sample instead of 4 + 4 + 4 + 4 + a second launch.
 // Same arithmetic, operation for operation, as dh_frontend_channel (the CPU harness runs that; oracle/frontend.c is the checker).
-#ifndef DH_FE_CH
 #define DH_FE_CH 16
-#endif
-#ifndef DH_FE_TS
 #define DH_FE_TS 128
-#endif
 #define DH_FE_SPT (DH_FE_CH * DH_FE_TS / 256)          // samples a thread converts per tile (a multiple of 4)
 // (four dwords from a row that is only promised to be 4-byte aligned: the plain vector type would tell the compiler 16)
 typedef uint32_t dh_u4w __attribute__((ext_vector_type(4), aligned(4)));
@@ -745,7 +677,7 @@ struct HipBackend {
     }
 
     template <int NZ, bool FAST, int SPS, bool KEEPF = false> int go_rrc_demod(const DhDspParams& P) {
-        const size_t lds = dh_dsp_shared_bytes(P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
+        const size_t lds = dh_dsp_shared_bytes(P.sps, NZ);
         if (lds > 48 * 1024) {
             if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS, KEEPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
                          "hipFuncSetAttribute")) return -1;
@@ -767,11 +699,8 @@ struct HipBackend {
         return -1;
     }
     template <int NZ, bool FAST, int PROTO, int SPS = 10, bool MAY_SPLIT = false> int go_chain(const DhDspParams& P, const DhDecParams& D) {
-        size_t lds = dh_dsp_shared_bytes(SPS ? (uint32_t) SPS : P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
+        size_t lds = dh_dsp_shared_bytes(SPS ? (uint32_t) SPS : P.sps, NZ);
         if (lds < sizeof(DhDecShared)) lds = sizeof(DhDecShared);
-#ifdef DH_LDS_PAD
-        lds += DH_LDS_PAD;                  // occupancy experiments (tools/build_variant.sh)
-#endif
         if constexpr (MAY_SPLIT) {
             if (overlap_pushes && P.n_channels >= DH_SPLIT_MIN_CHANNELS && side_ready()) {
                 const uint32_t first = (P.n_channels - P.n_channels / 4u) & ~63u;       // three quarters, whole multiples of 64
@@ -957,19 +886,8 @@ static int dh_be_dvfilter(const int16_t* in, int16_t* out, float* state, size_t 
 
 static int dh_be_frontend(const int16_t* in, size_t in_stride, float* out, size_t out_stride, float* state, size_t B, size_t n, int mode, int dcblock, void* stream) {
     if (!B || !n) return DH_OK;
-#ifdef DH_FE_TWO_LAUNCHES                   // (round 2's pair of kernels, kept for A/B: tools/build_variant.sh)
-    const unsigned gx = (unsigned) std::min<size_t>((n + 1023) / 1024, 64);
-    for (size_t b0 = 0; b0 < B; b0 += 65535) {              // channels on grid.y: at most 65 535 per launch
-        const size_t nb = std::min<size_t>(B - b0, 65535);
-        hipLaunchKernelGGL(k_fe_convert, dim3(gx, (unsigned) nb), dim3(256), 0, (hipStream_t) stream, in + b0 * in_stride, in_stride, out + b0 * out_stride, out_stride, (const float*) state + b0 * DH_FE_STATE_WORDS, n, mode);
-        HIP_TRY(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_fe_dcblock, dim3((unsigned) ((B + 63) / 64)), dim3(64), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
-    HIP_TRY(hipGetLastError());
-#else
     hipLaunchKernelGGL(k_fe_fused, dim3((unsigned) ((B + DH_FE_CH - 1) / DH_FE_CH)), dim3(320), 0, (hipStream_t) stream, in, in_stride, out, out_stride, state, B, n, mode, dcblock);
     HIP_TRY(hipGetLastError());
-#endif
     return DH_OK;
 }
 

@@ -148,14 +148,37 @@ DH_HD void dh_trellis_wave(const uint8_t* in, size_t in_stride, int n_dibits, ui
         }
     }
     DH_BARRIER();
-    dh_viterbi_wave(S, sizes);
+    // 100-dibit codewords (FICH, V/D2 DCH): the clean-codeword check of the YSF decoder (dh_ysf_clean100), one codeword per lane -- a
+    // codeword with a zero syndrome leaves with its message and metric 0, the full decoder only sees the others
+    uint64_t clean = 0;
+    if (n_dibits == 100) {
+        DH_FOR_LANES(lane) {
+            bool ok = false;
+            if (lane < 4 && wave * 4 + (size_t) lane < n) {
+                uint32_t h[4] = { 0, 0, 0, 0 }, l[4] = { 0, 0, 0, 0 }, o[4];
+                for (int i = 0; i < 100; i++) {
+                    const uint32_t d = (S.vit_in[lane][i >> 2] >> (8 * (i & 3))) & 3u;     // one dibit per byte (dh_vit_word)
+                    h[i >> 5] |= (d >> 1) << (i & 31); l[i >> 5] |= (d & 1u) << (i & 31);
+                }
+                ok = !dh_ysf_clean100(h, l, o);
+                if (ok) {
+                    const size_t cw = wave * 4 + (size_t) lane;
+                    for (int b = 0; b < 13; b++) out[cw * out_stride + b] = (uint8_t) (o[b >> 2] >> (8 * (b & 3)));
+                    metric[cw] = 0;
+                }
+            }
+            DH_BALLOT_ACC(clean, ok, lane);
+        }
+        for (int g = 0; g < 4; g++) if ((clean >> g) & 1ull) sizes[g] = 0;
+    }
+    if (sizes[0] | sizes[1] | sizes[2] | sizes[3]) dh_viterbi_wave(S, sizes);
     DH_FOR_LANES(lane) {
         for (int e = lane; e < 4 * nout; e += DH_WAVE) {
             const int g = e / nout, b = e % nout;
             const size_t cw = wave * 4 + g;
-            if (cw < n) out[cw * out_stride + b] = S.vit_out[g][b];
+            if (cw < n && !((clean >> g) & 1ull)) out[cw * out_stride + b] = S.vit_out[g][b];
         }
-        if (lane < 4 && wave * 4 + lane < n) metric[wave * 4 + lane] = S.vit_best_metric[lane];
+        if (lane < 4 && wave * 4 + lane < n && !((clean >> lane) & 1ull)) metric[wave * 4 + lane] = S.vit_best_metric[lane];
     }
     DH_BARRIER();
 }

@@ -50,8 +50,8 @@ struct HostBackend {
     bool overlap_pushes = false;                     // (a property of the GPU dispatcher; nothing to emulate)
 
     template <int NZ, bool FAST, int SPS, bool KEEPF = false> static void run_rrc_demod(const DhDspParams& P) {
-        std::vector<float> lds(dh_dsp_shared_bytes(P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value) / sizeof(float));     // exactly the device allocation
-        DhDspShared S = dh_dsp_carve(lds.data(), P.sps, NZ, DhIsRingless<NZ, FAST, SPS>::value);
+        std::vector<float> lds(dh_dsp_shared_bytes(P.sps, NZ) / sizeof(float));     // exactly the device allocation
+        DhDspShared S = dh_dsp_carve(lds.data(), P.sps, NZ);
         for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST, SPS, 0, KEEPF>(P, ch, S);
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
@@ -106,8 +106,8 @@ struct HostBackend {
             const uint32_t b0 = std::max<uint32_t>(1u, (uint32_t) ((uint64_t) P.n * pct / 100u));
             const uint32_t b1 = pct2 ? std::max<uint32_t>(b0, (uint32_t) ((uint64_t) P.n * pct2 / 100u)) : 0u;
             const uint32_t lo[3] = { 0u, b0, b1 }, hi[3] = { b0, b1 ? b1 : 0xFFFFFFFFu, 0xFFFFFFFFu };
-            std::vector<float> lds(dh_dsp_shared_bytes(P.sps, 80, DhIsRingless<80, false, 10>::value) / sizeof(float));
-            DhDspShared S = dh_dsp_carve(lds.data(), P.sps, 80, DhIsRingless<80, false, 10>::value);
+            std::vector<float> lds(dh_dsp_shared_bytes(P.sps, 80) / sizeof(float));
+            DhDspShared S = dh_dsp_carve(lds.data(), P.sps, 80);
             DhDecShared* DS = new DhDecShared;
             // DH_TAIL_SPLIT_FORCE_FAIL = k: the later parts of the channels with ch % k == 1 "fail" their hand-over, and what the
             // device's fix-up launch does is done here -- the rest of the row in one piece behind the first part
