@@ -1289,16 +1289,48 @@ DH_HD void dh_transpose_5x20(const uint32_t* x, uint32_t* y) {
         }
     }
 }
-// one 100-dibit codeword given as its two bit streams: true = not a codeword (the full decoder must look at it); otherwise the 100
-// message bits as the 13 bytes trellis.c:55-56,84 writes (first bit in the MSB of byte 0), in four words
-DH_HD bool dh_ysf_clean100(const uint32_t* h, const uint32_t* l, uint32_t* out4) {
+// one 100-dibit codeword given as its two bit streams: true = the full decoder must look at it; otherwise the 100 message bits as the
+// 13 bytes trellis.c:55-56,84 writes (first bit in the MSB of byte 0), in four words, and the metric the reference returns.
+// Two cases are settled here:
+//   * zero syndrome: a codeword (the argument above), metric 0;
+//   * ONE wrong dibit at position p, 16 <= p <= 88.  A wrong bit 1 at p shows in the syndrome at p, p + 1, p + 2, p + 4 (h G2), a wrong
+//     bit 0 at p, p + 3, p + 4 (l G1), both together at p + 1, p + 2, p + 3 -- a syndrome that is exactly one of these three patterns
+//     puts the received word within w = 1 or 2 bits of the codeword c with that dibit flipped back.  The reference returns c: the code
+//     is linear with free distance 7, every competitor c' that has merged with c around p costs w + d(c, c') > w, and one that has not
+//     -- a detour inside the block (>= 7), a different start state not yet merged at step p (f_start(p + 1) >= 5 for p >= 14), a
+//     divergence still open at the block's end (f_end(100 - p) >= 5 for p <= 91) -- costs at least d(c, c') - w >= 5 - 2 > w, so c is
+//     the unique best path into every state it passes and the unique best end state, whatever the tie rules (tools/trellis_margin.py
+//     computes f_start / f_end; no metric wraps in 100 steps).  Its metric is w.
+// tests/test_fec.py runs every position and pattern of single dibits, from every start state, against the reference compiled in place.
+#define DH_YSF_REPAIR_LO 16
+#define DH_YSF_REPAIR_HI 88
+DH_HD bool dh_ysf_clean100(const uint32_t* h, const uint32_t* l, uint32_t* out4, uint32_t* metric = nullptr) {
     DhU128 H, L;
     H.lo = (uint64_t) h[1] << 32 | h[0]; H.hi = (uint64_t) h[3] << 32 | h[2];
     L.lo = (uint64_t) l[1] << 32 | l[0]; L.hi = (uint64_t) l[3] << 32 | l[2];
     // syndrome, checks t = 4 .. 99
-    const DhU128 syn = dh_u128_xor(dh_u128_xor(dh_u128_xor(H, dh_u128_shl(H, 1)), dh_u128_xor(dh_u128_shl(H, 2), dh_u128_shl(H, 4))),
-                                   dh_u128_xor(dh_u128_xor(L, dh_u128_shl(L, 3)), dh_u128_shl(L, 4)));
-    const bool dirty = ((syn.lo & ~0xFull) | (syn.hi & ((1ull << 36) - 1ull))) != 0ull;
+    DhU128 syn = dh_u128_xor(dh_u128_xor(dh_u128_xor(H, dh_u128_shl(H, 1)), dh_u128_xor(dh_u128_shl(H, 2), dh_u128_shl(H, 4))),
+                             dh_u128_xor(dh_u128_xor(L, dh_u128_shl(L, 3)), dh_u128_shl(L, 4)));
+    syn.lo &= ~0xFull; syn.hi &= (1ull << 36) - 1ull;
+    bool dirty = (syn.lo | syn.hi) != 0ull;
+    uint32_t m = 0;
+    if (dirty) {
+        const uint32_t t0 = syn.lo ? (uint32_t) dh_ffs64(syn.lo) : 64u + (uint32_t) dh_ffs64(syn.hi);      // the first failing check
+        uint64_t five;                                             // checks t0 .. t0 + 4
+        if (t0 < 64u) five = (syn.lo >> t0) | (t0 > 59u ? syn.hi << (64u - t0) : 0ull); else five = syn.hi >> (t0 - 64u);
+        const uint32_t pat = (uint32_t) five & 31u;
+        // nothing beyond those five?
+        uint64_t rest_lo = syn.lo, rest_hi = syn.hi;
+        if (t0 < 64u) { rest_lo &= ~(31ull << t0); if (t0 > 59u) rest_hi &= ~(31ull >> (64u - t0)); } else rest_hi &= ~(31ull << (t0 - 64u));
+        const bool eh = pat == 0x17u || pat == 0x07u, el = pat == 0x19u || pat == 0x07u;
+        const uint32_t p = pat == 0x07u ? t0 - 1u : t0;
+        if ((rest_lo | rest_hi) == 0ull && (eh || el) && p >= DH_YSF_REPAIR_LO && p <= DH_YSF_REPAIR_HI) {
+            const uint64_t bit_lo = p < 64u ? 1ull << p : 0ull, bit_hi = p < 64u ? 0ull : 1ull << (p - 64u);
+            if (eh) { H.lo ^= bit_lo; H.hi ^= bit_hi; m++; }
+            if (el) { L.lo ^= bit_lo; L.hi ^= bit_hi; m++; }
+            dirty = false;
+        }
+    }
     // message bits 0 .. 97 by the inverse, 98 and 99 from G1 on bits that are then known
     DhU128 U = dh_u128_xor(dh_u128_xor(dh_u128_xor(dh_u128_shr(H, 2), dh_u128_shr(H, 1)), H), dh_u128_xor(dh_u128_shr(L, 2), L));
     U.hi &= (1ull << 34) - 1ull;
@@ -1310,6 +1342,7 @@ DH_HD bool dh_ysf_clean100(const uint32_t* h, const uint32_t* l, uint32_t* out4)
         const uint32_t r = dh_brev32(u[j]);                    // bit i -> 31 - i: the bytes in reverse order, each with its first bit on top
         out4[j] = (r >> 24) | ((r >> 8) & 0xFF00u) | ((r << 8) & 0xFF0000u) | (r << 24);
     }
+    if (metric) *metric = m;
     return dirty;
 }
 

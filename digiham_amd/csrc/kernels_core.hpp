@@ -148,8 +148,9 @@ DH_HD void dh_trellis_wave(const uint8_t* in, size_t in_stride, int n_dibits, ui
         }
     }
     DH_BARRIER();
-    // 100-dibit codewords (FICH, V/D2 DCH): the clean-codeword check of the YSF decoder (dh_ysf_clean100), one codeword per lane -- a
-    // codeword with a zero syndrome leaves with its message and metric 0, the full decoder only sees the others
+    // 100-dibit codewords (FICH, V/D2 DCH): the syndrome check of the YSF decoder (dh_ysf_clean100), one codeword per lane -- a codeword
+    // with a zero syndrome, or with one wrong dibit away from the block's ends, leaves with its message and metric; the full decoder only
+    // sees the others
     uint64_t clean = 0;
     if (n_dibits == 100) {
         DH_FOR_LANES(lane) {
@@ -160,11 +161,12 @@ DH_HD void dh_trellis_wave(const uint8_t* in, size_t in_stride, int n_dibits, ui
                     const uint32_t d = (S.vit_in[lane][i >> 2] >> (8 * (i & 3))) & 3u;     // one dibit per byte (dh_vit_word)
                     h[i >> 5] |= (d >> 1) << (i & 31); l[i >> 5] |= (d & 1u) << (i & 31);
                 }
-                ok = !dh_ysf_clean100(h, l, o);
+                uint32_t mt = 0;
+                ok = !dh_ysf_clean100(h, l, o, &mt);
                 if (ok) {
                     const size_t cw = wave * 4 + (size_t) lane;
                     for (int b = 0; b < 13; b++) out[cw * out_stride + b] = (uint8_t) (o[b >> 2] >> (8 * (b & 3)));
-                    metric[cw] = 0;
+                    metric[cw] = (uint8_t) mt;
                 }
             }
             DH_BALLOT_ACC(clean, ok, lane);

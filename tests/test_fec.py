@@ -119,6 +119,35 @@ def test_trellis_clean_codewords_from_every_start_state_vs_reference(ctx, oracle
         assert (m1[:48] == 0).all() and (m1[48:48 + 2 * nd] > 0).all(), nd
 
 
+def test_trellis_single_dibit_repair_vs_reference(ctx, oracle):
+    """The single-dibit repair of the 100-dibit codewords (decoder_core.hpp, dh_ysf_clean100): one wrong dibit -- bit 1, bit 0 or both -- at
+    EVERY position of words from every start state, and pairs of wrong dibits at every distance up to 12 across the window the repair is
+    allowed in: outputs and metrics equal the reference's decoder compiled in place (oracle `ref`), or the restatement where `_ref` is not built."""
+    which = "ref" if oracle.ref() is not None else "oracle"
+    rng = np.random.default_rng(99)
+    nd = 100
+    words = []
+    for start in range(16):
+        base = _encode_from_state(rng.integers(0, 2, nd), start)
+        for pos in range(nd):
+            for pat in (1, 2, 3):                                # wrong bit 0, bit 1, both
+                w = base.copy(); w[pos // 4] ^= pat << (6 - 2 * (pos % 4)); words.append(w)
+    for _ in range(4):
+        base = _encode_from_state(rng.integers(0, 2, nd), int(rng.integers(0, 16)))
+        for pos in range(0, nd):
+            for gap in range(1, 13):
+                if pos + gap < nd:
+                    w = base.copy()
+                    w[pos // 4] ^= int(rng.integers(1, 4)) << (6 - 2 * (pos % 4))
+                    w[(pos + gap) // 4] ^= int(rng.integers(1, 4)) << (6 - 2 * ((pos + gap) % 4))
+                    words.append(w)
+    x = np.stack(words)
+    o1, m1 = ctx.trellis(x, nd)
+    o2, m2 = oracle.trellis(x, nd, which)
+    assert (m1 == m2).all()
+    assert (o1 == o2).all()
+
+
 def test_crc_whitening_golden(ctx, golden):
     g = golden["fec"]
     for cnt in (4, 10, 20):
