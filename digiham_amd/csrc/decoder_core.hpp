@@ -233,13 +233,15 @@ struct DhDmrChunkShared {
     union { uint32_t emb_words[DH_DMR_CHUNK][4]; uint32_t voice[DH_DMR_CHUNK][7]; };
 };
 
-// YSF (dh_ysf_channel): the decoded FICH and V/D2 DCH codewords of the next frames (13 bytes each, in 4 words), and a block that holds
+// YSF (dh_ysf_channel): the decoded FICH and V/D2 DCH codewords of the next frames (13 bytes each, in 4 words), their V/D2 voice blocks
+// (decoded as if every frame were V/D mode 2: the frame loop copies them out when it is), and a block that holds
 // the bit planes of those frames while the codewords are picked out of them, then the dibit streams of the codewords that need
 // the full Viterbi decoder.
-#define DH_YSF_CHUNK 24
+#define DH_YSF_CHUNK 16
 #define DH_YSF_PLANE_WORDS (DH_YSF_CHUNK * 15 + 4)              /* 480 dibits a frame; + slack: a lane reads consecutive words */
 struct DhYsfChunkShared {
     uint32_t res[DH_YSF_CHUNK][2][4];
+    uint32_t voice[DH_YSF_CHUNK][10];                           // the five V/D2 voice blocks of a frame, 7 bytes in two words each (dh_ysf_v2_block)
     union {
         struct { uint32_t plane_h[DH_YSF_PLANE_WORDS], plane_l[DH_YSF_PLANE_WORDS]; };
         uint32_t dirty[2 * DH_YSF_CHUNK][8];                    // bit 1 / bit 0 streams (100 bits each) of a codeword
@@ -1424,12 +1426,29 @@ DH_HD void dh_ysf_decode_ahead(const DhDecParams& P, const DhFecTables& T, const
         dh_transpose_5x20(xh, dh); dh_transpose_5x20(xl, dl);
         const bool bad_d = dh_ysf_clean100(dh, dl, out);
         if ((uint32_t) lane < n) { S.ysf.res[f][1][0] = out[0]; S.ysf.res[f][1][1] = out[1]; S.ysf.res[f][1][2] = out[2]; S.ysf.res[f][1][3] = out[3]; }
+        // the frame's sync word (ysf_phase.cpp:16-18): one bit, kept in the top of the DCH entry's fourth word
+        {
+            constexpr uint32_t YH = DH_YSF_SYNC_H, YL = DH_YSF_SYNC_L;
+            const bool is_sync = dh_popc32(dh_plane_bits(S.ysf.plane_h, o, 20) ^ YH) + dh_popc32(dh_plane_bits(S.ysf.plane_l, o, 20) ^ YL) <= 3;
+            if ((uint32_t) lane < n) S.ysf.res[f][1][3] = (out[3] & 0xFFu) | (is_sync ? 0x80000000u : 0u);      // (byte 12 of the DCH is the word's first byte; 13..15 are unused)
+        }
         DH_BALLOT_ACC(dirty_f, (uint32_t) lane < n && bad_f, lane);
         DH_BALLOT_ACC(dirty_d, (uint32_t) lane < n && bad_d, lane);
         DH_LV(keep0, lane) = fh[0]; DH_LV(keep1, lane) = fh[1]; DH_LV(keep2, lane) = fh[2]; DH_LV(keep3, lane) = fh[3];
         DH_LV(keep4, lane) = fl[0]; DH_LV(keep5, lane) = fl[1]; DH_LV(keep6, lane) = fl[2]; DH_LV(keep7, lane) = fl[3];
         DH_LV(keep8, lane) = dh[0]; DH_LV(keep9, lane) = dh[1]; DH_LV(keep10, lane) = dh[2]; DH_LV(keep11, lane) = dh[3];
         DH_LV(keep12, lane) = dl[0]; DH_LV(keep13, lane) = dl[1]; DH_LV(keep14, lane) = dl[2]; DH_LV(keep15, lane) = dl[3];
+    }
+    // the V/D2 voice blocks (ysf_phase.cpp:180-256) of every frame, one (frame, block) per lane, while the planes are there
+    DH_FOR_LANES(lane) {
+        for (uint32_t e = (uint32_t) lane; e < 5u * n; e += DH_WAVE) {
+            const uint32_t f = e / 5u, b = e - 5u * f, at = off0 + 480u * f + 140u + 72u * b;
+            const uint64_t hx = (uint64_t) dh_plane_bits(S.ysf.plane_h, at, 32) | (uint64_t) dh_plane_bits(S.ysf.plane_h, at + 32u, 20) << 32;
+            const uint64_t lx = (uint64_t) dh_plane_bits(S.ysf.plane_l, at, 32) | (uint64_t) dh_plane_bits(S.ysf.plane_l, at + 32u, 20) << 32;
+            uint32_t v0, v1;
+            dh_ysf_v2_block(hx, lx, v0, v1);
+            S.ysf.voice[f][2u * b] = v0; S.ysf.voice[f][2u * b + 1u] = v1;
+        }
     }
     const uint32_t nf = (uint32_t) dh_popc64(dirty_f), nd = nf + (uint32_t) dh_popc64(dirty_d);
     if (nd == 0u) { DH_BARRIER(); dh_ysf_check_ahead(P, T, n, S); return; }
@@ -1473,7 +1492,9 @@ DH_HD void dh_ysf_decode_ahead(const DhDecParams& P, const DhFecTables& T, const
             const uint32_t g = (uint32_t) lane >> 2, j = (uint32_t) lane & 3u;
             if (lane < 16 && r0 + g < nd) {
                 const uint32_t id = who[r0 + g];
-                S.ysf.res[id & 127u][id >> 7][j] = reinterpret_cast<const uint32_t*>(S.vit_out[g])[j];
+                const uint32_t w = reinterpret_cast<const uint32_t*>(S.vit_out[g])[j];
+                if (j == 3u && (id >> 7)) S.ysf.res[id & 127u][1][3] = (w & 0xFFu) | (S.ysf.res[id & 127u][1][3] & 0x80000000u);      // (the DCH entry's fourth word also carries the sync bit)
+                else S.ysf.res[id & 127u][id >> 7][j] = w;
             }
         }
         DH_BARRIER();
@@ -1536,10 +1557,11 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             dh_ysf_decode_ahead(P, T, syms, pos, n, total, S);
             ahead_pos = pos; ahead_i = 0; ahead_n = n;
         }
-        dh_view_ensure(syms, pos, 512);
-        dh_load_planes(syms, pos, total, pl, 8);
+        // (the frame's bit planes are only built for the payloads that are not decoded ahead: V/D mode 1, voice full rate, header)
+        bool have_planes = false;
+        auto need_planes = [&]() { if (!have_planes) { dh_view_ensure(syms, pos, 512); dh_load_planes(syms, pos, total, pl, 8); have_planes = true; } };
         int sync_count = (int) s[DS_SYNC_COUNT];
-        if (dh_ysf_is_sync(pl, 0)) { if (++sync_count > 12) sync_count = 12; }
+        if (dh_uniform(S.ysf.res[ahead_i][1][3]) >> 31) { if (++sync_count > 12) sync_count = 12; }
         else if (DH_UNLIKELY(--sync_count < 0)) {
             dh_emit(c, DH_EV_YSF_META_RESET, 0, 0, nullptr, 0);
             phase = 0; ahead_pos = 0xFFFFFFFFu; continue;
@@ -1565,6 +1587,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                 if (data_type == 0) {                                               // V/D mode 1 (:73-84)
                     if (P.out_cap - c.nout < 50) c.overflow = true;
                     else {
+                        need_planes();
                         uint8_t* o = c.out + c.nout;
                         DH_FOR_LANES(lane) {
                             if (lane < 50) {
@@ -1579,18 +1602,12 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                     if (P.out_cap - c.nout < 40) c.overflow = true;
                     else {
                         uint8_t* o = c.out + c.nout;
+                        const uint32_t* vw = S.ysf.voice[ahead_i - 1u];
                         DH_FOR_LANES(lane) {
-                            // one block per lane (five of them): mode byte + seven voice bytes
-                            const int blk = lane < 5 ? lane : 0, base = 120 + 20 + blk * 72;
-                            const uint64_t hx = (uint64_t) dh_plane_range(pl.h, base, 32) | (uint64_t) dh_plane_range(pl.h, base + 32, 20) << 32;
-                            const uint64_t lx = (uint64_t) dh_plane_range(pl.l, base, 32) | (uint64_t) dh_plane_range(pl.l, base + 32, 20) << 32;
-                            uint32_t v0, v1;
-                            dh_ysf_v2_block(hx, lx, v0, v1);
-                            if (lane < 5) {
-                                uint8_t* ob = o + 8 * blk;
-                                ob[0] = (uint8_t) data_type;
-                                ob[1] = (uint8_t) v0; ob[2] = (uint8_t) (v0 >> 8); ob[3] = (uint8_t) (v0 >> 16); ob[4] = (uint8_t) (v0 >> 24);
-                                ob[5] = (uint8_t) v1; ob[6] = (uint8_t) (v1 >> 8); ob[7] = (uint8_t) (v1 >> 16);
+                            if (lane < 40) {                            // five blocks of mode byte + seven voice bytes, decoded ahead
+                                const uint32_t blk = (uint32_t) lane >> 3, j = (uint32_t) lane & 7u;
+                                const uint32_t w = vw[2u * blk + (j > 4u ? 1u : 0u)];
+                                o[lane] = j == 0u ? (uint8_t) data_type : (uint8_t) (w >> (8u * ((j - 1u) & 3u)));
                             }
                         }
                         c.nout += 40;
@@ -1609,6 +1626,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                     const uint32_t nbytes = (uint32_t) (5 - start_frame) * 19u;
                     if (P.out_cap - c.nout < nbytes) c.overflow = true;
                     else {
+                        need_planes();
                         uint8_t* o = c.out + c.nout;
                         DH_FOR_LANES(lane) {
                             for (uint32_t e = lane; e < nbytes; e += DH_WAVE) {
@@ -1627,6 +1645,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             } else if (DH_UNLIKELY(frame_type == 0)) {                              // header (:139-161)
                 dh_emit(c, DH_EV_YSF_META_RESET, 0, 1, nullptr, 0);
                 // stage 2 (header frames only): CSD1 and CSD2, 180 dibits each (ysf_phase.cpp:323-333)
+                need_planes();
                 DH_FOR_LANES(lane) {
                     if (lane < 45) {
                         uint32_t a = 0, b = 0;
