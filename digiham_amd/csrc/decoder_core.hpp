@@ -208,6 +208,18 @@ DH_HD void dh_emit(DhDecCtx& c, uint8_t type, uint8_t a, uint8_t b, const uint8_
     c.nev++;
 }
 
+// the same with the payload (up to 12 bytes, memory order) in three words: eight word stores, no byte shuffling (the frame loops' hot events)
+DH_HD void dh_emit_w(DhDecCtx& c, uint32_t type, uint32_t a, uint32_t b, uint32_t len, uint32_t w0 = 0, uint32_t w1 = 0, uint32_t w2 = 0) {
+    if (c.ev == nullptr) return;
+    if (c.nev >= c.P->ev_cap) { c.overflow = true; return; }
+    if (c.writer) {
+        uint32_t* q = reinterpret_cast<uint32_t*>(c.ev + c.nev);
+        q[0] = c.consumed; q[1] = type | a << 8 | b << 16 | len << 24;
+        q[2] = w0; q[3] = w1; q[4] = w2; q[5] = 0u; q[6] = 0u; q[7] = 0u;
+    }
+    c.nev++;
+}
+
 // FramePhase::FramePhase() + Decoder::setPhase (dmr_phase.cpp:49-52, dmr_phase.hpp:51-60, dmr_decoder.cpp:17-23)
 DH_HD void dh_dmr_enter_frame_phase(DhState& s) {
     s[DS_SYNC_COUNT] = 0; s[DS_SLOT] = (uint32_t) -1; s[DS_SLOT_STABILITY] = 0;
@@ -1568,22 +1580,21 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
         }
         s[DS_SYNC_COUNT] = (uint32_t) sync_count;
         const uint32_t cw_fich = dh_uniform(S.ysf.res[ahead_i][0][0]), cw_flags = dh_uniform(S.ysf.res[ahead_i][0][1]);
-        const uint8_t* const cw_dch = reinterpret_cast<const uint8_t*>(S.ysf.res[ahead_i][1]);
+        const uint32_t* const cw_dch = S.ysf.res[ahead_i][1];
         ahead_i++; ahead_pos = pos + 480u;
 
         // FICH (fich.cpp:24-49): decoded and checked ahead
         const uint32_t fich = (cw_flags & 1u) ? cw_fich : 0u; const bool fresh = (cw_flags & 1u) != 0u;
         if (fresh) {
-            const uint8_t be[4] = { (uint8_t) (fich >> 24), (uint8_t) (fich >> 16), (uint8_t) (fich >> 8), (uint8_t) fich };
             s[DS_FICH] = fich; s[DS_HAS_FICH] = 1;
-            dh_emit(c, DH_EV_YSF_FICH, 0, 0, be, 4);
+            dh_emit_w(c, DH_EV_YSF_FICH, 0, 0, 4, (fich >> 24) | ((fich >> 8) & 0xFF00u) | ((fich << 8) & 0xFF0000u) | (fich << 24));      // the four bytes, first on the air first
         }
 
         if (s[DS_HAS_FICH]) {
             const uint32_t rf = s[DS_FICH];
             const uint32_t frame_type = (rf >> 30) & 3u, data_type = (rf >> 8) & 3u;
             if (frame_type == 1) {                                                  // communication channel
-                dh_emit(c, DH_EV_YSF_MODE, 0, (uint8_t) data_type, nullptr, 0);
+                dh_emit_w(c, DH_EV_YSF_MODE, 0, data_type, 0);
                 if (data_type == 0) {                                               // V/D mode 1 (:73-84)
                     if (P.out_cap - c.nout < 50) c.overflow = true;
                     else {
@@ -1613,11 +1624,10 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                         c.nout += 40;
                     }
                     if (fresh) {                                                    // decodeV2DataChannel (:258-269)
-                        const uint8_t* w = cw_dch;
-                        if (cw_flags & 2u) {
-                            uint8_t dch[13];
-                            dh_whiten_packed(w, dch, 100);
-                            dh_emit(c, DH_EV_YSF_DCH, (uint8_t) ((fich >> 19) & 7u), 0, dch, 10);
+                        if (cw_flags & 2u) {                                        // de-whitened (whitening.c:6-22): the first ten bytes, as words
+                            const uint32_t* w = cw_dch;
+                            constexpr uint32_t PN0 = dh_pn9_le_word(0), PN1 = dh_pn9_le_word(1), PN2 = dh_pn9_le_word(2);
+                            dh_emit_w(c, DH_EV_YSF_DCH, (fich >> 19) & 7u, 0, 10, dh_uniform(w[0]) ^ PN0, dh_uniform(w[1]) ^ PN1, (dh_uniform(w[2]) ^ PN2) & 0xFFFFu);
                         }
                     }
                 } else if (data_type == 3) {                                        // voice full rate (:111-130)
@@ -1826,8 +1836,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
         if ((uint32_t) (dh_popc32(lb & 0xFu) & 1) == ((lb >> 7) & 1u)) {
             const uint32_t lich = dh_brev32(lb & 0x7Fu) >> 25;     // lich_bits[0] is the MSB
             s[DS_NX_LICH] = lich + 1u;
-            const uint8_t b = (uint8_t) lich;
-            dh_emit(c, DH_EV_NXDN_LICH, 0, 0, &b, 1);
+            dh_emit_w(c, DH_EV_NXDN_LICH, 0, 0, 1, lich & 0xFFu);
         }
         const uint32_t have_lich = s[DS_NX_LICH];
         const uint32_t lich = have_lich - 1u;
@@ -1907,7 +1916,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
                 for (int i = 0; i < 5; i++) sacch[i] = (uint8_t) dh_uniform(w[i]);
                 if (dh_nxdn_crc_ok(sacch, 26, 6, 0x3Fu, 0x13u, sacch[3] & 0x3Fu)) {
                     const uint32_t index = ((uint32_t) sacch[0] >> 6) ^ 3u;
-                    dh_emit(c, DH_EV_NXDN_SACCH, (uint8_t) index, 0, sacch, 5);
+                    dh_emit_w(c, DH_EV_NXDN_SACCH, index, 0, 5, (uint32_t) sacch[0] | (uint32_t) sacch[1] << 8 | (uint32_t) sacch[2] << 16 | (uint32_t) sacch[3] << 24, sacch[4]);
                     uint32_t have = s[DS_NX_HAVE];
                     if (!(index > 0u && !((have >> (index - 1u)) & 1u))) {        // SacchSuperframeCollector::push (sacch.cpp:90-98)
                         have |= 1u << index;
@@ -1931,7 +1940,7 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
             for (int i = 0; i < 2 && !released; i++) {
                 if ((option >> (1 - i)) & 1u) {                                   // voice (nxdn_phase.cpp:136-150)
                     if (sync_count >= 1) {
-                        dh_emit(c, DH_EV_NXDN_SYNC_VOICE, 0, 0, nullptr, 0);
+                        dh_emit_w(c, DH_EV_NXDN_SYNC_VOICE, 0, 0, 0);
                         if (P.out_cap - c.nout < 18) { c.overflow = true; break; }
                         uint8_t* o = c.out + c.nout;
                         DH_FOR_LANES(lane) {

@@ -192,6 +192,12 @@ static constexpr DhCrc16Table dh_crc16_table{};
 static constexpr DhPn9Bytes dh_pn9_bytes{};
 #endif
 
+// four bytes of the whitening sequence as a little-endian word (byte 4 i in bits 0..7)
+constexpr uint32_t dh_pn9_le_word(int i) {
+    constexpr DhPn9Bytes pn{};
+    return (uint32_t) pn.b[4 * i] | (uint32_t) pn.b[4 * i + 1] << 8 | (uint32_t) pn.b[4 * i + 2] << 16 | (uint32_t) pn.b[4 * i + 3] << 24;
+}
+
 DH_HD uint16_t dh_crc16_bytewise(const uint8_t* data, int count) {
     uint32_t crc = 0;
     for (int k = 0; k < count; k++) crc = ((crc << 8) & 0xFFFFu) ^ dh_crc16_table.t[((crc >> 8) ^ data[k]) & 0xFFu];
