@@ -465,7 +465,10 @@ class Job:
             if all("traffic" in q for q in pcs):
                 pc = dict(pc)
                 pc["traffic"] = sum(q["traffic"] for q in pcs)
-                pc["traffic_source"] = "sum over the step's engines: " + "; ".join(q["traffic_source"] for q in pcs)
+                pc["traffic_source"] = "WHOLE STEP, sum over its engines (compare with algorithmic_bytes_per_step): " + "; ".join(q["traffic_source"] for q in pcs)
+                # algorithmic bytes of the whole step: 4 B in + 1 B per sps samples per channel, + what the decoders put out
+                pc["algorithmic_bytes_per_step"] = sum(q["B"] * q["T"] * 4.0 + q["B"] * (q["T"] / float(q["kw"]["sps"])) +
+                                                       (int(q["eng"].frames()[1].sum()) if q["kw"]["proto"] != "none" else 0) for q in self.parts)
         if group is not None and "traffic" in pc:
             # the committed passes profiled whole pushes (one launch of all channels); PART 0 of an overlapped push takes `share` of them
             pc = dict(pc)
@@ -522,7 +525,7 @@ class Job:
                                           "16-byte-per-lane non-temporal copy kernel (dh_debug_copy), torch.Tensor.copy_ and the library's read-only stream (dh_debug_copy, null destination: read bytes only)",
                 "peak_achievable_rates": ceiling_rates,
                 "traffic": pc.get("traffic"), "traffic_source": pc.get("traffic_source"),
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_step": pc.get("algorithmic_bytes_per_step"), "avg_launch_ms": dom_ms,
                 "co_limit": co}, \
                {"rrc": mean(rrc_ms), "slicer": mean(slicer_ms), "decoder": mean(dec_ms)}
 
@@ -670,7 +673,8 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
                  "launch_group": roof.get("launch_group"),
                  "steps": steps, "ms_per_step": dt / steps * 1e3, "value": job.samples_per_step * steps / dt / SAMPLE_RATE, "unit": "channels",
                  "kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "frac": roof["frac"], "frac_of_achievable": roof["frac_of_achievable"],
-                 "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "traffic": roof["traffic"], "traffic_source": roof["traffic_source"],
+                 "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "algorithmic_bytes_per_step": roof.get("algorithmic_bytes_per_step"),
+                 "traffic": roof["traffic"], "traffic_source": roof["traffic_source"],
                  "stage_ms": stage}
         if verify:
             ok, entry["verified"] = job.verify_timed(verify, steps + warmup)

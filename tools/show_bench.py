@@ -21,5 +21,5 @@ for o in oc or []:
     v = o.get("verified") or {}
     print("  %-28s %-22s %7.3f ms  kernel %7.3f ms  frac %.3f  traffic/alg %-6s  ok=%s%s"
           % (o["workload"], o["config"].split(" x ")[0], o["ms_per_step"], o["avg_launch_ms"], o["frac"],
-             "%.3f" % (o["traffic"] / o["algorithmic_bytes_per_launch"]) if o.get("traffic") else "-",
+             "%.3f" % (o["traffic"] / (o.get("algorithmic_bytes_per_step") or o["algorithmic_bytes_per_launch"])) if o.get("traffic") else "-",
              v.get("bit_exact_vs_oracle", v.get("within_1e-6_vs_oracle")), " (1e-6: %.2e)" % v["max_rel_err"] if "max_rel_err" in v else ""))
