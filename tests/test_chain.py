@@ -173,6 +173,85 @@ def test_decoder_only_engine(ctx, oracle):
             assert np.concatenate(got_e[b]).tobytes() == ev.tobytes()
 
 
+def test_dmr_sync_loss_at_every_burst_index(ctx, oracle):
+    """The frame-parallel DMR decoder takes a push in chunks of up to 64 bursts (one burst per lane; the slot / superframe machine walks
+    their summaries) and leaves a chunk where a burst sends the decoder back to its SyncPhase.  Here every channel loses its signal at a
+    different burst -- channel c from burst c on, for 8 to 20 bursts of random dibits (sync counters run down, META_RESET, SyncPhase,
+    re-acquisition somewhere inside the next chunk) -- in one push, in pushes of 1 000 symbols and in pushes of a few symbols more than
+    a burst: decoder bytes and events equal the reference-shaped oracle decoder's (dmr_phase.cpp:35-47, :163-204) for every index."""
+    from digiham_amd import api
+    rng = np.random.default_rng(2024)
+    B, nb = 72, 150
+    rows = []
+    for c in range(B):
+        s = synth.dmr_stream(300 + c, nb, two_slots=bool(c & 1), lead_in=int(rng.integers(0, 50))).copy()
+        lead = len(s) - 144 * nb
+        gap = int(rng.integers(8, 21))
+        s[lead + 144 * c: lead + 144 * (c + gap)] = rng.integers(0, 4, 144 * gap)
+        flips = rng.integers(0, len(s), len(s) // 150)            # scattered wrong dibits: the block codes have work to do
+        s[flips] ^= rng.integers(1, 4, len(flips)).astype(np.uint8)
+        rows.append(s)
+    n = min(len(r) for r in rows)
+    syms = np.stack([r[:n] for r in rows])
+    want = []
+    for b in range(B):
+        o, ev = oracle.Decoder("dmr").process(syms[b])
+        want.append((o, ev.tobytes()))
+    for step in (n, 1000, 151):
+        eng = api.Engine(B, min(step, n), rrc="none", demod="none", proto="dmr", ctx=ctx)
+        got_f, got_e = [[] for _ in range(B)], [[] for _ in range(B)]
+        for lo in range(0, n, step):
+            part = np.ascontiguousarray(syms[:, lo:lo + step])
+            eng.push_symbols(part, np.full(B, part.shape[1], np.uint32))
+            f, fc = eng.frames(); e, ec = eng.events()
+            for b in range(B):
+                got_f[b].append(f[b, :fc[b]].copy()); got_e[b].append(e[b, :ec[b]].copy())
+        for b in range(B):
+            assert (np.concatenate(got_f[b]) == want[b][0]).all(), (step, b)
+            assert np.concatenate(got_e[b]).tobytes() == want[b][1], (step, b)
+        eng.close()
+    assert any(3 in set(np.frombuffer(w[1], api.EVENT_DTYPE)["type"].tolist()) for w in want)      # META_RESETs happened
+
+
+def test_ysf_sync_loss_at_every_frame_index(ctx, oracle):
+    """The YSF decoder decodes the codewords, voice blocks and sync words of up to 16 frames AHEAD on the grid the current frame starts; a
+    frame that sends it back to its SyncPhase invalidates what was decoded ahead.  Every channel loses its signal at a different frame
+    (channel c from frame c on, 14 to 20 frames of random dibits), with scattered wrong dibits elsewhere (clean, repaired and Viterbi-decoded
+    codewords side by side), in one push and in pushes of 1 000 and of 481 symbols: decoder bytes and events equal the oracle decoder's."""
+    from digiham_amd import api
+    rng = np.random.default_rng(2025)
+    B, nfr = 24, 48
+    rows = []
+    for c in range(B):
+        s = synth.ysf_stream(400 + c, nfr, mode=("vd2", "vd1", "fr")[c % 3] if c % 4 == 3 else "vd2", lead_in=int(rng.integers(0, 60))).copy()
+        lead = len(s) - 480 * nfr if len(s) >= 480 * nfr else 0
+        gap = int(rng.integers(14, 21))
+        s[lead + 480 * c: lead + 480 * (c + gap)] = rng.integers(0, 4, len(s[lead + 480 * c: lead + 480 * (c + gap)]))
+        flips = rng.integers(0, len(s), len(s) // 120)
+        s[flips] ^= rng.integers(1, 4, len(flips)).astype(np.uint8)
+        rows.append(s)
+    n = min(len(r) for r in rows)
+    syms = np.stack([r[:n] for r in rows])
+    want = []
+    for b in range(B):
+        o, ev = oracle.Decoder("ysf").process(syms[b])
+        want.append((o, ev.tobytes()))
+    for step in (n, 1000, 481):
+        eng = api.Engine(B, min(step, n), rrc="none", demod="none", proto="ysf", ctx=ctx)
+        got_f, got_e = [[] for _ in range(B)], [[] for _ in range(B)]
+        for lo in range(0, n, step):
+            part = np.ascontiguousarray(syms[:, lo:lo + step])
+            eng.push_symbols(part, np.full(B, part.shape[1], np.uint32))
+            f, fc = eng.frames(); e, ec = eng.events()
+            for b in range(B):
+                got_f[b].append(f[b, :fc[b]].copy()); got_e[b].append(e[b, :ec[b]].copy())
+        for b in range(B):
+            assert (np.concatenate(got_f[b]) == want[b][0]).all(), (step, b)
+            assert np.concatenate(got_e[b]).tobytes() == want[b][1], (step, b)
+        eng.close()
+    assert any(20 in set(np.frombuffer(w[1], api.EVENT_DTYPE)["type"].tolist()) for w in want)     # META_RESETs happened
+
+
 def test_lc_fields_from_events(ctx):
     """The LC words carried by DH_EV_DMR_LC events decode to the source / target ids the generator put in
     (Digiham::Dmr::Lc getters, lc.cpp:26-43) -- for the voice-header LC (BPTC) and the embedded LC alike."""
