@@ -1,4 +1,4 @@
-// fec_core.hpp -- block codes, BPTC(196,96), CRC-16, PN9 as lane-local functions.
+// fec_core.hpp -- block codes, CRC-16, PN9 as lane-local functions.
 //
 // What the reference does with a bit-serial syndrome loop plus a linear scan of a generated
 // {syndrome, pattern} list (e.g. src/dmr_decoder/golay_20_8.c:1403-1435) is done here with
@@ -83,42 +83,7 @@ DH_HD bool dh_block_decode_wave(const DhCode& c, const LutT* lut, uint32_t& word
     return true;
 }
 
-// ------------------------------------------------------------------ BPTC(196,96)
-// reference: src/dmr_decoder/bptc_196_96.c:5-59.  `raw` holds the 196 received bits MSB-first
-// in 25 bytes.  The de-interleave (i*181 mod 196) and the 13x15 pivot are folded into one gather.
-DH_HD int dh_bptc_bit(const uint8_t* raw, int i) { return (raw[i >> 3] >> (7 - (i & 7))) & 1; }
-
-DH_HD bool dh_bptc_196_96(const DhFecTables& T, const uint8_t* raw, uint8_t* out12) {
-    uint32_t cols[15];
-    bool ok = true;
-    for (int i = 0; i < 15; i++) {
-        uint32_t w = 0;
-        for (int k = 0; k < 13; k++) {
-            const int di = k * 15 + i + 1;                 // skip R(3)
-            w |= (uint32_t) dh_bptc_bit(raw, (di * 181) % 196) << (12 - k);
-        }
-        ok &= dh_block_decode(T.h139, T.lut_h139, w);      // all 15 columns are always decoded (:27)
-        cols[i] = w;
-    }
-    if (!ok) return false;
-    uint32_t rows[9];
-    for (int i = 0; i < 9; i++) {
-        uint32_t w = 0;
-        for (int k = 0; k < 15; k++) w |= ((cols[k] >> (12 - i)) & 1u) << (14 - k);
-        ok &= dh_block_decode(T.h1511, T.lut_h1511, w);
-        rows[i] = w;
-    }
-    if (!ok) return false;
-    // 96 information bits: row 0 carries 3 reserved + 8, rows 1..8 carry 11 each (:45-56)
-    uint64_t acc = 0; int nacc = 0, ob = 0;
-    for (int r = 0; r < 9; r++) {
-        const int nb = r == 0 ? 8 : 11;
-        const uint32_t bits = (rows[r] >> 4) & ((1u << nb) - 1);
-        acc = (acc << nb) | bits; nacc += nb;
-        while (nacc >= 8) { out12[ob++] = (uint8_t) (acc >> (nacc - 8)); nacc -= 8; }
-    }
-    return true;
-}
+// (BPTC(196,96): decoder_core.hpp, dh_dmr_bptc_lane -- one block per lane, the column code bit-sliced; the batch entry dh_bptc_196_96 runs it too)
 
 // ------------------------------------------------------------------ CRC-16 / PN9
 // reference: src/ysf_decoder/crc16.c:3-18

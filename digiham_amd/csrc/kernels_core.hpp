@@ -113,12 +113,15 @@ DH_HD void dh_fec_block_item(const DhFecTables& T, int code, void* words, uint8_
     ok[i] = r ? 1 : 0;
 }
 
+// (the lane-local decoder of the DMR chain, dh_dmr_bptc_lane -- columns bit-sliced over row words: the batch entry runs the same code, so
+// the reference's golden vectors pin it directly)
 DH_HD void dh_bptc_item(const DhFecTables& T, const uint8_t* in, uint8_t* out, uint8_t* ok, size_t i) {
-    uint8_t raw[25], o[12];
-    for (int b = 0; b < 25; b++) raw[b] = in[i * 25 + b];
-    for (int b = 0; b < 12; b++) o[b] = 0;
-    const bool r = dh_bptc_196_96(T, raw, o);
-    for (int b = 0; b < 12; b++) out[i * 12 + b] = r ? o[b] : (uint8_t) 0;
+    uint32_t w[7] = { 0, 0, 0, 0, 0, 0, 0 };                      // the 196 received bits, first bit on top of w[0]
+    for (int b = 0; b < 25; b++) w[b >> 2] |= (uint32_t) in[i * 25 + b] << (24 - 8 * (b & 3));
+    uint32_t o[3];
+    const uint32_t* wp = w;
+    const bool r = dh_dmr_bptc_lane(T, [wp](int k) -> uint32_t { return (wp[k >> 5] >> (31 - (k & 31))) & 1u; }, o);
+    for (int b = 0; b < 12; b++) out[i * 12 + b] = r ? (uint8_t) (o[b >> 2] >> (8 * (b & 3))) : (uint8_t) 0;
     ok[i] = r ? 1 : 0;
 }
 
