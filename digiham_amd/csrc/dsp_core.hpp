@@ -632,7 +632,6 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #define DH_FIR_F16 1
 #define DH_PLAN_FAST 1                       // sps-10 kernels: the run planning of a whole-block run in three compares
 #define DH_EXACT_BATCH 2                     // exact evaluations of the 81-tap kernels: this many products at a time, their LDS reads in flight together (the 161-tap ones: 8)
-#define DH_EXACT_STAGED 1                    // the exact re-evaluations of the sps-10 kernels stage their raw samples through LDS, like the generic-sps ones
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
 #define DH_F16_EDGE_WINDOWS 1                // split-f16 kernels: the first / last windows of a push take the split-f16 FIR too (0: the reference-order FIR, as before)
 // K = taps + 15 rounded up to whole MFMAs of 32: three for the wide filter (96), six for the narrow one (192; taps beyond the
@@ -1109,69 +1108,6 @@ DH_HD int32_t dh_slot_position(const DhExactCtx& C, uint32_t j, uint32_t k, uint
     return (C.blk_flags & 2u) ? C.prev_start + (int32_t) (j * sps) + (j ? C.prev_off : 0) : INT32_MIN;
 }
 
-// Symbol k of the current block decided with the reference's arithmetic (gfsk_demodulator.cpp:82-122): its mid-symbol
-// average from exact filtered samples, and the exact minimum / maximum of the volume ring -- only ring slots whose
-// approximate volume lies within 2.5 e of the approximate extreme can hold the exact one, so only those are recomputed
-// (ten exact samples each, summed in order, / sps).  Wave-level: all lanes call it; `scratch` = 64 floats of LDS.
-template <int NZ, int SPS>
-DH_COLD uint8_t dh_exact_symbol(const DhExactCtx& C, DhDspShared& S, uint32_t k, float* scratch) {
-    constexpr uint32_t sps = SPS, LO = 3, HI = 7;
-    const float mn_a = S.mn[k], mx_a = S.mx[k];
-    const float lo_thr = mn_a + 2.5f * C.e_eff, hi_thr = mx_a - 2.5f * C.e_eff;
-    uint64_t cand_lo[2] = { 0, 0 }, cand_hi[2] = { 0, 0 };
-    for (int h = 0; h < 2; h++) {
-        uint64_t vlo = 0, vhi = 0;
-        DH_FOR_LANES_FRESH(lane) {
-            const uint32_t j = (uint32_t) lane + 64u * (uint32_t) h;
-            bool lo = false, hi = false;
-            if (j < DH_VOLUME_RB_SIZE) {
-                const float v = (j >= C.k0 && j <= k) ? S.vol_new[j] : S.vol_old[j];
-                lo = v <= lo_thr; hi = v >= hi_thr;
-            }
-            DH_BALLOT_ACC(vlo, lo, lane); DH_BALLOT_ACC(vhi, hi, lane);
-        }
-        cand_lo[h] = vlo; cand_hi[h] = vhi;
-    }
-    float exact_min = DH_FLT_MAX, exact_max = DH_FLT_MIN;            // the reference's seeds (gfsk_demodulator.cpp:110-111)
-    float avg_sum = 0.0f;
-    bool first = true;
-    uint64_t todo[2] = { cand_lo[0] | cand_hi[0], cand_lo[1] | cand_hi[1] };
-    while (first || todo[0] || todo[1]) {
-        uint32_t slot[6]; int n = 0;
-        for (int h = 0; h < 2 && n < 6; h++)
-            while (todo[h] && n < 6) { const int b = dh_ffs64(todo[h]); todo[h] &= todo[h] - 1; slot[n++] = (uint32_t) b + 64u * (uint32_t) h; }
-        DH_BARRIER();                                                  // the scratch of the previous round has been read
-        DH_FOR_LANES_FRESH(lane) {
-            int32_t f = INT32_MIN;
-            if (lane < 4) { if (first) f = dh_slot_position(C, k, k, sps) + (int32_t) LO + lane; }
-            else {
-                const int c = (lane - 4) / 10, i = (lane - 4) % 10;
-                if (c < n) { const int32_t s0 = dh_slot_position(C, slot[c], k, sps); if (s0 != INT32_MIN) f = s0 + i; }
-            }
-            scratch[lane] = f == INT32_MIN ? 0.0f : dh_exact_filtered<NZ>(C.tail, C.tc, C.in, C.nv, C.tapsf, C.gain, C.rgain, f);
-        }
-        DH_BARRIER();
-        if (first) { for (int i = 0; i < (int) (HI - LO); i++) avg_sum += scratch[i]; first = false; }
-        for (int c = 0; c < n; c++) {
-            float vol = 0.0f;
-            for (int i = 0; i < 10; i++) vol += scratch[4 + 10 * c + i];
-            vol = dh_div_const(vol, (float) sps, C.sps_rcp);
-            const uint32_t j = slot[c];
-            if ((cand_lo[j >> 6] >> (j & 63u)) & 1u) exact_min = dh_fmin_(exact_min, vol);
-            if ((cand_hi[j >> 6] >> (j & 63u)) & 1u) exact_max = dh_fmax_(exact_max, vol);
-        }
-    }
-    const float center = (exact_max + exact_min) / 2.0f;
-    const float average = avg_sum / (float) (HI - LO);
-    if (C.levels == 4) {
-        const float umid = __builtin_fmaf(exact_max - center, 0.625f, center);
-        const float lmid = __builtin_fmaf(exact_min - center, 0.625f, center);
-        if (average > center) return average > umid ? 1 : 0;
-        return average < lmid ? 3 : 2;
-    }
-    return average > center ? (uint8_t) !C.invert : (uint8_t) (C.invert != 0);
-}
-
 // ---- the same two exact evaluations with the raw samples staged through LDS (generic sps; used by the narrow filter, whose
 // 161-tap chains would otherwise fetch every sample with a dependent load of its own from HBM / L2)
 // raw[0 ..] = V[base ..]: the reference's filtered sample at filtered position f (rrc_filter.cpp:22-34), 0 where the stream
@@ -1237,6 +1173,7 @@ DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint
     // <= sps / 3 + 1, and two areas in `stage`: both hold for every sps up to DH_MAX_SPS with the window blocks of dh_dsp_xf_words().
     // The staging areas run over S.sum, behind the filtered samples: the slicing phase has consumed it by the time this is called.)
     static_assert(DH_MAX_SPS + DH_MAX_SPS / 3 + 2 <= DH_WAVE, "a candidate slot's samples and the evaluation window fit one round of lanes");
+    static_assert(DH_MAX_SPS + DH_MAX_NZ + 1 <= 4 * DH_WAVE, "an area is staged with four elements per lane");
     uint32_t per_round = dh_min<uint32_t>(A - 1u, (DH_WAVE - W) / sps);
     if (per_round > 8u) per_round = 8u;
     float* scratch = stage + A * STRIDE;
@@ -1278,39 +1215,40 @@ DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint
         }
         for (uint32_t b = 0; b < ns; b++) { if (todo[0]) todo[0] &= todo[0] - 1; else todo[1] &= todo[1] - 1; }
         DH_BARRIER();
-        // raw samples of all areas: area 0 = V[mid_base ..) (first round only), area 1 + c = V[pos_c ..); four loads per lane in flight
-        const uint32_t a_lo = first ? 0u : 1u, total = (1u + ns) * STRIDE;
-        DH_FOR_LANES_FRESH(lane) {
-            for (uint32_t e0 = a_lo * STRIDE + (uint32_t) lane; e0 < total; e0 += 4u * DH_WAVE) {
+        // raw samples, area by area (wave-uniform loop: area 0 = V[mid_base ..), first round only; area 1 + c = V[pos_c ..)): a lane takes
+        // elements lane, lane + 64, ... of the area, its (up to four) loads in flight together.  (As ONE loop over all areas' elements
+        // every element paid a division by the area stride, a run-time value wherever the evaluation window is.)
+        for (uint32_t a = first ? 0u : 1u; a <= ns; a++) {
+            const int32_t base = a == 0u ? mid_base : (int32_t) dh_uniform((uint32_t) tbl_pos[a - 1u]);
+            const uint32_t count = (a == 0u ? W : sps) + (uint32_t) NZ + 1u;
+            float* const area = stage + a * STRIDE;
+            DH_FOR_LANES_FRESH(lane) {
                 float v[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; u++) {
-                    const uint32_t e = e0 + u * DH_WAVE;
-                    const uint32_t a = e < total ? e / STRIDE : a_lo, i = e - a * STRIDE;
-                    const int32_t base = a == 0u ? mid_base : tbl_pos[a - 1u];
-                    const uint32_t count = (a == 0u ? W : sps) + (uint32_t) NZ + 1u;
+                    const uint32_t i = (uint32_t) lane + u * DH_WAVE;
                     const int32_t idx = base + (int32_t) i;
-                    const bool have = e < total && i < count && base != INT32_MIN && idx >= 0 && (uint32_t) idx < C.nv;
+                    const bool have = i < count && base != INT32_MIN && idx >= 0 && (uint32_t) idx < C.nv;
                     const uint32_t at = have ? (uint32_t) idx : C.tc;            // (any valid address for the lanes that store a zero)
                     const float* src = at < C.tc ? C.tail + at : C.in + (at - C.tc);
                     v[u] = (have || C.nv > C.tc) ? *src : 0.0f;
                     if (!have) v[u] = 0.0f;
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; u++) { const uint32_t e = e0 + u * DH_WAVE; if (e < total) stage[e] = v[u]; }
+                for (uint32_t u = 0; u < 4u; u++) { const uint32_t i = (uint32_t) lane + u * DH_WAVE; if (i < count) area[i] = v[u]; }
             }
         }
         DH_BARRIER();
         DH_FOR_LANES_FRESH(lane) {
+            // lanes 0 .. W - 1: the evaluation window (first round); W + c sps + i: sample i of the round's slot c -- one chain per lane,
+            // from ONE call site (area, position and sample index are per-lane values)
             float y = 0.0f;
-            if ((uint32_t) lane < W) { if (first) y = dh_exact_filtered_lds<NZ>(stage, mid_base, C.nv, C.tapsf, C.gain, C.rgain, mid_base + lane); }
-            else {
+            uint32_t area = 0; int32_t s0 = mid_base, f = mid_base + lane; bool run = (uint32_t) lane < W && first;
+            if ((uint32_t) lane >= W) {
                 const uint32_t c = ((uint32_t) lane - W) / sps, i = ((uint32_t) lane - W) - c * sps;
-                if (c < ns) {
-                    const int32_t s0 = tbl_pos[c];
-                    if (s0 != INT32_MIN) y = dh_exact_filtered_lds<NZ>(stage + (1u + c) * STRIDE, s0, C.nv, C.tapsf, C.gain, C.rgain, s0 + (int32_t) i);
-                }
+                if (c < ns) { s0 = tbl_pos[c]; f = s0 + (int32_t) i; area = 1u + c; run = s0 != INT32_MIN; }
             }
+            if (run) y = dh_exact_filtered_lds<NZ>(stage + area * STRIDE, s0, C.nv, C.tapsf, C.gain, C.rgain, f);
             scratch[lane] = y;
         }
         DH_BARRIER();
@@ -1387,22 +1325,6 @@ DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t ne
         }
     }
 }
-
-// the variance ring of the block that just ended, recomputed with the reference's arithmetic (ordered timing chain)
-template <int NZ>
-DH_COLD void dh_exact_var_ring(const DhExactCtx& C, DhDspShared& S, uint32_t sps) {
-    for (uint32_t r = 0; r * DH_WAVE < DH_VARIANCE_SYMBOLS * sps; r++) {
-        DH_FOR_LANES_FRESH(lane) {
-            const uint32_t e = r * DH_WAVE + (uint32_t) lane;
-            if (e < DH_VARIANCE_SYMBOLS * sps) {
-                const uint32_t j = e / sps, i = e - j * sps;
-                const int32_t f = C.cur_start + (int32_t) (j * sps) + (j ? C.cur_off : 0) + (int32_t) i;
-                S.var_rb[i * DH_VARIANCE_SYMBOLS + j] = dh_exact_filtered<NZ>(C.tail, C.tc, C.in, C.nv, C.tapsf, C.gain, C.rgain, f);
-            }
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
@@ -1951,7 +1873,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         if (BOUNDED) { e_blk = dh_uniform_f(__builtin_fmaxf(BS->e_blk, e_run)); BS->e_blk = e_blk; }
         const float e_eff = BOUNDED ? dh_uniform_f(__builtin_fmaxf(e_run, __builtin_fmaxf(BS->e_cur, BS->e_prev))) : 0.0f;
         const float T = DH_BOUND_T_FACTOR * e_eff;
-        uint64_t unsure[2] = { 0, 0 };                  // symbols k0 + 64 h + lane
+        uint64_t vote_a = 0, vote_b = 0;                // doubtful symbols of the run: bit l of vote_a = symbol 2 l, of vote_b = symbol 2 l + 1
         // Straight-line per half of the run (m <= 100 symbols: lanes 0..63, then 0..35): every lane computes, a predicate
         // guards the store -- written as a loop over the lane's symbols this compiled to a real loop with exec-mask
         // bookkeeping (half of this phase's instructions were scalar).  The wave-uniform choices (4 / 2 levels, invert,
@@ -2070,7 +1992,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // both symbols -- one pass of ~40 vector instructions instead of two of ~37.  Every operation is the one the one-symbol
         // form performs (same operands, same order), so the dibits and the doubts are the same.
         if (DH_STOP_AFTER >= 5) {
-        uint64_t vote_a = 0, vote_b = 0;
         DH_FOR_LANES_FRESH(lane) {
             const uint32_t qa = 2u * (uint32_t) lane;
             const bool va = qa < m, vb = qa + 1u < m;
@@ -2108,33 +2029,25 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_BALLOT_ACC(vote_a, doubt_a, lane);
             DH_BALLOT_ACC(vote_b, doubt_b, lane);
         }
-        // symbol q's doubt sits in bit q / 2 of vote_a (even q) or vote_b (odd q): back to one bit per symbol, 64 per word
-        if (DH_UNLIKELY((vote_a | vote_b) != 0)) {
-            for (uint32_t l = 0; l < 50u; l++) {
-                if ((vote_a >> l) & 1ull) unsure[(2u * l) >> 6] |= 1ull << ((2u * l) & 63u);
-                if ((vote_b >> l) & 1ull) unsure[(2u * l + 1u) >> 6] |= 1ull << ((2u * l + 1u) & 63u);
-            }
         }
-        }
-        if (BOUNDED && DH_UNLIKELY((unsure[0] | unsure[1]) != 0)) {
+        if (BOUNDED && DH_UNLIKELY((vote_a | vote_b) != 0)) {
             DhExactCtx C;
             C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
             C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
             C.prev_start = (int32_t) dh_uniform((uint32_t) BS->prev_start); C.prev_off = (int32_t) dh_uniform((uint32_t) BS->prev_off);
             C.blk_flags = dh_uniform(BS->blk_flags);
             C.k0 = k0; C.e_eff = e_eff; C.levels = P.levels; C.invert = P.invert;
-            for (int h = 0; h < 2; h++) {
-                uint64_t todo = unsure[h];
-                while (todo) {
-                    const uint32_t q = (uint32_t) dh_ffs64(todo) + 64u * (uint32_t) h;
-                    todo &= todo - 1;
-                    // (the raw samples behind each evaluation staged through the dead part of the window block: fetched one by
-                    // one from HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
-                    const uint8_t sym = DH_EXACT_STAGED || SPS != 10 ? dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi)
-                                                 : dh_exact_symbol<NZ, 10>(C, S, k0 + q, S.xf + 640);
-                    DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
-                    BS->n_uncertain++;
-                }
+            // one evaluation at a time, the even symbols' votes first (the evaluations do not depend on one another); ONE call site:
+            // the evaluation is a thousand instructions of text
+            uint64_t ta = vote_a, tb = vote_b;
+            while ((ta | tb) != 0) {
+                uint32_t q;
+                if (ta) { q = 2u * (uint32_t) dh_ffs64(ta); ta &= ta - 1; } else { q = 2u * (uint32_t) dh_ffs64(tb) + 1u; tb &= tb - 1; }
+                // (the raw samples behind each evaluation are staged through the dead part of the window block: fetched one by one from
+                // HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
+                const uint8_t sym = dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi);
+                DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
+                BS->n_uncertain++;
             }
         }
 
@@ -2466,8 +2379,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
                         // (the window block is dead here except words 512..575, where the L2 touch of the next window may
                         // still be dropping its dwords: the staged variant uses the words behind them)
-                        if (DH_EXACT_STAGED || SPS != 10) dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, chain_rows);
-                        else dh_exact_var_ring<NZ>(C, S, sps);
+                        dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, chain_rows);
                         BS->n_exact_blocks++;
                         DH_BARRIER();
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
