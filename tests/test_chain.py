@@ -252,6 +252,58 @@ def test_ysf_sync_loss_at_every_frame_index(ctx, oracle):
     assert any(20 in set(np.frombuffer(w[1], api.EVENT_DTYPE)["type"].tolist()) for w in want)     # META_RESETs happened
 
 
+def test_dmr_event_row_overflow_truncates_like_the_burst_serial_decoder(ctx, oracle):
+    """An event row that is too small: the reference-shaped decoder (oracle) drops the events that do not fit, finishes the burst in which
+    that happened and stops; dh_engine_sync reports DH_ECAPACITY.  The frame-parallel DMR decoder must cut at the same burst -- its
+    pass C notices the overflow on the per-burst event counts of a whole chunk and walks the chunk again up to that burst.  Streams
+    built to emit FIVE events per burst (every burst claims slot 0 in its TACT: slot switch + sync + slot type + BPTC + LC) against a
+    row sized for four, the overflow falling at different bursts of different chunks per channel."""
+    import ctypes as C
+    from digiham_amd import api
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    rows = []
+    for c in range(6):
+        five = [160, 120, 90, 64, 40, 30][c]                    # bursts with five events, then four per burst: the row overflows at another burst per channel
+        s = list(rng.integers(0, 4, 7 * c))
+        for i in range(160):
+            lc = synth.dmr_lc(0, 0, 0, int(rng.integers(1, 1 << 24)), int(rng.integers(1, 1 << 24)))
+            slot = 0 if i < five else (i - five + 1) & 1
+            s += list(synth.dmr_data_burst(slot, 1, 1, bytes(lc) + bytes(3), "bs_data", rng))
+        rows.append(np.array(s, np.uint8))
+    n = min(len(r) for r in rows)
+    syms = np.stack([r[:n] for r in rows])
+    B = len(rows)
+    eng = api.Engine(B, n, rrc="none", demod="none", proto="dmr", ctx=ctx)
+    eng.push_symbols(np.ascontiguousarray(syms), np.full(B, n, np.uint32))
+    with pytest.raises(RuntimeError, match="DH_ECAPACITY"):
+        eng.sync()
+    lib = ctx.lib
+    p, stride, cnt = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    assert lib.dh_engine_events(eng._h, C.byref(p), C.byref(stride), C.byref(cnt)) == 0
+    cap = stride.value
+    erows = np.empty((B, cap), api.EVENT_DTYPE); ecnt = np.empty(B, np.uint32)
+    assert lib.dh_copy_to_host(erows.ctypes.data_as(C.c_void_p), p, erows.nbytes) == 0
+    assert lib.dh_copy_to_host(ecnt.ctypes.data_as(C.c_void_p), cnt, ecnt.nbytes) == 0
+    p2, stride2, cnt2 = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    assert lib.dh_engine_frames(eng._h, C.byref(p2), C.byref(stride2), C.byref(cnt2)) == 0
+    frows = np.empty((B, stride2.value), np.uint8); fcnt = np.empty(B, np.uint32)
+    assert lib.dh_copy_to_host(frows.ctypes.data_as(C.c_void_p), p2, frows.nbytes) == 0
+    assert lib.dh_copy_to_host(fcnt.ctypes.data_as(C.c_void_p), cnt2, fcnt.nbytes) == 0
+    overflowed = 0
+    for b in range(B):
+        d = O.Decoder("dmr")
+        out = np.zeros(n + 256, np.uint8); oev = np.zeros(cap, O.EVENT_DTYPE)
+        no, ne = C.c_size_t(), C.c_size_t()
+        O.lib().orc_decoder_process(d._h, O._p(syms[b]), C.c_size_t(n), O._p(out), C.c_size_t(out.size), C.byref(no), O._p(oev), C.c_size_t(cap), C.byref(ne))
+        assert ecnt[b] == ne.value, (b, int(ecnt[b]), ne.value)
+        assert erows[b, :ecnt[b]].tobytes() == oev[:ne.value].tobytes(), b
+        assert fcnt[b] == no.value and (frows[b, :fcnt[b]] == out[:no.value]).all(), b
+        overflowed += int(ne.value == cap)
+    assert overflowed >= 5
+    eng.close()
+
+
 def test_lc_fields_from_events(ctx):
     """The LC words carried by DH_EV_DMR_LC events decode to the source / target ids the generator put in
     (Digiham::Dmr::Lc getters, lc.cpp:26-43) -- for the voice-header LC (BPTC) and the embedded LC alike."""
