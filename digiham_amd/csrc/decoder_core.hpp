@@ -1878,7 +1878,15 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
                     const int sizes[4] = { 36, 36, nahead > 2u ? 36 : 0, nahead > 3u ? 36 : 0 };
                     dh_viterbi_wave<true, false>(S, sizes);
                     DH_FOR_LANES(lane) {
-                        if (lane < 8) S.colword[lane] = ((uint32_t) lane >> 1) < nahead ? reinterpret_cast<const uint32_t*>(S.vit_out[lane >> 1])[lane & 1] : 0u;
+                        // lanes 0 .. 3: the five bytes of one frame's SACCH and its CRC-6 (sacch.cpp:70-84), checked here, one frame per lane
+                        // (bit 31 of the second word says "CRC right"; bytes 5 .. 7 of an entry are not used)
+                        if (lane < 4) {
+                            const uint32_t* w = reinterpret_cast<const uint32_t*>(S.vit_out[lane]);
+                            const uint32_t w0 = (uint32_t) lane < nahead ? w[0] : 0u, w1 = (uint32_t) lane < nahead ? w[1] & 0xFFu : 0u;
+                            const uint8_t by[5] = { (uint8_t) w0, (uint8_t) (w0 >> 8), (uint8_t) (w0 >> 16), (uint8_t) (w0 >> 24), (uint8_t) w1 };
+                            const bool ok = dh_nxdn_crc_ok(by, 26, 6, 0x3Fu, 0x13u, by[3] & 0x3Fu);
+                            S.colword[2 * lane] = w0; S.colword[2 * lane + 1] = w1 | (ok ? 0x80000000u : 0u);
+                        }
                     }
                     DH_BARRIER();
                     ahead_pos = pos; ahead_n = nahead; sacch_slot = 0;
@@ -1914,7 +1922,9 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
                 const uint8_t* w = sacch_from_cache ? reinterpret_cast<const uint8_t*>(S.colword + 2u * sacch_slot) : S.vit_out[0];
                 uint8_t sacch[5];
                 for (int i = 0; i < 5; i++) sacch[i] = (uint8_t) dh_uniform(w[i]);
-                if (dh_nxdn_crc_ok(sacch, 26, 6, 0x3Fu, 0x13u, sacch[3] & 0x3Fu)) {
+                const bool sacch_ok = sacch_from_cache ? (dh_uniform(S.colword[2u * sacch_slot + 1u]) >> 31) != 0u
+                                                       : dh_nxdn_crc_ok(sacch, 26, 6, 0x3Fu, 0x13u, sacch[3] & 0x3Fu);
+                if (sacch_ok) {
                     const uint32_t index = ((uint32_t) sacch[0] >> 6) ^ 3u;
                     dh_emit_w(c, DH_EV_NXDN_SACCH, index, 0, 5, (uint32_t) sacch[0] | (uint32_t) sacch[1] << 8 | (uint32_t) sacch[2] << 16 | (uint32_t) sacch[3] << 24, sacch[4]);
                     uint32_t have = s[DS_NX_HAVE];
@@ -1937,6 +1947,22 @@ DH_HD void dh_nxdn_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, ui
             }
             used += 30;
             bool released = false;
+            if (option == 3u && sync_count >= 1 && P.out_cap - c.nout >= 36u) {
+                // both blocks are voice (the usual frame of a call): their 2 x 18 bytes in ONE pass of 36 lanes (nxdn_phase.cpp:136-150, twice)
+                dh_emit_w(c, DH_EV_NXDN_SYNC_VOICE, 0, 0, 0);
+                dh_emit_w(c, DH_EV_NXDN_SYNC_VOICE, 0, 0, 0);
+                uint8_t* o = c.out + c.nout;
+                DH_FOR_LANES(lane) {
+                    if (lane < 36) {
+                        const uint32_t blk = lane >= 18 ? 1u : 0u, j = (uint32_t) lane - 18u * blk;
+                        uint32_t v = 0;
+                        for (int q = 0; q < 4; q++) v = (v << 2) | dh_nxdn_dibit(syms, pos, 38u + 72u * blk + 4u * j + (uint32_t) q);
+                        o[lane] = (uint8_t) v;
+                    }
+                }
+                c.nout += 36;
+                used += 144;
+            } else
             for (int i = 0; i < 2 && !released; i++) {
                 if ((option >> (1 - i)) & 1u) {                                   // voice (nxdn_phase.cpp:136-150)
                     if (sync_count >= 1) {
