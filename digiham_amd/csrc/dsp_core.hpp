@@ -624,11 +624,12 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 // dh_f16_error_coefficient() adds it all up (reference chain gamma_82 + its division; 123 u for the three chained MFMAs of
 // M; the split residuals; the dropped products; the two roundings of the combine) and keeps the 1.44 of head room for the
 // slicer's own roundings that the f32 bound has.  Toeplitz layout as in dh_fir_mfma, natural block order:
-//   A: lane (m = l & 15, q = l >> 4) holds h[16 (16 T + m) + 32 s + 8 q + j], j = 0..7 -- ONE ds_read_b128 from the plain f16
-//      window (32 bytes per row, 16 per q: conflict-free in every lane group of a b128 read)
+//   A: lane (m = l & 15, q = l >> 4) holds h[16 (16 T + b(m)) + 32 s + 8 q + j], j = 0..7 -- ONE ds_read_b128 from the plain f16
+//      window (32 bytes per row, 16 per q: conflict-free in every lane group of a b128 read); b(m) = DH_F16_ROW_BLOCK(m), a
+//      permutation of the tile's sixteen blocks inside each half of the rows (see DH_F16_OUT)
 //   B: lane (n = l & 15, q = l >> 4) holds g[32 s + 8 q + j - n]: per-lane fragments precomputed on the host (6 x 1 KiB,
 //      dh_f16_tap_fragments), fetched with the samples
-//   D: lane (n, g), register r holds y[256 T + 64 g + 16 r + n]
+//   D: lane (n, g), register r holds y[256 T + 16 b(4 g + r) + n] = y[DH_F16_OUT(T, r, g, n)]
 #define DH_FIR_F16 1
 #define DH_PLAN_FAST 1                       // sps-10 kernels: the run planning of a whole-block run in three compares
 #define DH_EXACT_BATCH 2                     // exact evaluations of the 81-tap kernels: this many products at a time, their LDS reads in flight together (the 161-tap ones: 8)
@@ -640,7 +641,11 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 #define DH_F16_MAX_KSTEPS DH_F16_KSTEPS_OF(DH_MAX_NZ)
 #define DH_F16_HALVES_OF(nz) (1008 + 32 * DH_F16_KSTEPS_OF(nz))     // halves per array: the last block (63) reads up to here
 #define DH_F16_H2_OFFSET_OF(nz) (DH_F16_HALVES_OF(nz) / 2)           // word offset of the h2 array inside the window block
-#define DH_F16_OUT(T, r, g, n) (256u * (uint32_t) (T) + 64u * (uint32_t) (g) + 16u * (uint32_t) (r) + (uint32_t) (n))
+// Row m = 4 g + r of a tile (the block of sixteen outputs an A row produces) is block 2 r + (g & 1) + 8 (g >> 1) of the tile, not block m:
+// register r of the lanes of ONE store pass (32 lanes: g = 0, 1 or g = 2, 3) then covers 32 consecutive words -- in natural order the
+// two groups of a pass were 64 words apart and every result store ran into a two-way bank conflict.
+#define DH_F16_ROW_BLOCK(m) (2u * ((uint32_t) (m) & 3u) + (((uint32_t) (m) >> 2) & 1u) + 8u * ((uint32_t) (m) >> 3))
+#define DH_F16_OUT(T, r, g, n) (256u * (uint32_t) (T) + 128u * ((uint32_t) (g) >> 1) + 32u * (uint32_t) (r) + 16u * ((uint32_t) (g) & 1u) + (uint32_t) (n))
 
 // IEEE binary16 <-> binary32 in integer arithmetic (host and harness; the device converts in hardware): round to nearest even
 DH_HD uint16_t dh_f16_bits(float f) {
@@ -743,7 +748,7 @@ template <int NZ>
 __device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[2 * DH_F16_KSTEPS_OF(NZ)], int lane, float k1, float k2, float* out16) {
     constexpr int DH_F16_KSTEPS = DH_F16_KSTEPS_OF(NZ), DH_F16_FRAGS = 2 * DH_F16_KSTEPS, DH_F16_H2_OFFSET = DH_F16_H2_OFFSET_OF(NZ);
     const int m = lane & 15, q = lane >> 4;
-    const char* base = reinterpret_cast<const char*>(hw) + 32 * m + 16 * q;
+    const char* base = reinterpret_cast<const char*>(hw) + 32 * (int) DH_F16_ROW_BLOCK(m) + 16 * q;
     dh_h8 g[DH_F16_FRAGS];
 #pragma unroll
     for (int f = 0; f < DH_F16_FRAGS; f++) g[f] = __builtin_bit_cast(dh_h8, G[f]);
