@@ -390,6 +390,12 @@ template <int O0, int O1> __device__ __forceinline__ dh_f2 dh_lds_read2(uint32_t
     asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
     return v;
 }
+// (eight bytes from a four-byte aligned address: the queue's LDS alignment mode is "unaligned" on this target)
+template <int OFF_BYTES> __device__ __forceinline__ dh_f2 dh_lds_read_b64(uint32_t addr) {
+    dh_f2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES) : "memory");
+    return v;
+}
 // pair i of the slide sequence: (x[8 + i], x[16 + i]), consumed when tap i has been accumulated
 template <int NZ, int I> __device__ __forceinline__ void dh_fir_issue_one(uint32_t addr, dh_f2& d) {
     if constexpr (I < NZ) d = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr);
@@ -1893,47 +1899,49 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const bool pair_store = ((uint32_t) (uintptr_t) syms + nsym) % 2u == 0u;      // (paired slicing phases: symbols 2 l, 2 l + 1 of the run as one 16-bit store)
 
         // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
-        // sps 10: TWO symbols per lane, the whole run in one pass of straight-line code.  A lane's symbols q and q + 24 both lie
-        // behind the pending timing step, so their samples sit at compile-time offsets (i and 240 + i words) from ONE per-lane
-        // base and a single ds_read2_b32 delivers sample i of both as a register pair:
-        //   lanes 0..23: q = lane + 1 (and q + 24);  lanes 24..47: q = lane + 25 (and q + 24);  lanes 48..50: q = lane + 49 alone (as
-        //   the second of a pair whose first is not theirs: every read stays inside the window block);  lane 51: symbol 0, the only
-        //   one in front of the step.
-        // The two symbols of a lane share every addition (v_pk_add_f32 on the pair: each symbol's sums still run in sample order,
-        // as the reference's do) and the division; loads and stores carry their offsets as immediates, so the phase costs ~35
-        // vector instructions instead of the ~85 of two passes of one symbol per lane.  Lanes beyond the run read words of the
-        // window block that nothing will look at (possibly halves of the staged arrays) and store nothing.
+        // sps 10: two symbols per lane -- q = lane + 1 and (lanes 0..34) q = lane + 65, lane 35: symbol 0, the only one in front of the pending
+        // timing step -- each read as five ds_read_b64 at compile-time offsets from one per-lane base (eight bytes from a four-byte aligned
+        // address: the symbols start 40 bytes apart and a timing step moves them by four).  Ten words per lane, read in pairs, touch every
+        // bank twice per 32 lanes: conflict-free.  Until the end of round 5 the two symbols of a lane were 24 symbols apart and a
+        // ds_read2_b32 delivered sample i of both as a register pair for packed additions (16 vector instructions less per run): a
+        // ten-word lane stride read ONE word at a time only ever reaches the sixteen banks of its parity, every read was a two-way conflict --
+        // SQ_LDS_BANK_CONFLICT 4.75e8 -> 1.74e8 per launch, SQ_LDS_IDX_ACTIVE -21 %, chain -2 % (profiles/r05_a_ab_logs.txt).  Each
+        // symbol's sums run in sample order, as the reference's do.  Lanes beyond the run read words of the window block that nothing will
+        // look at and store nothing.
         if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
             const uint32_t l = (uint32_t) lane;
-            const uint32_t qa = l < 51u ? l + 1u + (l >= 24u ? 24u : 0u) : 0u, qb = qa + 24u;
-            const bool va = (l < 48u || l == 51u) && qa < m, vb = l < 51u && qb < m;
-            const float* src = fbuf + (l < 51u ? (int32_t) (qa * 10u) + step_off : 0);
-            dh_f2 v[10];
+            const uint32_t qa = l + 1u, qb = l < 35u ? l + 65u : 0u;
+            const bool va = qa < m, vb = l < 35u ? qb < m : l == 35u;
+            const float* srca = fbuf + (int32_t) (qa * 10u) + step_off;
+            const float* srcb = l < 35u ? srca + 640 : fbuf;
+            float v[10], w[10];
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
             {
-                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
-                v[0] = dh_lds_read2<0, 240>(a); v[1] = dh_lds_read2<1, 241>(a); v[2] = dh_lds_read2<2, 242>(a); v[3] = dh_lds_read2<3, 243>(a);
-                v[4] = dh_lds_read2<4, 244>(a); v[5] = dh_lds_read2<5, 245>(a); v[6] = dh_lds_read2<6, 246>(a); v[7] = dh_lds_read2<7, 247>(a);
-                v[8] = dh_lds_read2<8, 248>(a); v[9] = dh_lds_read2<9, 249>(a);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]) :: "memory");
+                const uint32_t aa = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) srca;
+                const uint32_t ab = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) srcb;
+                dh_f2 x0 = dh_lds_read_b64<0>(aa), x1 = dh_lds_read_b64<8>(aa), x2 = dh_lds_read_b64<16>(aa), x3 = dh_lds_read_b64<24>(aa), x4 = dh_lds_read_b64<32>(aa);
+                dh_f2 y0 = dh_lds_read_b64<0>(ab), y1 = dh_lds_read_b64<8>(ab), y2 = dh_lds_read_b64<16>(ab), y3 = dh_lds_read_b64<24>(ab), y4 = dh_lds_read_b64<32>(ab);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4) :: "memory");
+                v[0] = x0.x; v[1] = x0.y; v[2] = x1.x; v[3] = x1.y; v[4] = x2.x; v[5] = x2.y; v[6] = x3.x; v[7] = x3.y; v[8] = x4.x; v[9] = x4.y;
+                w[0] = y0.x; w[1] = y0.y; w[2] = y1.x; w[3] = y1.y; w[4] = y2.x; w[5] = y2.y; w[6] = y3.x; w[7] = y3.y; w[8] = y4.x; w[9] = y4.y;
             }
 #else
-            for (int i = 0; i < 10; i++) v[i] = dh_f2_make(src[i], src[240 + i]);
+            for (int i = 0; i < 10; i++) { v[i] = srca[i]; w[i] = srcb[i]; }
 #endif
-            dh_f2 vol = v[0];
+            float vola = v[0], volb = w[0];
 #pragma unroll
-            for (int i = 1; i < 10; i++) vol = dh_f2_add(vol, v[i]);
-            const dh_f2 mid = dh_f2_add(dh_f2_add(dh_f2_add(v[3], v[4]), v[5]), v[6]);          // samples ev_lo .. ev_hi - 1 = 3 .. 6
-            const dh_f2 volume = dh_div_const2(vol, 10.0f, sps_rcp);
-            const uint32_t ka = k0 + qa;
-            float* ring = S.var_rb + ka;
+            for (int i = 1; i < 10; i++) { vola += v[i]; volb += w[i]; }
+            const float mida = ((v[3] + v[4]) + v[5]) + v[6], midb = ((w[3] + w[4]) + w[5]) + w[6];          // samples ev_lo .. ev_hi - 1 = 3 .. 6
+            const float volume_a = dh_div_const(vola, 10.0f, sps_rcp), volume_b = dh_div_const(volb, 10.0f, sps_rcp);
             if (va) {
-                dh_lds_store_row10<0>(ring, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x, v[9].x);      // transposed ring: phase-major
-                S.sum[qa] = mid.x; S.vol_new[ka] = volume.x;
+                const uint32_t ka = k0 + qa;
+                dh_lds_store_row10<0>(S.var_rb + ka, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
+                S.sum[qa] = mida; S.vol_new[ka] = volume_a;
             }
             if (vb) {
-                dh_lds_store_row10<24>(ring, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y, v[9].y);
-                S.sum[qb] = mid.y; S.vol_new[ka + 24u] = volume.y;
+                const uint32_t kb = k0 + qb;
+                dh_lds_store_row10<0>(S.var_rb + kb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9]);
+                S.sum[qb] = midb; S.vol_new[kb] = volume_b;
             }
             dh_lds_stores_done();
         }
