@@ -396,6 +396,12 @@ template <int OFF_BYTES> __device__ __forceinline__ dh_f2 dh_lds_read_b64(uint32
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES) : "memory");
     return v;
 }
+typedef float dh_v4f __attribute__((ext_vector_type(4)));
+template <int OFF_BYTES> __device__ __forceinline__ dh_v4f dh_lds_read_b128(uint32_t addr) {
+    dh_v4f v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES) : "memory");
+    return v;
+}
 // pair i of the slide sequence: (x[8 + i], x[16 + i]), consumed when tap i has been accumulated
 template <int NZ, int I> __device__ __forceinline__ void dh_fir_issue_one(uint32_t addr, dh_f2& d) {
     if constexpr (I < NZ) d = dh_lds_read2<DH_XLOFF(DH_FIR_H + I), DH_XLOFF(2 * DH_FIR_H + I)>(addr);
@@ -1357,7 +1363,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
     const uint32_t sps = SPS ? (uint32_t) SPS : P.sps;
-    const uint32_t ev_lo = SPS == 10 ? 3u : P.lo, ev_hi = SPS == 10 ? 7u : P.hi;
+    const uint32_t ev_lo = SPS == 10 ? 3u : SPS == 20 ? 7u : P.lo, ev_hi = SPS == 10 ? 7u : SPS == 20 ? 13u : P.hi;        // (round(sps / 3), round(2 sps / 3): engine_impl.hpp)
     const float sps_rcp = 1.0f / (float) sps;           // correctly rounded (IEEE division, once per push)
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
     const float* in = P.in + (size_t) ch * P.in_stride + part_lo;
@@ -1945,7 +1951,40 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
             dh_lds_stores_done();
         }
-        if (SPS != 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        // sps 20 (a FIR pass holds at most 51 symbols): one symbol per lane, q = lane + 1, lane 63: symbol 0; its twenty samples as five
+        // ds_read_b128 (sixteen bytes from a four-byte aligned address).  Twenty words per lane read in fours touch every bank once per
+        // eight lanes; read one word at a time (the general form below) every read was a four-way conflict.
+        if (SPS == 20 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+            const uint32_t l = (uint32_t) lane;
+            const uint32_t q = l < 63u ? l + 1u : 0u;
+            const bool valid = q < m;
+            const float* src = valid && q > 0u ? fbuf + (int32_t) (q * 20u) + step_off : fbuf;       // (lanes beyond the run read symbol 0 and store nothing)
+            float v[20];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            {
+                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
+                dh_v4f x0 = dh_lds_read_b128<0>(a), x1 = dh_lds_read_b128<16>(a), x2 = dh_lds_read_b128<32>(a), x3 = dh_lds_read_b128<48>(a), x4 = dh_lds_read_b128<64>(a);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4) :: "memory");
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w; v[8] = x2.x; v[9] = x2.y;
+                v[10] = x2.z; v[11] = x2.w; v[12] = x3.x; v[13] = x3.y; v[14] = x3.z; v[15] = x3.w; v[16] = x4.x; v[17] = x4.y; v[18] = x4.z; v[19] = x4.w;
+            }
+#else
+            for (int i = 0; i < 20; i++) v[i] = src[i];
+#endif
+            float vol = v[0];
+#pragma unroll
+            for (int i = 1; i < 20; i++) vol += v[i];
+            const float mid = ((((v[7] + v[8]) + v[9]) + v[10]) + v[11]) + v[12];                    // samples ev_lo .. ev_hi - 1 = 7 .. 12
+            const float volume = dh_div_const(vol, 20.0f, sps_rcp);
+            if (valid) {
+                const uint32_t k = k0 + q;
+                dh_lds_store_row10<0>(S.var_rb + k, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
+                dh_lds_store_row10<1000>(S.var_rb + k, v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
+                S.sum[q] = mid; S.vol_new[k] = volume;
+            }
+            dh_lds_stores_done();
+        }
+        if (SPS != 10 && SPS != 20 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
