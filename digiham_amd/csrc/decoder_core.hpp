@@ -1410,46 +1410,38 @@ DH_HD void dh_ysf_decode_ahead(const DhDecParams& P, const DhFecTables& T, const
     const uint32_t a16 = (uint32_t) ((uintptr_t) syms.fresh & 15u);
     const uint32_t off0 = (pos - syms.nc + a16) & 15u;
     dh_build_chunk_planes(syms, (int32_t) pos - (int32_t) off0, (off0 + 480u * n + 15u) / 16u, total, S.ysf.plane_h, S.ysf.plane_l);
-    uint64_t dirty_f = 0, dirty_d = 0;
-    DH_LANE_VALUE(uint32_t, keep0); DH_LANE_VALUE(uint32_t, keep1); DH_LANE_VALUE(uint32_t, keep2); DH_LANE_VALUE(uint32_t, keep3);      // the dirty codewords' streams: FICH h
-    DH_LANE_VALUE(uint32_t, keep4); DH_LANE_VALUE(uint32_t, keep5); DH_LANE_VALUE(uint32_t, keep6); DH_LANE_VALUE(uint32_t, keep7);      // FICH l
-    DH_LANE_VALUE(uint32_t, keep8); DH_LANE_VALUE(uint32_t, keep9); DH_LANE_VALUE(uint32_t, keep10); DH_LANE_VALUE(uint32_t, keep11);    // DCH h
-    DH_LANE_VALUE(uint32_t, keep12); DH_LANE_VALUE(uint32_t, keep13); DH_LANE_VALUE(uint32_t, keep14); DH_LANE_VALUE(uint32_t, keep15);  // DCH l
+    // lanes 0..15: the FICH of frame `lane`, lanes 16..31: the DCH of frame `lane - 16` -- both are five rows of twenty dibits:
+    //   FICH: dibits 20 .. 119 of the frame, codeword dibit i at 20 + 20 (i % 5) + i / 5 (fich.cpp:16-19)
+    //   DCH:  the first 20 dibits of each of the five 72-dibit blocks behind dibit 120, dibit i at 120 + 72 (i % 5) + i / 5 (ysf_phase.cpp:103-106)
+    uint64_t dirty = 0;
+    DH_LANE_VALUE(uint32_t, keep0); DH_LANE_VALUE(uint32_t, keep1); DH_LANE_VALUE(uint32_t, keep2); DH_LANE_VALUE(uint32_t, keep3);      // a dirty codeword's streams: h
+    DH_LANE_VALUE(uint32_t, keep4); DH_LANE_VALUE(uint32_t, keep5); DH_LANE_VALUE(uint32_t, keep6); DH_LANE_VALUE(uint32_t, keep7);      // l
     DH_FOR_LANES(lane) {
-        const uint32_t f = (uint32_t) lane < n ? (uint32_t) lane : 0u;         // (lanes beyond the chunk repeat frame 0 and store nothing)
-        const uint32_t o = off0 + 480u * f;
-        uint32_t xh[4], xl[4], fh[4], fl[4], dh[4], dl[4], out[4];
-        // FICH: dibits 20 .. 119 of the frame, codeword dibit i at 20 + 20 (i % 5) + i / 5 (fich.cpp:16-19)
-        xh[0] = dh_plane_bits(S.ysf.plane_h, o + 20u, 32); xh[1] = dh_plane_bits(S.ysf.plane_h, o + 52u, 32);
-        xh[2] = dh_plane_bits(S.ysf.plane_h, o + 84u, 32); xh[3] = dh_plane_bits(S.ysf.plane_h, o + 116u, 4);
-        xl[0] = dh_plane_bits(S.ysf.plane_l, o + 20u, 32); xl[1] = dh_plane_bits(S.ysf.plane_l, o + 52u, 32);
-        xl[2] = dh_plane_bits(S.ysf.plane_l, o + 84u, 32); xl[3] = dh_plane_bits(S.ysf.plane_l, o + 116u, 4);
-        dh_transpose_5x20(xh, fh); dh_transpose_5x20(xl, fl);
-        const bool bad_f = dh_ysf_clean100(fh, fl, out);
-        if ((uint32_t) lane < n) { S.ysf.res[f][0][0] = out[0]; S.ysf.res[f][0][1] = out[1]; S.ysf.res[f][0][2] = out[2]; S.ysf.res[f][0][3] = out[3]; }
-        // DCH: the first 20 dibits of each of the five 72-dibit blocks behind dibit 120, dibit i at 120 + 72 (i % 5) + i / 5 (ysf_phase.cpp:103-106)
+        const uint32_t kind = ((uint32_t) lane >> 4) & 1u, fl = (uint32_t) lane & 15u;
+        const bool mine = (uint32_t) lane < 32u && fl < n;
+        const uint32_t f = mine ? fl : 0u;                                    // (lanes beyond the chunk repeat frame 0 and store nothing)
+        const uint32_t o = off0 + 480u * f, first = o + (kind ? 120u : 20u), step = kind ? 72u : 20u;
+        uint32_t xh[4], xl[4], ch[4], cl[4], out[4];
         {
             uint32_t rh[5], rl[5];
 #pragma unroll
-            for (int b = 0; b < 5; b++) { rh[b] = dh_plane_bits(S.ysf.plane_h, o + 120u + 72u * (uint32_t) b, 20); rl[b] = dh_plane_bits(S.ysf.plane_l, o + 120u + 72u * (uint32_t) b, 20); }
+            for (int b = 0; b < 5; b++) { rh[b] = dh_plane_bits(S.ysf.plane_h, first + step * (uint32_t) b, 20); rl[b] = dh_plane_bits(S.ysf.plane_l, first + step * (uint32_t) b, 20); }
             xh[0] = rh[0] | rh[1] << 20; xh[1] = rh[1] >> 12 | rh[2] << 8 | rh[3] << 28; xh[2] = rh[3] >> 4 | rh[4] << 16; xh[3] = rh[4] >> 16;
             xl[0] = rl[0] | rl[1] << 20; xl[1] = rl[1] >> 12 | rl[2] << 8 | rl[3] << 28; xl[2] = rl[3] >> 4 | rl[4] << 16; xl[3] = rl[4] >> 16;
         }
-        dh_transpose_5x20(xh, dh); dh_transpose_5x20(xl, dl);
-        const bool bad_d = dh_ysf_clean100(dh, dl, out);
-        if ((uint32_t) lane < n) { S.ysf.res[f][1][0] = out[0]; S.ysf.res[f][1][1] = out[1]; S.ysf.res[f][1][2] = out[2]; S.ysf.res[f][1][3] = out[3]; }
-        // the frame's sync word (ysf_phase.cpp:16-18): one bit, kept in the top of the DCH entry's fourth word
-        {
-            constexpr uint32_t YH = DH_YSF_SYNC_H, YL = DH_YSF_SYNC_L;
-            const bool is_sync = dh_popc32(dh_plane_bits(S.ysf.plane_h, o, 20) ^ YH) + dh_popc32(dh_plane_bits(S.ysf.plane_l, o, 20) ^ YL) <= 3;
-            if ((uint32_t) lane < n) S.ysf.res[f][1][3] = (out[3] & 0xFFu) | (is_sync ? 0x80000000u : 0u);      // (byte 12 of the DCH is the word's first byte; 13..15 are unused)
+        dh_transpose_5x20(xh, ch); dh_transpose_5x20(xl, cl);
+        const bool bad = dh_ysf_clean100(ch, cl, out);
+        // the frame's sync word (ysf_phase.cpp:16-18): one bit, kept in the top of the DCH entry's fourth word (byte 12 of the DCH is the
+        // word's first byte; 13..15 are unused)
+        constexpr uint32_t YH = DH_YSF_SYNC_H, YL = DH_YSF_SYNC_L;
+        const bool is_sync = dh_popc32(dh_plane_bits(S.ysf.plane_h, o, 20) ^ YH) + dh_popc32(dh_plane_bits(S.ysf.plane_l, o, 20) ^ YL) <= 3;
+        if (mine) {
+            uint32_t* r = S.ysf.res[f][kind];
+            r[0] = out[0]; r[1] = out[1]; r[2] = out[2]; r[3] = kind ? (out[3] & 0xFFu) | (is_sync ? 0x80000000u : 0u) : out[3];
         }
-        DH_BALLOT_ACC(dirty_f, (uint32_t) lane < n && bad_f, lane);
-        DH_BALLOT_ACC(dirty_d, (uint32_t) lane < n && bad_d, lane);
-        DH_LV(keep0, lane) = fh[0]; DH_LV(keep1, lane) = fh[1]; DH_LV(keep2, lane) = fh[2]; DH_LV(keep3, lane) = fh[3];
-        DH_LV(keep4, lane) = fl[0]; DH_LV(keep5, lane) = fl[1]; DH_LV(keep6, lane) = fl[2]; DH_LV(keep7, lane) = fl[3];
-        DH_LV(keep8, lane) = dh[0]; DH_LV(keep9, lane) = dh[1]; DH_LV(keep10, lane) = dh[2]; DH_LV(keep11, lane) = dh[3];
-        DH_LV(keep12, lane) = dl[0]; DH_LV(keep13, lane) = dl[1]; DH_LV(keep14, lane) = dl[2]; DH_LV(keep15, lane) = dl[3];
+        DH_BALLOT_ACC(dirty, mine && bad, lane);
+        DH_LV(keep0, lane) = ch[0]; DH_LV(keep1, lane) = ch[1]; DH_LV(keep2, lane) = ch[2]; DH_LV(keep3, lane) = ch[3];
+        DH_LV(keep4, lane) = cl[0]; DH_LV(keep5, lane) = cl[1]; DH_LV(keep6, lane) = cl[2]; DH_LV(keep7, lane) = cl[3];
     }
     // the V/D2 voice blocks (ysf_phase.cpp:180-256) of every frame, one (frame, block) per lane, while the planes are there
     DH_FOR_LANES(lane) {
@@ -1462,24 +1454,17 @@ DH_HD void dh_ysf_decode_ahead(const DhDecParams& P, const DhFecTables& T, const
             S.ysf.voice[f][2u * b] = v0; S.ysf.voice[f][2u * b + 1u] = v1;
         }
     }
-    const uint32_t nf = (uint32_t) dh_popc64(dirty_f), nd = nf + (uint32_t) dh_popc64(dirty_d);
+    const uint32_t nd = (uint32_t) dh_popc64(dirty);
     if (nd == 0u) { DH_BARRIER(); dh_ysf_check_ahead(P, T, n, S); return; }
     DH_BARRIER();                                                  // every lane has read the planes: their block takes the dirty streams
     uint8_t* const who = reinterpret_cast<uint8_t*>(S.colword);    // rank -> frame | codeword << 7
     DH_FOR_LANES(lane) {
-        if ((dirty_f >> lane) & 1ull) {
-            const uint32_t r = DH_LANES_BELOW(dirty_f, lane);
+        if ((dirty >> lane) & 1ull) {
+            const uint32_t r = DH_LANES_BELOW(dirty, lane);
             uint32_t* d = S.ysf.dirty[r];
             d[0] = DH_LV(keep0, lane); d[1] = DH_LV(keep1, lane); d[2] = DH_LV(keep2, lane); d[3] = DH_LV(keep3, lane);
             d[4] = DH_LV(keep4, lane); d[5] = DH_LV(keep5, lane); d[6] = DH_LV(keep6, lane); d[7] = DH_LV(keep7, lane);
-            who[r] = (uint8_t) lane;
-        }
-        if ((dirty_d >> lane) & 1ull) {
-            const uint32_t r = nf + DH_LANES_BELOW(dirty_d, lane);
-            uint32_t* d = S.ysf.dirty[r];
-            d[0] = DH_LV(keep8, lane); d[1] = DH_LV(keep9, lane); d[2] = DH_LV(keep10, lane); d[3] = DH_LV(keep11, lane);
-            d[4] = DH_LV(keep12, lane); d[5] = DH_LV(keep13, lane); d[6] = DH_LV(keep14, lane); d[7] = DH_LV(keep15, lane);
-            who[r] = (uint8_t) (lane | 128);
+            who[r] = (uint8_t) (((uint32_t) lane & 15u) | (((uint32_t) lane >> 4) << 7));
         }
     }
     DH_BARRIER();

@@ -2051,7 +2051,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[k + 1u]), mx = dh_f2_make(S.mx[k], S.mx[k + 1u]);
             const dh_f2 sumq = dh_f2_make(S.sum[qq], S.sum[qq + 1u]);
             const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);                // (max + min) / 2.0f: the division by two is exact
-            const dh_f2 average = width_pow2 ? dh_f2_scale(sumq, inv_width) : dh_f2_make(sumq.x / (float) (ev_hi - ev_lo), sumq.y / (float) (ev_hi - ev_lo));
+            // (sps 20: the division by the window's six samples as reciprocal product + exact residual + correction, dh_div_const; tests/test_numerics.py)
+            const dh_f2 average = width_pow2 ? dh_f2_scale(sumq, inv_width) : SPS == 20 ? dh_div_const2(sumq, 6.0f, inv_width)
+                                                                                        : dh_f2_make(sumq.x / (float) (ev_hi - ev_lo), sumq.y / (float) (ev_hi - ev_lo));
             const dh_f2 c625 = dh_f2_make(0.625f, 0.625f);
             const dh_f2 umid = dh_f2_fma(dh_f2_sub(mx, center), c625, center);        // one float FMA each: see the one-symbol form below
             const dh_f2 lmid = dh_f2_fma(dh_f2_sub(mn, center), c625, center);

@@ -45,9 +45,9 @@ def test_gain_division_is_exactly_the_double_division(ctx, narrow):
     assert ties.size > 100
 
 
-@pytest.mark.parametrize("divisor", [5, 10, 20, 40])
+@pytest.mark.parametrize("divisor", [5, 6, 10, 20, 40])
 def test_division_by_samples_per_symbol_is_the_ieee_division(ctx, divisor):
-    """`volume_sum / samplesPerSymbol` (gfsk_demodulator.cpp:83) as three instructions (reciprocal product, exact FMA
+    """`volume_sum / samplesPerSymbol` (gfsk_demodulator.cpp:83; 6 = the `sum / (highestEval - lowestEval)` of sps 20, :91) as three instructions (reciprocal product, exact FMA
     residual, correction; dsp_core.hpp: dh_div_const): equal to the IEEE float division for random floats of every
     exponent, signal-sized values, the guard band around 2^-100 / 2^100, zeros, infinities and NaN."""
     rng = np.random.default_rng(23 + divisor)
