@@ -1253,10 +1253,6 @@ DH_HD void dh_ysf_v2_block(uint64_t hx, uint64_t lx, uint32_t& out_lo, uint32_t&
     out_lo = (uint32_t) out; out_hi = (uint32_t) (out >> 32);
 }
 
-DH_HD void dh_ysf_enter_frame_phase(DhState& s) {
-    s[DS_SYNC_COUNT] = 0; s[DS_HAS_FICH] = 0; s[DS_FICH] = 0; s[DS_EXPECT_SUB] = 0;
-}
-
 DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.cpp:16-18
     constexpr uint32_t YH = DH_YSF_SYNC_H, YL = DH_YSF_SYNC_L;
     return dh_popc32(dh_plane_range(p.h, start, 20) ^ YH) + dh_popc32(dh_plane_range(p.l, start, 20) ^ YL) <= 3;
@@ -1524,6 +1520,14 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
     uint32_t pos = 0, phase = s[DS_PHASE];
     // frames whose two codewords are already decoded (dh_ysf_decode_ahead): the one at ahead_pos is S.ysf.res[ahead_i], ahead_n in all
     uint32_t ahead_pos = 0xFFFFFFFFu, ahead_i = 0, ahead_n = 0;
+    // ... and what the frame loop wants of them, one frame per lane: the FICH word; its flags (bit 0 fresh, bit 1 the DCH's CRC, bit 31 the
+    // frame's sync word); the DCH's first three words.  A frame's values are read with v_readlane: fetched from LDS one by one, six round
+    // trips per frame were a third of the loop's time.
+    DH_LANE_VALUE(uint32_t, fr_fich); DH_LANE_VALUE(uint32_t, fr_flags); DH_LANE_VALUE(uint32_t, fr_d0); DH_LANE_VALUE(uint32_t, fr_d1); DH_LANE_VALUE(uint32_t, fr_d2);
+    DH_FOR_LANES(lane) { DH_LV(fr_fich, lane) = 0; DH_LV(fr_flags, lane) = 0; DH_LV(fr_d0, lane) = 0; DH_LV(fr_d1, lane) = 0; DH_LV(fr_d2, lane) = 0; }
+    // the frame phase's members (ysf_phase.hpp:36-44) in scalars across the loop; back into the state words behind it
+    int sync_count = (int) s[DS_SYNC_COUNT];
+    uint32_t running_fich = s[DS_FICH], has_fich = s[DS_HAS_FICH], expect_sub = s[DS_EXPECT_SUB];
 
     for (;;) {
         const uint32_t avail = total - pos;
@@ -1539,7 +1543,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             }
             if (hits) {
                 const uint32_t l = (uint32_t) dh_ffs64(hits);
-                pos += l; c.consumed += l; phase = 1; dh_ysf_enter_frame_phase(s);
+                pos += l; c.consumed += l; phase = 1; sync_count = 0; has_fich = 0; running_fich = 0; expect_sub = 0;      // FramePhase::FramePhase()
             } else {
                 const uint32_t adv = dh_min<uint32_t>(64u, avail - 20u);
                 pos += adv; c.consumed += adv;
@@ -1553,30 +1557,33 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             const uint32_t n = dh_min<uint32_t>((avail - 1u) / 480u, (uint32_t) DH_YSF_CHUNK);
             dh_ysf_decode_ahead(P, T, syms, pos, n, total, S);
             ahead_pos = pos; ahead_i = 0; ahead_n = n;
+            DH_FOR_LANES(lane) {
+                const uint32_t f = (uint32_t) lane < n ? (uint32_t) lane : 0u;
+                DH_LV(fr_fich, lane) = S.ysf.res[f][0][0]; DH_LV(fr_flags, lane) = (S.ysf.res[f][0][1] & 3u) | (S.ysf.res[f][1][3] & 0x80000000u);
+                DH_LV(fr_d0, lane) = S.ysf.res[f][1][0]; DH_LV(fr_d1, lane) = S.ysf.res[f][1][1]; DH_LV(fr_d2, lane) = S.ysf.res[f][1][2];
+            }
         }
         // (the frame's bit planes are only built for the payloads that are not decoded ahead: V/D mode 1, voice full rate, header)
         bool have_planes = false;
         auto need_planes = [&]() { if (!have_planes) { dh_view_ensure(syms, pos, 512); dh_load_planes(syms, pos, total, pl, 8); have_planes = true; } };
-        int sync_count = (int) s[DS_SYNC_COUNT];
-        if (dh_uniform(S.ysf.res[ahead_i][1][3]) >> 31) { if (++sync_count > 12) sync_count = 12; }
+        const uint32_t cw_flags = DH_LV_READ(fr_flags, ahead_i), cw_fich = DH_LV_READ(fr_fich, ahead_i);
+        if (cw_flags >> 31) { if (++sync_count > 12) sync_count = 12; }
         else if (DH_UNLIKELY(--sync_count < 0)) {
             dh_emit(c, DH_EV_YSF_META_RESET, 0, 0, nullptr, 0);
-            phase = 0; ahead_pos = 0xFFFFFFFFu; continue;
+            sync_count = 0; phase = 0; ahead_pos = 0xFFFFFFFFu; continue;
         }
-        s[DS_SYNC_COUNT] = (uint32_t) sync_count;
-        const uint32_t cw_fich = dh_uniform(S.ysf.res[ahead_i][0][0]), cw_flags = dh_uniform(S.ysf.res[ahead_i][0][1]);
-        const uint32_t* const cw_dch = S.ysf.res[ahead_i][1];
+        const uint32_t frame_i = ahead_i;
         ahead_i++; ahead_pos = pos + 480u;
 
         // FICH (fich.cpp:24-49): decoded and checked ahead
         const uint32_t fich = (cw_flags & 1u) ? cw_fich : 0u; const bool fresh = (cw_flags & 1u) != 0u;
         if (fresh) {
-            s[DS_FICH] = fich; s[DS_HAS_FICH] = 1;
+            running_fich = fich; has_fich = 1;
             dh_emit_w(c, DH_EV_YSF_FICH, 0, 0, 4, (fich >> 24) | ((fich >> 8) & 0xFF00u) | ((fich << 8) & 0xFF0000u) | (fich << 24));      // the four bytes, first on the air first
         }
 
-        if (s[DS_HAS_FICH]) {
-            const uint32_t rf = s[DS_FICH];
+        if (has_fich) {
+            const uint32_t rf = running_fich;
             const uint32_t frame_type = (rf >> 30) & 3u, data_type = (rf >> 8) & 3u;
             if (frame_type == 1) {                                                  // communication channel
                 dh_emit_w(c, DH_EV_YSF_MODE, 0, data_type, 0);
@@ -1598,7 +1605,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                     if (P.out_cap - c.nout < 40) c.overflow = true;
                     else {
                         uint8_t* o = c.out + c.nout;
-                        const uint32_t* vw = S.ysf.voice[ahead_i - 1u];
+                        const uint32_t* vw = S.ysf.voice[frame_i];
                         DH_FOR_LANES(lane) {
                             if (lane < 40) {                            // five blocks of mode byte + seven voice bytes, decoded ahead
                                 const uint32_t blk = (uint32_t) lane >> 3, j = (uint32_t) lane & 7u;
@@ -1610,14 +1617,13 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                     }
                     if (fresh) {                                                    // decodeV2DataChannel (:258-269)
                         if (cw_flags & 2u) {                                        // de-whitened (whitening.c:6-22): the first ten bytes, as words
-                            const uint32_t* w = cw_dch;
                             constexpr uint32_t PN0 = dh_pn9_le_word(0), PN1 = dh_pn9_le_word(1), PN2 = dh_pn9_le_word(2);
-                            dh_emit_w(c, DH_EV_YSF_DCH, (fich >> 19) & 7u, 0, 10, dh_uniform(w[0]) ^ PN0, dh_uniform(w[1]) ^ PN1, (dh_uniform(w[2]) ^ PN2) & 0xFFFFu);
+                            dh_emit_w(c, DH_EV_YSF_DCH, (fich >> 19) & 7u, 0, 10, DH_LV_READ(fr_d0, frame_i) ^ PN0, DH_LV_READ(fr_d1, frame_i) ^ PN1, (DH_LV_READ(fr_d2, frame_i) ^ PN2) & 0xFFFFu);
                         }
                     }
                 } else if (data_type == 3) {                                        // voice full rate (:111-130)
-                    const int start_frame = s[DS_EXPECT_SUB] ? 3 : 0;
-                    s[DS_EXPECT_SUB] = 0;
+                    const int start_frame = expect_sub ? 3 : 0;
+                    expect_sub = 0;
                     const uint32_t nbytes = (uint32_t) (5 - start_frame) * 19u;
                     if (P.out_cap - c.nout < nbytes) c.overflow = true;
                     else {
@@ -1668,7 +1674,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
                         dh_emit(c, DH_EV_YSF_HEADER_DCH, (uint8_t) half, 0, dch, 20);
                     }
                 }
-                s[DS_EXPECT_SUB] = 1;
+                expect_sub = 1;
             } else if (frame_type == 2) {                                           // terminator (:162-164)
                 dh_emit(c, DH_EV_YSF_META_RESET, 0, 2, nullptr, 0);
             }
@@ -1689,6 +1695,7 @@ DH_HD void dh_ysf_channel(const DhDecParams& P, uint32_t ch, DhDecShared& S, uin
             if ((c.overflow || rem > DH_SYM_CARRY_MAX) && P.overflow) *P.overflow = 1u;
         }
     }
+    s[DS_SYNC_COUNT] = (uint32_t) sync_count; s[DS_FICH] = running_fich; s[DS_HAS_FICH] = has_fich; s[DS_EXPECT_SUB] = expect_sub;
     s[DS_PHASE] = phase; s[DS_CONSUMED] = c.consumed;
     s[DS_CARRY] = rem < DH_SYM_CARRY_MAX ? rem : DH_SYM_CARRY_MAX;
     s.store(st_global);

@@ -21,10 +21,19 @@ def build(force=False):
     srcs = [os.path.join(_DIR, "harness.cpp")] + [os.path.join(_ROOT, "digiham_amd", "csrc", f)
                                                   for f in os.listdir(os.path.join(_ROOT, "digiham_amd", "csrc"))]
     srcs.append(os.path.join(_ROOT, "include", "digiham_amd.h"))
-    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
+    def fresh():
+        return os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)
+    if not force and fresh():
         return _SO
-    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                    "-Wno-subobject-linkage", os.path.join(_DIR, "harness.cpp"), "-o", _SO], check=True)
+    # one build at a time (pytest-xdist workers all come through here), into a temporary name: nobody loads half a library
+    import fcntl
+    with open(os.path.join(_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = _SO + ".%d.tmp" % os.getpid()
+            subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                            "-Wno-subobject-linkage", os.path.join(_DIR, "harness.cpp"), "-o", tmp], check=True)
+            os.replace(tmp, _SO)
     return _SO
 
 
