@@ -947,9 +947,11 @@ __device__ __forceinline__ float dh_wave_prev(float v, float first) {
 }
 
 // lane l owns ring slots 2l and 2l+1 for the prefix part; the suffix part is the same scan over the ring read
-// backwards (lane l takes slots 126-2l and 127-2l), handed back to the owning lanes through LDS (S.mn / S.mx are
-// the exchange buffers: each slot is written once with its suffix value and then overwritten with the result).
-__device__ __forceinline__ void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
+// backwards (lane l takes slots 126-2l and 127-2l), handed back to the owning lanes -- lane 63 - l -- by four ds_bpermute
+// (until round 5 through S.mn / S.mx: four stores, a barrier, four loads, a barrier -- one LDS round trip more).  The lane's
+// results (slots 2l and 2l+1) are also returned: the slicing phase of a run that starts its block takes them from there.
+struct DhAgcPair { float mn0, mx0, mn1, mx1; };
+__device__ __forceinline__ DhAgcPair dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
     const int lane = dh_fresh_lane_id_();
     const uint32_t e0 = 2u * (uint32_t) lane, e1 = e0 + 1u;
     // prefix source: old below k0, new in [k0, k1), identity above
@@ -969,15 +971,18 @@ __device__ __forceinline__ void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_
     // exclusive parts: everything before this lane's pair (prefix), everything after slot r1 (suffix)
     float epmn = DH_FLT_MAX, epmx = DH_FLT_MIN, esmn = DH_FLT_MAX, esmx = DH_FLT_MIN;
     dh_wave_prev4(epmn, epmx, esmn, esmx, pmn, pmx, smn, smx);
-    // suffix (exclusive of the slot itself) for slots r1 and r0
-    S.mn[r1] = esmn; S.mx[r1] = esmx;
-    S.mn[r0] = dh_vmin(omn1, esmn); S.mx[r0] = dh_vmax(omx1, esmx);
-    __syncthreads();
-    const float s0n = S.mn[e0], s0x = S.mx[e0], s1n = S.mn[e1], s1x = S.mx[e1];
-    __syncthreads();
+    // suffix (exclusive of the slot itself) for slots r1 (esmn / esmx) and r0; slot e of lane l is slot r of lane 63 - l
+    const int from = (63 - lane) << 2;
+    const float s1n = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(esmn)));
+    const float s1x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(esmx)));
+    const float s0n = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(dh_vmin(omn1, esmn))));
+    const float s0x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(dh_vmax(omx1, esmx))));
     // slot e0: prefix through e0 = before this lane + own e0; slot e1: inclusive prefix of the lane
-    S.mn[e0] = dh_vmin(dh_vmin(epmn, pmn0), s0n); S.mx[e0] = dh_vmax(dh_vmax(epmx, pmx0), s0x);
-    S.mn[e1] = dh_vmin(pmn, s1n); S.mx[e1] = dh_vmax(pmx, s1x);
+    DhAgcPair r;
+    r.mn0 = dh_vmin(dh_vmin(epmn, pmn0), s0n); r.mx0 = dh_vmax(dh_vmax(epmx, pmx0), s0x);
+    r.mn1 = dh_vmin(pmn, s1n); r.mx1 = dh_vmax(pmx, s1x);
+    S.mn[e0] = r.mn0; S.mx[e0] = r.mx0; S.mn[e1] = r.mn1; S.mx[e1] = r.mx1;
+    return r;
 }
 #else
 inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
@@ -1989,20 +1994,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
                 float sum = 0.0f, volume_sum = 0.0f;
-                if (SPS == 10) {
-                    // all ten samples first (the ring stores below may alias them as far as the compiler knows: read one by
-                    // one, every sample would wait out its own LDS round trip before the next is even requested)
-                    float value[SPS ? SPS : 1];
-#pragma unroll
-                    for (uint32_t i = 0; i < (SPS ? SPS : 1); i++) value[i] = DH_FB(s + i);
-#pragma unroll
-                    for (uint32_t i = 0; i < (SPS ? SPS : 1); i++) {
-                        if (i >= ev_lo && i < ev_hi) sum += value[i];
-                        volume_sum += value[i];
-                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value[i];    // transposed ring: phase-major
-                    }
-                } else {
-                    // four samples at a time, all four requested before the first is used (see above); sums in sample order
+                {
+                    // (the ring stores below may alias the samples as far as the compiler knows: read one by one, every sample would wait out
+                    // its own LDS round trip before the next is even requested)
+                    // four samples at a time, all four requested before the first is used; sums in sample order
                     uint32_t i = 0;
                     for (; i + 4u <= sps; i += 4u) {
                         float value[4];
@@ -2032,7 +2027,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         issue_next_window();
 
         // ---- P4: sliding AGC min/max as two wave scans
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        DhAgcPair agc = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (DH_STOP_AFTER >= 4) agc = dh_agc_scan(S, k0, k0 + m);
+#else
         if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
+#endif
         DH_BARRIER();
         DH_CLK(3);
 
@@ -2048,7 +2048,14 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             const uint32_t qa = 2u * (uint32_t) lane;
             const bool va = qa < m, vb = qa + 1u < m;
             const uint32_t qq = va ? qa : 0u, k = k0 + qq;                            // (lanes beyond the run recompute symbols 0 / 1: in-range reads, no store)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            // (a run that starts its block: the lane's symbols 2 l, 2 l + 1 are the ring slots the AGC scan left in its registers)
+            dh_f2 mn, mx;
+            if (k0 == 0u) { mn = dh_f2_make(agc.mn0, agc.mn1); mx = dh_f2_make(agc.mx0, agc.mx1); }
+            else { mn = dh_f2_make(S.mn[k], S.mn[k + 1u]); mx = dh_f2_make(S.mx[k], S.mx[k + 1u]); }
+#else
             const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[k + 1u]), mx = dh_f2_make(S.mx[k], S.mx[k + 1u]);
+#endif
             const dh_f2 sumq = dh_f2_make(S.sum[qq], S.sum[qq + 1u]);
             const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);                // (max + min) / 2.0f: the division by two is exact
             // (sps 20: the division by the window's six samples as reciprocal product + exact residual + correction, dh_div_const; tests/test_numerics.py)
