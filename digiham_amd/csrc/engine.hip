@@ -212,6 +212,28 @@ __global__ __launch_bounds__(DH_WAVE) void k_xcc_probe(uint32_t* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;       // HW_REG_XCC_ID
 }
 
+// what the window phases of the slicer rest on (dsp_core.hpp, P3): eight / sixteen bytes read from LDS at an address that is only four-byte
+// aligned come back whole (the queues run with the LDS alignment mode "unaligned"; a mode that rounds the address down would slice wrong
+// symbols after every timing step of one sample).  HipBackend::lds_unaligned_probe looks once per device and process.
+__global__ __launch_bounds__(DH_WAVE) void k_lds_unaligned_probe(uint32_t* out) {
+#if defined(__HIP_DEVICE_COMPILE__)         // (the LDS read helpers only exist in the device pass)
+    __shared__ float w[DH_WAVE + 8];
+    w[threadIdx.x] = (float) threadIdx.x;
+    if (threadIdx.x < 8) w[DH_WAVE + threadIdx.x] = (float) (DH_WAVE + threadIdx.x);
+    __syncthreads();
+    const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) (w + threadIdx.x);     // lane l: word l (odd lanes: not eight-byte aligned)
+    const dh_f2 p = dh_lds_read_b64<0>(a);
+    const dh_v4f q = dh_lds_read_b128<4>(a);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float l = (float) threadIdx.x;
+    const bool ok = p.x == l && p.y == l + 1.0f && q.x == l + 1.0f && q.y == l + 2.0f && q.z == l + 3.0f && q.w == l + 4.0f;
+    const uint64_t all = __builtin_amdgcn_ballot_w64(ok);
+    if (threadIdx.x == 0) out[0] = all == ~0ull ? 1u : 2u;
+#else
+    (void) out;
+#endif
+}
+
 __global__ void k_init_state(uint32_t* dsp_state, size_t state_words, uint32_t tail0, uint32_t* dec_state, uint32_t slot_filter, uint32_t B) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < B) dh_init_state_channel(dsp_state, state_words, tail0, dec_state, slot_filter, ch);
@@ -498,6 +520,7 @@ struct HipBackend {
         if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) return DH_ENODEV;
         if (dev < 0 || dev >= count) return DH_EINVAL;
         device = dev; stream = (hipStream_t) s;
+        if (!lds_unaligned_probe()) { g_last_error = "the device does not return unaligned 8 / 16-byte LDS reads whole (LDS alignment mode): the slicer kernels need it"; return DH_EDEVICE; }
         if (!tail_split_probe()) tail_split_pct = 0;              // workgroup i does not run on XCD i mod 8 here (another part, a partitioned one): one workgroup per channel
         if (const char* e = std::getenv("DH_TAIL_SPLIT_FORCE_FAIL")) tail_split_force_fail = (uint32_t) std::strtoul(e, nullptr, 10);     // tests: see DhDspParams
         if (const char* e = std::getenv("DH_TAIL_SPLIT")) {       // "80" or "75,93" (percent of a push where the second / third workgroup of a channel starts), "0" = off
@@ -566,6 +589,28 @@ struct HipBackend {
         for (uint32_t i = 0; i < 8 && ok; i++) for (uint32_t j = 0; j < i; j++) ok = ok && h[i] != h[j];      // eight XCDs, each index class its own
         verdict[device] = ok ? 1 : -1;
         return ok;
+    }
+    // see k_lds_unaligned_probe; a probe that could not run (allocation / launch failure) is an error of its own, reported by the caller's next HIP call
+    bool lds_unaligned_probe() {
+        static std::mutex m; static int verdict[64] = { 0 };         // 0 unknown, 1 holds, -1 does not
+        if (device < 0 || device >= 64) return false;
+        std::lock_guard<std::mutex> lock(m);
+        if (verdict[device]) return verdict[device] > 0;
+        Scope on_device(device);
+        uint32_t* d = nullptr; uint32_t h = 0;
+        hipStream_t probe = nullptr;
+        if (hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return false; }
+        if (hipMalloc((void**) &d, sizeof(uint32_t)) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamDestroy(probe); return false; }
+        bool ran = hipMemsetAsync(d, 0, sizeof(uint32_t), probe) == hipSuccess;
+        if (ran) {
+            hipLaunchKernelGGL(k_lds_unaligned_probe, dim3(1), dim3(DH_WAVE), 0, probe, d);
+            ran = hipGetLastError() == hipSuccess && hipStreamSynchronize(probe) == hipSuccess && hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        (void) hipFree(d);
+        (void) hipStreamDestroy(probe);
+        if (!ran || h == 0u) { (void) hipGetLastError(); return false; }
+        verdict[device] = h == 1u ? 1 : -1;
+        return h == 1u;
     }
     hipStream_t side = nullptr, side_lo = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_lo = nullptr;
