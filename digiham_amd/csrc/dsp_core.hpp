@@ -1368,7 +1368,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
     const uint32_t sps = SPS ? (uint32_t) SPS : P.sps;
-    const uint32_t ev_lo = SPS == 10 ? 3u : SPS == 20 ? 7u : P.lo, ev_hi = SPS == 10 ? 7u : SPS == 20 ? 13u : P.hi;        // (round(sps / 3), round(2 sps / 3): engine_impl.hpp)
+    const uint32_t ev_lo = SPS == 10 ? 3u : SPS == 20 ? 7u : SPS == 40 ? 13u : P.lo, ev_hi = SPS == 10 ? 7u : SPS == 20 ? 13u : SPS == 40 ? 27u : P.hi;        // (round(sps / 3), round(2 sps / 3): engine_impl.hpp)
     const float sps_rcp = 1.0f / (float) sps;           // correctly rounded (IEEE division, once per push)
     float* tail = st + DH_ST_VAR + DH_VARIANCE_SYMBOLS * sps;
     const float* in = P.in + (size_t) ch * P.in_stride + part_lo;
@@ -1989,7 +1989,44 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
             dh_lds_stores_done();
         }
-        if (SPS != 10 && SPS != 20 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        // sps 40 (a pass holds at most 25 symbols): the same with ten ds_read_b128 per symbol (a forty-word lane stride read one word at a
+        // time reaches four banks: eight-way conflicts in the general loop)
+        if (SPS == 40 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+            const uint32_t l = (uint32_t) lane;
+            const uint32_t q = l < 63u ? l + 1u : 0u;
+            const bool valid = q < m;
+            const float* src = valid && q > 0u ? fbuf + (int32_t) (q * 40u) + step_off : fbuf;       // (lanes beyond the run read symbol 0 and store nothing)
+            float v[40];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            {
+                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
+                dh_v4f x0 = dh_lds_read_b128<0>(a), x1 = dh_lds_read_b128<16>(a), x2 = dh_lds_read_b128<32>(a), x3 = dh_lds_read_b128<48>(a), x4 = dh_lds_read_b128<64>(a);
+                dh_v4f x5 = dh_lds_read_b128<80>(a), x6 = dh_lds_read_b128<96>(a), x7 = dh_lds_read_b128<112>(a), x8 = dh_lds_read_b128<128>(a), x9 = dh_lds_read_b128<144>(a);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9) :: "memory");
+                const dh_v4f x[10] = { x0, x1, x2, x3, x4, x5, x6, x7, x8, x9 };
+#pragma unroll
+                for (int i = 0; i < 10; i++) { v[4 * i] = x[i].x; v[4 * i + 1] = x[i].y; v[4 * i + 2] = x[i].z; v[4 * i + 3] = x[i].w; }
+            }
+#else
+            for (int i = 0; i < 40; i++) v[i] = src[i];
+#endif
+            float vol = v[0], mid = v[13];
+#pragma unroll
+            for (int i = 1; i < 40; i++) vol += v[i];
+#pragma unroll
+            for (int i = 14; i < 27; i++) mid += v[i];                                               // samples ev_lo .. ev_hi - 1 = 13 .. 26
+            const float volume = dh_div_const(vol, 40.0f, sps_rcp);
+            if (valid) {
+                const uint32_t k = k0 + q;
+                dh_lds_store_row10<0>(S.var_rb + k, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
+                dh_lds_store_row10<1000>(S.var_rb + k, v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
+                dh_lds_store_row10<2000>(S.var_rb + k, v[20], v[21], v[22], v[23], v[24], v[25], v[26], v[27], v[28], v[29]);
+                dh_lds_store_row10<3000>(S.var_rb + k, v[30], v[31], v[32], v[33], v[34], v[35], v[36], v[37], v[38], v[39]);
+                S.sum[q] = mid; S.vol_new[k] = volume;
+            }
+            dh_lds_stores_done();
+        }
+        if (SPS != 10 && SPS != 20 && SPS != 40 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
             for (uint32_t q = lane; q < m; q += DH_WAVE) {
                 const uint32_t k = k0 + q;
                 const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
