@@ -595,6 +595,7 @@ struct HipBackend {
         static std::mutex m; static int verdict[64] = { 0 };         // 0 unknown, 1 holds, -1 does not
         if (device < 0 || device >= 64) return false;
         std::lock_guard<std::mutex> lock(m);
+        if (std::getenv("DH_LDS_PROBE_FORCE_FAIL")) return false;     // tests: what an engine on a device without unaligned LDS reads is told
         if (verdict[device]) return verdict[device] > 0;
         Scope on_device(device);
         uint32_t* d = nullptr; uint32_t h = 0;

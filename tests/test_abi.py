@@ -67,3 +67,16 @@ def test_engine_config_validation_in_emulation(emu_ctx):
     import numpy as np
     with pytest.raises(DhError):
         eng.push(np.zeros((2, 101), np.float32))          # n > max_samples
+
+
+@pytest.mark.gpu
+def test_engine_refuses_a_device_without_unaligned_lds_reads(gpu_ctx, monkeypatch):
+    """The slicer's window phases read 8 / 16 bytes from four-byte aligned LDS addresses (dsp_core.hpp, P3); the backend probes once
+    per device that such reads come back whole (engine.hip: k_lds_unaligned_probe).  A failed probe -- forced here -- must refuse the
+    engine with an error that says why, not run kernels that would slice wrong symbols after every timing step."""
+    from digiham_amd import api
+    api.Engine(2, 4096, proto="dmr", ctx=gpu_ctx).close()              # the real probe passes on an MI355X
+    monkeypatch.setenv("DH_LDS_PROBE_FORCE_FAIL", "1")
+    with pytest.raises(Exception) as e:
+        api.Engine(2, 4096, proto="dmr", ctx=gpu_ctx)
+    assert "LDS" in str(e.value)
