@@ -1266,8 +1266,8 @@ DH_HD bool dh_ysf_is_sync(const DhPlanes& p, int start) {         // ysf_phase.c
 // the codewords arrive without a single wrong dibit (the clean-codeword argument above: zero syndrome <=> exactly one path of
 // metric 0, whose message falls out of the dibits), but a pass holds four codewords, of two frames, and is only saved when all
 // four are clean.  So while the frame grid holds (sync kept: pos + 480 k) the codewords of up to DH_YSF_CHUNK frames are taken
-// together: bit planes of the chunk in LDS (16 dibits per lane and load, as in the DMR decoder), then one FRAME per lane -- its two
-// codewords out of the planes (the 20 x 5 de-interleave as five nibble spreads per row), syndrome and message with 128-bit shifts,
+// together: bit planes of the chunk in LDS (16 dibits per lane and load, as in the DMR decoder), then one CODEWORD per lane (a frame's
+// FICH and DCH in lanes f and 16 + f) -- out of the planes (the 20 x 5 de-interleave as five nibble spreads per row), syndrome and message with 128-bit shifts,
 // lane-locally -- and only the codewords with a non-zero syndrome go through the Viterbi decoder, packed four to a pass whatever
 // frames they belong to.  The frame loop finds the decoded bytes in S.ysf.res.
 struct DhU128 { uint64_t lo, hi; };
