@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from digiham_amd import api, synth_torch, _capi
 proto = sys.argv[1]
-B = 16384
+B = int(os.environ.get("DH_AB_CHANNELS", "16384"))
 units = {"dmr": 132, "ysf": 40, "nxdn": 50, "dstar": 198, "pocsag": 148}[proto]
 ekw = {"nxdn": dict(rrc="narrow", sps=20), "dstar": dict(rrc="none", demod="fsk", sps=10),
        "pocsag": dict(rrc="none", demod="fsk", sps=40, invert=True)}.get(proto, {})
