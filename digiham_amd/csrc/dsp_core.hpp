@@ -1419,7 +1419,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // raw samples behind every entry of the 100-symbol rings are still at hand when a comparison has to be settled exactly
     uint32_t p = BOUNDED ? sth[DH_ST_P0] : 0u;          // read position in the filtered stream
     bool staged = false; uint32_t staged_p = 0;         // the LDS window already holds V[staged_p ...) (prefetch)
-    constexpr bool PF_REG = MF16 && DH_PF_REG;          // ... as two arrays of halves, with these constants of its run:
+    // the next window fetched into registers behind P3 and put into the window block in P7: the split-f16 kernels (as two arrays of
+    // halves, with the constants of its run below) and the kernels without an RRC stage (as it is: they have the registers, and staged
+    // from L2 at the start of the next run every run waited out an L2 round trip: POCSAG slicer 4.86 -> 4.34 ms, D-Star chain 3.94 -> 3.65,
+    // r05_a_ab_logs.txt pf1)
+    constexpr bool PF_PLAIN = DH_PF_REG && NZ == 0 && !BOUNDED && !KEEPF;
+    constexpr bool PF_REG = (MF16 && DH_PF_REG) || PF_PLAIN;
     float st_e_run = 0.0f, st_k1 = 0.0f, st_k2 = 0.0f;
     // split-f16 FIR: the window held in `varr` (five 16-byte groups per lane, as loaded) -> zeros beyond `have`, max |x| of the
     // wavefront, the power-of-two scale that puts it into [0.5, 1), the two arrays of halves in the window block.  Returns
@@ -1577,9 +1582,10 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // ---- P1: stage raw samples V[p .. p+need+NZ) into the padded LDS window (zeros beyond)
         // After the first run of a push the whole window comes straight from `in`: 16 B per lane per load,
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
-        // From the second run on, the window was already put there by the previous iteration's prefetch.
+        // From the second run on, the window was already put there by the previous iteration's prefetch (the kernels that fetch it into
+        // registers: PF_REG; the others have had it pulled into L2).
         if (DH_LIKELY(staged && staged_p == p)) {
-            if (PF_REG) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; }      // (put there by P7 of the previous run)
+            if (PF_REG && MF16) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; }      // (put there by P7 of the previous run)
         } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
             // whole window inside the input buffer: unconditional loads (all in flight together, see the prefetch
             // below for why that matters), samples past the end of the stream zeroed afterwards
@@ -1867,7 +1873,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 const bool in_last = (uint32_t) lane < LAST_LANES;
 #pragma unroll
                 for (int r = 0; r < DH_PF_N - 1; r++) DH_LA(pfr, lane)[PF_REG ? r : 0] = dh_load4_stream(lsrc + 4 * DH_WAVE * r);
-                DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_stream(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+                if constexpr (LAST_LANES > 0) DH_LA(pfr, lane)[PF_REG ? DH_PF_N - 1 : 0] = dh_load4_stream(lsrc + (in_last ? 4 * DH_WAVE * (DH_PF_N - 1) : 0));
+                else (void) in_last;
             }
         } else {
         // Register-free variant: one dword per 128-byte line of the next window is requested now, which pulls the
@@ -2572,7 +2579,26 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
         staged = false;
         if (DH_LIKELY(pf_reg)) {
-            if constexpr (PF_REG) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = p_next; }
+            if constexpr (PF_REG && MF16) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = p_next; }
+            else if constexpr (PF_PLAIN) {
+                // no RRC stage: the window is the 1 024 samples themselves (four groups of four per lane, unpadded), zeros beyond the stream's end
+                static_assert(!PF_PLAIN || (DH_FTILE == 4u * DH_WAVE * (DH_PF_N - 1)), "four full groups cover the window");
+                DH_FOR_LANES_FRESH(lane) {
+                    const uint32_t l4 = 4u * (uint32_t) lane;
+                    float* ldst = &S.xf[l4];
+#pragma unroll
+                    for (int r = 0; r < DH_PF_N - 1; r++) {
+                        dh_f4 w = DH_LA(pfr, lane)[PF_REG ? r : 0];
+                        if (DH_UNLIKELY(pf_have < DH_FTILE)) {
+                            const uint32_t e = l4 + 4u * DH_WAVE * (uint32_t) r;
+                            w.x = e + 0u < pf_have ? w.x : 0.0f; w.y = e + 1u < pf_have ? w.y : 0.0f;
+                            w.z = e + 2u < pf_have ? w.z : 0.0f; w.w = e + 3u < pf_have ? w.w : 0.0f;
+                        }
+                        dh_store4(ldst + 4 * DH_WAVE * r, w);
+                    }
+                }
+                staged = true; staged_p = p_next;
+            }
         }
         DH_BARRIER();
         p = p_next;
