@@ -105,8 +105,17 @@ def profiled_counters(workload, channels, T, part0=False):
             continue
         scale = (channels * float(T)) / (ran[0] * float(ran[1]))
         c = {}
+        pass_ms = None                           # avg_launch_ms the pass's own bench line reported (tools/profile_gpu.sh, round 6 on)
         for line in open(os.path.join(pdir, name)):
+            if line.startswith("## config:"):
+                kv = dict(t.split("=", 1) for t in line.split()[2:] if "=" in t)
+                try:
+                    pass_ms = float(kv["avg_launch_ms"])
+                except (KeyError, ValueError):
+                    pass_ms = None
             if want(line) and "avg=" in line:
+                if " GRBM_GUI_ACTIVE " in line and "GRBM_GUI_ACTIVE" not in c and pass_ms:
+                    c["_grbm_pass_ms"] = pass_ms
                 for key in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE",
                             "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                     if " %s " % key in line and key not in c:
@@ -126,6 +135,9 @@ def profiled_counters(workload, channels, T, part0=False):
                     out[k.lower() + "_per_launch"] = c[k] * scale
             if "GRBM_GUI_ACTIVE" in c:
                 out["gpu_cycles_per_launch_profiled"] = c["GRBM_GUI_ACTIVE"] / 8.0 * scale      # (summed over the 8 XCDs)
+                out["profile_scale"] = scale
+                if "_grbm_pass_ms" in c:
+                    out["profiled_avg_launch_ms"] = c["_grbm_pass_ms"]
             out["pmc_source"] = "profiles/" + name
             return out
     return {}
@@ -415,6 +427,17 @@ class Job:
         self.sync()
         return dt
 
+    def step_algorithmic_bytes(self):
+        """SURVEY.md section 8(d) for the WHOLE step, every engine of it: 4 B in per sample (f32 audio, or an int16 I/Q pair) +
+        1 B per symbol + the decoders' output of the last step (+ 4 B per sample where the filtered signal is materialised)."""
+        total = 0.0
+        for p in self.parts:
+            kw = p["kw"]
+            total += p["B"] * p["T"] * (4.0 + (4.0 if kw.get("keep_filtered") else 0.0) + 1.0 / kw["sps"])
+            if kw["proto"] != "none":
+                total += int(p["eng"].frames()[1].sum())
+        return total
+
     def roofline(self, split_stages=False, step_ms=None):
         """Dominant kernel of the first part: its algorithmic bytes per launch over its average
         launch duration, from the HIP events the engine records on its own stream around every launch."""
@@ -475,7 +498,7 @@ class Job:
             pc["traffic"] *= share
             pc["traffic_source"] += "; x%.3f: the first launch's share of the channels" % share
             for k in list(pc):
-                if k.endswith("_per_launch") or k == "gpu_cycles_per_launch_profiled":
+                if k.endswith("_per_launch") or k in ("gpu_cycles_per_launch_profiled", "profile_scale"):
                     pc[k] *= share
         mean = lambda a: float(np.mean(a)) if len(a) else None
         f16 = (dom_name == "k_chain" or kw.get("one_launch")) and not kw.get("fast_fir") and kw["rrc"] == "wide" and kw["sps"] == 10
@@ -505,11 +528,20 @@ class Job:
                                ("lds_bank_conflict_cycles", "sq_lds_bank_conflict_per_launch"), ("lds_active_cycles", "sq_lds_idx_active_per_launch")):
                 if key in pc:
                     issue[name_] = pc[key] / runs
-            # 1 024 SIMDs share the launch: SIMD-cycles per run = launch duration x shader clock x 1 024 / runs
-            clock_ghz = 2.05                                                          # GRBM_GUI_ACTIVE over the launch, chain kernels
-            issue["simd_cycles_per_run"] = dom_ms * 1e-3 * clock_ghz * 1e9 * 1024.0 / runs
-            issue["shader_clock_ghz_assumed"] = clock_ghz
-            if "vector" in issue:
+            # 1 024 SIMDs share the launch: SIMD-cycles per run = launch duration x shader clock x 1 024 / runs.  The clock is the
+            # counter pass's own: GRBM_GUI_ACTIVE cycles of the launch (summed over the 8 XCDs) over the duration that pass's bench
+            # line reported for it (tools/profile_gpu.sh writes it into the `## config:` line); passes older than that give cycles
+            # only, and the clock is then those cycles over THIS run's duration (same kernel, another lease: marked as such).
+            if "gpu_cycles_per_launch_profiled" in pc:
+                prof_ms = pc.get("profiled_avg_launch_ms")
+                clock_ghz = pc["gpu_cycles_per_launch_profiled"] / ((prof_ms * pc.get("profile_scale", 1.0) if prof_ms else dom_ms) * 1e6)
+                issue["shader_clock_source"] = "GRBM_GUI_ACTIVE / 8 over " + ("the counter pass's own launch duration" if prof_ms else "this run's launch duration")
+            else:
+                clock_ghz = None
+            issue["shader_clock_ghz"] = clock_ghz
+            if clock_ghz:
+                issue["simd_cycles_per_run"] = dom_ms * 1e-3 * clock_ghz * 1e9 * 1024.0 / runs
+            if "vector" in issue and "simd_cycles_per_run" in issue:
                 issue["simd_cycles_per_vector_instruction"] = issue["simd_cycles_per_run"] / issue["vector"]
             issue["microbench_floor"] = {"source": "tools/microbench/clock_probe.hip, valu_rate.hip (MI355X, four wavefronts per SIMD)",
                                          "cycles_per_plain_f32_or_int_vector_instruction": 2.4, "cycles_per_packed_conversion_minmax_dpp_instruction": 4.2,
@@ -667,7 +699,11 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
         job = Job(torch, ctx, device, workload, channels, rank=0, overlap=overlap, streams=streams)
         dt = job.timed(steps, warmup)
         roof, stage = job.roofline(step_ms=dt / steps * 1e3)
+        step_alg = job.step_algorithmic_bytes()
         entry = {"workload": workload + (" --overlap" if overlap else "") + (" --streams 2" if streams == 2 else ""),
+                 "channels": channels if isinstance(channels, int) else list(channels),
+                 # the whole step's algorithmic bytes over the step period where the step is more than the dominant launch
+                 "algorithmic_bytes_per_whole_step": step_alg, "frac_step": step_alg / (dt / steps) / 1e9 / HBM_PEAK_GBS,
                  "config": "%s channels x %d samples: %s%s" % (channels, job.parts[0]["T"], job.desc,
                                                               "; pushes overlapped on the engine's own streams (DH_FLAG_OVERLAP_PUSHES)" if overlap else ""),
                  "launch_group": roof.get("launch_group"),
@@ -687,6 +723,98 @@ def other_configs(torch, ctx, device, steps, warmup, verify):
         entry["wall_s"] = time.perf_counter() - t_start
         out.append(entry)
     return out
+
+
+MAX_LINE_BYTES = 4096          # the driver keeps an 8 KB tail of stdout and parses its last line: round 5's 20.7 KB line was lost
+
+
+def _sig(v, digits=6):
+    """Numbers of the final line at `digits` significant digits (floats that are whole numbers stay ints)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (str, int)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        if v == int(v) and abs(v) < 1e15:
+            return int(v)
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return v
+
+
+def compact_line(line, detail_path=None):
+    """The LAST stdout line: the contract's keys, `roofline`, `cpu_baseline`, `verified` and one short record per other
+    workload -- numbers only, no prose.  Everything else (sources, notes, reference_fec, rates, the micro-benchmark floor)
+    stays in the full record: bench_detail.json beside bench.py and the `BENCH_DETAIL ` stdout line printed before this one."""
+    pick = lambda d, keys: {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    out = pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = line.get("config", {})
+    out["config"] = pick(cfg, ("channels_per_gpu", "samples_per_channel_per_step", "total_channels", "sharding"))
+    out["config"]["workload"] = str(cfg.get("workload", ""))[:160]
+    out["msamples_per_s"] = line.get("msamples_per_s")
+    if line.get("frac_step") is not None:
+        out["frac_step"] = line["frac_step"]
+    roof = line.get("roofline") or {}
+    r = pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "peak_achievable", "frac_of_achievable", "traffic",
+                    "algorithmic_bytes_per_launch", "avg_launch_ms"))
+    co = roof.get("co_limit") or {}
+    issue = co.get("issue") or {}
+    if issue:
+        # `bound` stays "hbm" (the roofline the metric is quoted against); what binds is said here
+        r["co_limit"] = {"binds": "instruction issue", "valu_issue_frac": co.get("valu_issue_frac"), "mfma_busy_frac": co.get("mfma_busy_frac"),
+                         "issue": pick(issue, ("vector", "scalar", "lds", "mfma", "branch", "vmem_read", "vmem_write", "lds_bank_conflict_cycles",
+                                               "lds_active_cycles", "simd_cycles_per_run", "shader_clock_ghz"))}
+    out["roofline"] = r
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = pick(cb, ("value", "unit", "msamples_per_s", "cores", "kind", "gpu_matches_baseline_outputs", "error"))
+        if "sample" in cb:
+            out["cpu_baseline"]["sample"] = "%s channels x %s samples, oracle/ port" % (cb.get("channels_hashed"), cfg.get("samples_per_channel_per_step"))
+        rf = cb.get("reference_fec")
+        if isinstance(rf, dict) and "bptc_196_96" in rf:
+            out["cpu_baseline"]["reference_fec"] = {k: {"ref_per_s": rf[k]["reference_blocks_per_s"], "gpu_per_s": rf[k]["gpu_blocks_per_s"], "identical": rf[k]["identical"]}
+                                                    for k in ("bptc_196_96", "trellis_180") if k in rf}
+    v = line.get("verified")
+    if isinstance(v, dict):
+        out["verified"] = pick(v, ("bit_exact_vs_oracle", "channels", "pushes"))
+    oc = line.get("other_configs")
+    if isinstance(oc, list):
+        rows = []
+        for e in oc:
+            ver = e.get("verified") or {}
+            ok = ver.get("bit_exact_vs_oracle")
+            if not ok and ("within_1e-6_vs_oracle" in ver or "floats_within_2.5e-6_vs_oracle" in ver):
+                ok = bool(ver.get("floats_within_2.5e-6_vs_oracle", ver.get("within_1e-6_vs_oracle")))
+            row = {"workload": e.get("workload"), "channels": e.get("channels"), "ms_per_step": e.get("ms_per_step"), "frac": e.get("frac"),
+                   "frac_step": e.get("frac_step"), "ok": ok}
+            alg = e.get("algorithmic_bytes_per_step") or e.get("algorithmic_bytes_per_launch")
+            if e.get("traffic") and alg:
+                row["traffic_ratio"] = e["traffic"] / alg
+            if "max_rel_err" in ver:
+                row["max_rel_err"] = ver["max_rel_err"]
+            rows.append({k: v for k, v in row.items() if v is not None})
+        out["other_configs"] = rows
+    elif oc is not None:
+        out["other_configs"] = oc
+    if detail_path:
+        out["detail"] = detail_path
+    out = _sig(out)
+    text = json.dumps(out, separators=(",", ":"))
+    # belt and braces: a line over the bound loses the least important parts first, never the headline
+    for drop in (("other_configs",), ("roofline", "co_limit"), ("cpu_baseline", "reference_fec"), ("config", "workload")):
+        if len(text) <= MAX_LINE_BYTES:
+            break
+        d = out
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        if drop[-1] in d:
+            d[drop[-1]] = "see " + (detail_path or "the BENCH_DETAIL line")
+        text = json.dumps(out, separators=(",", ":"))
+    assert len(text) <= MAX_LINE_BYTES, "bench.py: final line %d bytes" % len(text)
+    return text
 
 
 def main():
@@ -772,6 +900,7 @@ def main():
                        # the rows from this percentage on (engine.hip: go_chain / k_chain); "0" = one workgroup per channel
                        "tail_split_pct": os.environ.get("DH_TAIL_SPLIT", "80")},
             "msamples_per_s": rate / 1e6,
+            "frac_step": job.step_algorithmic_bytes() * args.steps / dt / 1e9 / HBM_PEAK_GBS,      # this rank's whole step over its own period
             "roofline": roof, "stage_ms": stage, "verified": verified,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -815,7 +944,19 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)         # the last line of stdout, after RCCL's own chatter
+        detail = None
+        for cand in (os.environ.get("DH_BENCH_DETAIL"), os.path.join(ROOT, "bench_detail.json")):
+            if not cand:
+                continue
+            try:
+                with open(cand, "w") as f:
+                    json.dump(line, f, indent=1)
+                detail = os.path.relpath(cand, ROOT) if cand.startswith(ROOT) else cand
+                break
+            except OSError:
+                continue
+        print("BENCH_DETAIL " + json.dumps(line), flush=True)          # the full record (sources, notes, per-workload detail): NOT the line the driver parses
+        print(compact_line(line, detail), flush=True)                  # the last line of stdout, after RCCL's own chatter: <= 4 KB
 
 
 if __name__ == "__main__":

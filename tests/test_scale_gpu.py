@@ -269,6 +269,11 @@ def test_bench_runs_its_distributed_path_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["verified"]["bit_exact_vs_oracle"]
+    # the line the driver parses is the LAST one of stdout, at most 4 KB, with the roofline in it; the full record comes before it
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last == lines[0] and len(last) <= 4096 and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["avg_launch_ms"] > 0
+    detail = [l for l in r.stdout.splitlines() if l.startswith("BENCH_DETAIL ")]
+    assert len(detail) == 1 and json.loads(detail[0][len("BENCH_DETAIL "):])["roofline"]["peak_achievable_rates"]
 
 
 @pytest.mark.gpu

@@ -2,6 +2,7 @@
 # tools/collect_prof.sh <tag>: copy what tools/run_prof.sh <tag> left under gpurun_out/ into profiles/ (here, after the gpurun call)
 TAG=${1:?tag}
 [ -s gpurun_out/${TAG}_bench_default.json ] && cp gpurun_out/${TAG}_bench_default.json profiles/
+[ -s gpurun_out/${TAG}_bench_default_detail.json ] && cp gpurun_out/${TAG}_bench_default_detail.json profiles/
 for d in gpurun_out/prof_${TAG}_*; do
   [ -d "$d" ] || continue
   w=${d#gpurun_out/prof_${TAG}_}

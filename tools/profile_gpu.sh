@@ -20,6 +20,8 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   timeout 600 rocprofv3 --kernel-include-regex "k_chain|k_rrc_demod|k_dmr|k_ysf|k_rrc_tile|k_nxdn" --pmc $set -d $OUT -o pmc$i -- python bench.py $ARGS > $OUT/pmc$i.log 2>&1
   # what the pass ran on, from its own bench line: bench.py scales the counters by it (profiled_counters)
   CFG=$(grep '^{' $OUT/pmc$i.log | tail -1 | python -c 'import json,sys; c=json.loads(sys.stdin.read())["config"]; print("channels_per_gpu=%d samples_per_channel=%d" % (c["channels_per_gpu"], c["samples_per_channel_per_step"]))' 2>/dev/null)
+  MS=$(grep '^BENCH_DETAIL ' $OUT/pmc$i.log | tail -1 | cut -d' ' -f2- | python -c 'import json,sys; print("avg_launch_ms=%.6f" % json.loads(sys.stdin.read())["roofline"]["avg_launch_ms"])' 2>/dev/null)
+  CFG="$CFG $MS"
   { echo "## config: $CFG args=\"$ARGS\""; python tools/rocpd_summary.py $OUT/pmc${i}_results.db 2>&1 | grep -A200 "PMC counters" | grep -E "k_chain|k_rrc_demod|k_dmr|k_ysf|k_rrc_tile|PMC"; } > $OUT/pmc${i}_summary.txt
 done
 rm -f $OUT/*.db

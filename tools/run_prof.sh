@@ -9,6 +9,8 @@ set -x
 mkdir -p gpurun_out
 if [ -z "${SKIP_BENCH:-}" ]; then
   python bench.py > gpurun_out/${TAG}_bench_default.log 2>&1; tail -1 gpurun_out/${TAG}_bench_default.log > gpurun_out/${TAG}_bench_default.json
+  grep '^BENCH_DETAIL ' gpurun_out/${TAG}_bench_default.log | tail -1 | cut -d' ' -f2- > gpurun_out/${TAG}_bench_default_detail.json
+  wc -c gpurun_out/${TAG}_bench_default.json
   head -c 2500 gpurun_out/${TAG}_bench_default.json; echo
 fi
 for w in $WL; do

@@ -3,7 +3,10 @@
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+# the full record: bench_detail.json, or the `BENCH_DETAIL ` line of a bench log (the last stdout line is the compact one)
+text = open(sys.argv[1]).read().strip()
+det = [l for l in text.splitlines() if l.startswith("BENCH_DETAIL ")]
+d = json.loads(det[-1][len("BENCH_DETAIL "):]) if det else json.loads(text) if text.startswith("{\n") else json.loads(text.splitlines()[-1])
 r = d["roofline"]
 print("%s: %.3f ms/step, %.2f M channels, kernel %.3f ms, frac %.3f (of achievable %.3f, ceiling %.0f GB/s %s), traffic/alg %s"
       % (d["config"]["workload"][:40], d["ms_per_step"], d["value"] / 1e6, r["avg_launch_ms"], r["frac"], r["frac_of_achievable"], r["peak_achievable"],
