@@ -6,29 +6,25 @@
 // parser on the GPU emits in the reference's call order.  PARITY UNPINNED (see meta.hpp).
 #pragma once
 
+#include <cerrno>
 #include <cstdlib>
 #include <cstring>
-#include <sstream>
 #include <string>
-#include <vector>
 
 #include "meta.hpp"
 
 namespace Digiham {
     namespace DStar {
 
-        // Crc::isCrcValid (src/dstar_decoder/crc.cpp:6-23)
-        inline bool isCrcValid(const unsigned char* data, size_t len, uint16_t to_check) {
-            uint16_t checksum = 0xFFFF;
-            for (size_t k = 0; k < len; k++) {
-                for (int i = 0; i < 8; i++) {
-                    checksum ^= (data[k] >> i) & 1;
-                    if (checksum & 1) checksum = (uint16_t) ((checksum >> 1) ^ 0x8408);
-                    else checksum >>= 1;
-                }
+        // The D-Star checksum (reflected CRC-CCITT, polynomial 0x8408, preset and final inversion 0xFFFF) of `len` bytes against
+        // `expected`; same value as Crc::isCrcValid (src/dstar_decoder/crc.cpp:6-23), which feeds the register bit by bit.
+        inline bool isCrcValid(const unsigned char* data, size_t len, uint16_t expected) {
+            unsigned reg = 0xFFFF;
+            while (len--) {
+                reg ^= *data++;
+                for (int bit = 0; bit < 8; bit++) reg = (reg >> 1) ^ (0x8408u & (0u - (reg & 1u)));
             }
-            checksum ^= 0xFFFF;
-            return checksum == to_check;
+            return (uint16_t) ~reg == expected;
         }
 
         class MetaCollector: public Digiham::MetaCollector {
@@ -69,24 +65,24 @@ namespace Digiham {
             protected:
                 std::string getProtocol() override { return "DSTAR"; }
                 std::map<std::string, std::string> collect() override {     // dstar_meta.cpp:100-135
-                    auto metadata = Digiham::MetaCollector::collect();
-                    if (!sync.empty()) metadata["sync"] = sync;
-                    if (!departure.empty()) metadata["departure"] = departure;
-                    if (!destination.empty()) metadata["destination"] = destination;
-                    if (!ourCall.empty()) metadata["ourcall"] = ourCall;
-                    if (!yourCall.empty()) metadata["yourcall"] = yourCall;
-                    if (!message.empty()) metadata["message"] = message;
-                    if (!dprs.empty()) metadata["dprs"] = dprs;
-                    if (coord != nullptr) {
-                        metadata["lat"] = std::to_string(coord->lat);
-                        metadata["lon"] = std::to_string(coord->lon);
+                    std::map<std::string, std::string> line = Digiham::MetaCollector::collect();
+                    const std::pair<const char*, const std::string*> texts[] = {
+                        {"sync", &sync}, {"departure", &departure}, {"destination", &destination}, {"ourcall", &ourCall},
+                        {"yourcall", &yourCall}, {"message", &message}, {"dprs", &dprs}};
+                    for (const auto& t: texts)
+                        if (!t.second->empty()) line[t.first] = *t.second;
+                    if (coord) {
+                        line["lat"] = std::to_string(coord->lat);
+                        line["lon"] = std::to_string(coord->lon);
                     }
-                    return metadata;
+                    return line;
                 }
             private:
-                static std::string rtrim(std::string input) {               // header.cpp:154-157
-                    input.erase(input.find_last_not_of(' ') + 1);
-                    return input;
+                static std::string rtrim(std::string text) {                // header.cpp:154-157: trailing blanks off
+                    size_t keep = text.size();
+                    while (keep > 0 && text[keep - 1] == ' ') keep--;
+                    text.resize(keep);
+                    return text;
                 }
                 std::string field(int at, int len) const { return rtrim(Converter::convertToUtf8((const char*) header + at, (size_t) len)); }
                 void setFromHeader() {                                      // dstar_meta.cpp:15-27, header.cpp:150-181
@@ -101,60 +97,107 @@ namespace Digiham {
                     setYourCall(field(19, 8));
                     release();
                 }
-                // `ss << std::hex << text; ss >> value` (dstar_phase.cpp:222-225, :262-265): leading hex digits, 0 when none
-                static uint16_t hexValue(const std::string& text) {
-                    std::stringstream ss;
-                    uint16_t v = 0;
-                    ss << std::hex << text;
-                    ss >> v;
-                    return ss.fail() ? (uint16_t) 0 : v;
+                // ---- slow-data text (what the reference's VoicePhase does with strings and streams, dstar_phase.cpp:211-290) ----
+                // Here: one pass over the received bytes with a read-only window; no streams, nothing thrown.
+
+                // A window on received text.
+                struct Text {
+                    const char* p; size_t n;
+                    char operator[](size_t i) const { return p[i]; }
+                    Text from(size_t at) const { return at >= n ? Text{p + n, 0} : Text{p + at, n - at}; }
+                    Text first(size_t len) const { return Text{p, len < n ? len : n}; }
+                    bool is(const char* lit) const { return std::strlen(lit) == n && std::memcmp(p, lit, n) == 0; }
+                    std::string str() const { return std::string(p, n); }
+                };
+                // What formatted extraction of a uint16_t in base 16 leaves in the variable (the reference reads both of its
+                // checksums that way, :222-225 and :262-265): blanks skipped, a sign, zeros with at most one x among them, then
+                // hex digits; nothing usable gives 0, too much gives 0xFFFF, a minus sign negates modulo 2^16.
+                static uint16_t hex16(Text t) {
+                    size_t i = 0;
+                    while (i < t.n && std::strchr(" \t\n\v\f\r", t[i]) != nullptr && t[i] != 0) i++;
+                    bool minus = false;
+                    if (i < t.n && (t[i] == '+' || t[i] == '-')) minus = t[i++] == '-';
+                    bool zero = false, x = false;
+                    unsigned digits = 0;
+                    for (; i < t.n; i++) {
+                        if (t[i] == '0' && !zero) { zero = true; digits++; }
+                        else if (zero && (t[i] == 'x' || t[i] == 'X') && !x) { zero = false; digits = 0; x = true; }
+                        else break;
+                    }
+                    unsigned long v = 0;
+                    for (; i < t.n; i++, digits++) {
+                        const char c = t[i];
+                        const int d = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+                        if (d < 0) break;
+                        if (v <= 0xFFFFFF) v = v * 16 + (unsigned) d;
+                    }
+                    if (digits == 0 && !zero) return 0;
+                    if (v > 0xFFFF) return 0xFFFF;
+                    return (uint16_t) (minus ? 0u - v : v);
                 }
+                // ddmm.mmmm -> degrees in the reference's float steps (:281-282, :285-286; the lines must agree to the last bit)
+                static float degrees(float ddmm) {
+                    float whole = (int) ddmm / 100;
+                    whole += (ddmm - whole * 100) / 60;
+                    return whole;
+                }
+                // A field as std::stof reads it (strtof's longest prefix); false where stof would have thrown, or where the
+                // (int) of the value is not defined.
+                static bool number(Text t, float& out) {
+                    const std::string z = t.str();                                      // (strtof wants a terminator)
+                    char* end = nullptr;
+                    errno = 0;
+                    out = std::strtof(z.c_str(), &end);
+                    if (end == z.c_str() || errno == ERANGE) return false;
+                    return out > -2147483648.0f && out < 2147483648.0f;                 // also refuses NaN
+                }
+                // Every complete sentence of the collected simple data (terminated by \r or \r\n), oldest first.
                 void parseSimpleData() {
-                    size_t pos;
-                    while ((pos = simpleData.find('\r')) != std::string::npos) {
-                        const std::string something = simpleData.substr(0, pos + 1);
-                        if (something.length() >= 10 && something.substr(0, 5) == "$$CRC" && something.at(9) == ',') {
-                            const uint16_t checksum = hexValue(something.substr(5, 4));
-                            const std::string body = something.substr(10);
-                            if (isCrcValid((const unsigned char*) body.c_str(), something.length() - 10, checksum))
-                                setDPRS(something.substr(10, something.length() - 11));
-                        } else if (something.length() > 5 && something.at(0) == '$') {
-                            parseNMEAData(something);
+                    size_t done = 0;
+                    for (;;) {
+                        const void* cr = std::memchr(simpleData.data() + done, '\r', simpleData.size() - done);
+                        if (cr == nullptr) break;
+                        const size_t end = (size_t) ((const char*) cr - simpleData.data()) + 1;     // one past the \r
+                        const Text s{simpleData.data() + done, end - done};
+                        if (s.n >= 10 && s.first(5).is("$$CRC") && s[9] == ',') {
+                            const Text covered = s.from(10);                            // the CRC covers the \r, the field does not
+                            if (isCrcValid((const unsigned char*) covered.p, covered.n, hex16(s.from(5).first(4))))
+                                setDPRS(covered.first(covered.n - 1).str());
+                        } else if (s.n > 5 && s[0] == '$') {
+                            nmea(s);
                         }
-                        // termination may be \r or \r\n (:243-244)
-                        simpleData = simpleData.substr(pos + 1 + (simpleData.length() > pos + 1 && simpleData.at(pos + 1) == '\n'));
+                        done = end + (end < simpleData.size() && simpleData[end] == '\n');
                     }
+                    simpleData.erase(0, done);
                 }
-                // dstar_phase.cpp:248-290.  Where the reference would throw out of a malformed sentence (substr / stof on
-                // short or empty fields, :257, :281-286) and end the process, the sentence is dropped instead.
-                void parseNMEAData(const std::string& input) {
-                    const size_t checksum_pos = input.find_last_of("*");
-                    if (checksum_pos == std::string::npos) return;
-                    if (checksum_pos + 2 > input.length()) return;
-                    if (checksum_pos < 1) return;
-                    const std::string body = input.substr(1, checksum_pos - 1);
-                    if (body.length() < 2) return;
-                    const std::string sentence = body.substr(2, 3);
-                    uint8_t checksum = 0;
-                    for (size_t i = 0; i < body.length(); i++) checksum ^= (uint8_t) body.at(i);
-                    if (checksum != hexValue(input.substr(checksum_pos + 1, 2))) return;
-                    std::vector<std::string> fields;
-                    std::stringstream splitter(body);
-                    std::string item;
-                    while (getline(splitter, item, ',')) fields.push_back(item);
-                    if (sentence == "GGA") {
-                        if (fields.size() < 6) return;
-                        float lat_combined, lon_combined;
-                        try { lat_combined = std::stof(fields[2]); lon_combined = std::stof(fields[4]); }
-                        catch (const std::exception&) { return; }
-                        float lat = (int) lat_combined / 100;
-                        lat += (lat_combined - lat * 100) / 60;
-                        if (fields[3] == "S") lat *= -1;
-                        float lon = (int) lon_combined / 100;
-                        lon += (lon_combined - lon * 100) / 60;
-                        if (fields[5] == "W") lon *= -1;
-                        setGPS(new Coordinate(lat, lon));
+                // `$ttSSS,f1,f2,...*hh\r`: XOR of everything between $ and the LAST `*` against the two characters behind it; of all
+                // sentences only GGA is used (fields 2..5 = latitude, N/S, longitude, E/W).  A sentence the reference could not
+                // have survived (fields missing, no number where one belongs: an exception out of its process) is dropped.
+                void nmea(Text s) {
+                    size_t star = s.n;
+                    while (star > 0 && s[star - 1] != '*') star--;
+                    if (star == 0 || star + 1 > s.n) return;                            // no `*`, or nothing behind it
+                    star--;
+                    const Text body = s.from(1).first(star - 1);
+                    if (body.n < 2) return;
+                    uint8_t x = 0;
+                    for (size_t i = 0; i < body.n; i++) x ^= (uint8_t) body[i];
+                    if (x != hex16(s.from(star + 1).first(2))) return;
+                    if (!body.from(2).first(3).is("GGA")) return;
+                    Text f[6];
+                    size_t count = 0, at = 0;
+                    while (at < body.n) {                                               // (an empty field behind a trailing comma does not count)
+                        size_t comma = at;
+                        while (comma < body.n && body[comma] != ',') comma++;
+                        if (count < 6) f[count] = body.from(at).first(comma - at);
+                        count++;
+                        at = comma + 1;
                     }
+                    if (count < 6) return;
+                    float la, lo;
+                    if (!number(f[2], la) || !number(f[4], lo)) return;
+                    const float lat = degrees(la), lon = degrees(lo);
+                    setGPS(new Coordinate(f[3].is("S") ? -lat : lat, f[5].is("W") ? -lon : lon));
                 }
                 void setSync(const std::string& v) { if (sync == v) return; sync = v; sendMetaData(); }
                 void setMessage(const std::string& v) { if (message == v) return; message = v; sendMetaData(); }
