@@ -40,7 +40,9 @@ int hip_fail(hipError_t e, const char* what) {
 #define DH_TAIL_SPLIT_PCT2 0       // a third workgroup per channel from this percentage on (0 = two parts)
 #define DH_TAIL_SPLIT_MIN_CHANNELS 8192     // the tail split of the chain kernels (HipBackend::go_chain) takes effect for launches at least this wide ...
 #define DH_TAIL_SPLIT_MIN_SAMPLES 65536     // ... and pushes at least this long
+#ifndef DH_LB
 #define DH_LB 4          // minimum waves per SIMD the wide-filter kernels are register-budgeted for (128 VGPRs)
+#endif
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
 // KEEPF: the launch also delivers the filtered samples (DhDspParams::filt_out; BASELINE configs[1] in one kernel)
