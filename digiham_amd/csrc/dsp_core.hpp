@@ -48,8 +48,7 @@ enum { DH_ST_K = 0, DH_ST_OFF = 1, DH_ST_TAIL = 2, DH_ST_NSYM = 3, DH_ST_ORDERED
        DH_ST_E_CUR = 12, DH_ST_E_PREV = 13, DH_ST_E_COUNT = 14, DH_ST_E_BLOCK = 15,          // error radii of the ring entries (floats), symbols in the current bucket
        DH_ST_UNCERTAIN = 16, DH_ST_EXACT_RUNS = 17, DH_ST_EXACT_BLOCKS = 18,                    // statistics: symbols / runs / timing blocks decided by exact arithmetic
        DH_ST_PART = 19,              // tail split (k_chain): epoch of the last split push (24 bits) | parts written back << 24 | a later part gave up << 26 | XCC id << 28
-       DH_ST_SYM_RUNS = 20,          // statistics: symbol-major runs (hundreds of symbols that went through dh_fir_f16_sym)
-       DH_ST_DIAG = 21 };            // 21..31: free (diagnostic builds)
+       DH_ST_DIAG = 20 };            // 20..31: diagnostic builds (phase clocks 20..27, wave timeline 28..31)
 #define DH_ST_VOL DH_STATE_HDR
 #define DH_ST_VAR (DH_STATE_HDR + DH_VOLUME_RB_SIZE)
 
@@ -73,7 +72,6 @@ struct DhDspParams {
     double gain, rgain; float inv_gain;                // rgain = 1/gain rounded to double
     float taps[DH_MAX_NZ / 2 + 1];                     // first half + centre of the symmetric response
     const uint32_t* tapfrag;                           // split-f16 FIR: the per-lane tap fragments (DhF16Taps::frag), or null
-    const uint32_t* tapfrag_sym;                       // its symbol-major form (DhF16SymTaps::frag: two parities x six fragments), or null: no symbol-major runs
     float err_coef_f16;                                // its error radius per unit of max |x| (dh_f16_error_coefficient)
     // tail split (engine.hip, HipBackend::go_chain): the launch has two or three workgroups per channel; workgroup
     // k * split_pad + channel takes the samples [0, split_n0), [split_n0, split_n1 or the end), [split_n1, end) of the
@@ -645,9 +643,6 @@ inline void dh_fir_mfma(const float* tapsf, const float* xs, int lane, float* ac
 //      dh_f16_tap_fragments), fetched with the samples
 //   D: lane (n, g), register r holds y[256 T + 16 b(4 g + r) + n] = y[DH_F16_OUT(T, r, g, n)]
 #define DH_FIR_F16 1
-#ifndef DH_SYM_RUNS
-#define DH_SYM_RUNS 1                        // symbol-major runs of the wide-filter sps-10 chain / slicer kernels (see DhF16SymTaps; 0: every run through the window phase)
-#endif
 #define DH_PLAN_FAST 1                       // sps-10 kernels: the run planning of a whole-block run in three compares
 #define DH_EXACT_BATCH 2                     // exact evaluations of the 81-tap kernels: this many products at a time, their LDS reads in flight together (the 161-tap ones: 8)
 #define DH_PF_REG 1                          // split-f16 kernels: the next window is fetched into registers behind P3 and split into halves in P7
@@ -738,78 +733,6 @@ inline float dh_f16_error_coefficient(const DhF16Taps& F, uint32_t nz, double ga
     return f;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Symbol-major split-f16 FIR (round 6; wide filter, sps 10).  Inside a variance block the symbol windows lie on a grid (V3:
-// start[k] = base + 10 k + off), so the matrix cores can deliver per SYMBOL what the window phase used to re-derive from the
-// filtered samples: its ten filtered samples (the variance ring's column), the mid-window sum (samples 3..6) and the volume
-// (sum of all ten / 10) -- twelve linear functionals of the symbol's 90 raw samples x[0..89]:
-//   T_i[k] = c[k - i]                  i = 0..9    (rrc_filter.cpp:22-34 for output i of the symbol)
-//   T_10[k] = sum_{a=3..6} c[k - a]                (gfsk_demodulator.cpp:31: `sum`)
-//   T_11[k] = sum_{a=0..9} c[k - a] / 10           (:32, :83: volume_sum / samplesPerSymbol)
-// A tile is 16 functionals (rows, A operand: the tap tables, per-lane fragments from the host; rows 12..15 are zeros) x 16
-// symbols (columns, B operand: lane (q, n) reads halves [10 j + 32 s + 8 q, + 8) of symbol j's window -- 20 bytes apart, a
-// ds_read_b128 at four-byte alignment) with K = 96: 9 MFMAs per 16 symbols, 63 per 100-symbol run instead of 36, and no write-back
-// of filtered samples, no window phase.  D: lane (g, n), register r = functional 4 g + r of symbol 16 T + n.
-// Windows start at EVEN half offsets only (four-byte alignment), so a run whose symbols sit at an odd offset inside the staged
-// window uses the second set of tables, shifted by one tap: T'_i[k] = T_i[k - 1].
-#define DH_SYM_FUNCS 12
-#define DH_SYM_TILES 7
-#define DH_SYM_K 96
-struct DhF16SymTaps {
-    uint32_t frag[2][6][DH_WAVE][4];                         // [parity][g1 slices 0..2, g2 slices 3..5][lane][four pairs of halves]
-    float coef;                                              // error radius per unit of max |x| (see dh_f16_sym_fragments)
-};
-// Error radius (what an average, a volume or a ring sample of the symbol-major product can be off the reference's by, per unit of
-// max |x|, in units of u / gain), per functional with table d = T_i and L1 norms of its f16 split:
-//   product:   41 KS L1(g1(d)) (1 + 2^-11) + 82 KS / 2048 (L1(g2(d)) + L1(g1(d)) / 2) + 2 (2^-23 L1(g2(d)) + sum |delta(d)| (1 + 2^-12) + u L1(d)) / u + 3.1 L1(d)
-//              (the terms of dh_f16_error_coefficient, with the table's own norms)
-//   reference: a sample: (taps + 1 + 0.01) L1 + 1.0001 L1 =: R1 (its chain and its division);
-//              the mid-window sum: 4 R1 + 9 L1 (three float additions of partial sums <= 2 Y, 3 Y, 4 Y), compared as sum / 4 (exact);
-//              the volume: (10 R1 + 54 L1) / 10 (nine additions, partial sums <= 2 Y .. 10 Y) + 1.0001 L1 (its division by ten)
-// The engine's coefficient is 1.44 x the largest of the three (the head room for the slicer's centre / threshold roundings as before).
-inline void dh_f16_sym_fragments(const float* taps_half, uint32_t nz, double gain, DhF16SymTaps& F) {
-    const double u = 5.9604644775390625e-08;
-    double c[DH_MAX_NZ + 1], l1 = 0.0;
-    for (uint32_t i = 0; i <= nz; i++) { c[i] = (double) taps_half[i <= nz / 2 ? i : nz - i]; l1 += c[i] < 0 ? -c[i] : c[i]; }
-    uint16_t g1[DH_SYM_FUNCS][DH_SYM_K], g2[DH_SYM_FUNCS][DH_SYM_K];
-    const double ks = 3.0, r1 = ((double) nz + 2.01) * l1 + 1.0001 * l1;
-    double worst = 0.0;
-    for (int i = 0; i < DH_SYM_FUNCS; i++) {
-        double dl1 = 0.0, dg1 = 0.0, dg2 = 0.0, dd = 0.0;
-        for (int k = 0; k < DH_SYM_K; k++) {
-            const int a_lo = i < 10 ? i : i == 10 ? 3 : 0, a_hi = i < 10 ? i : i == 10 ? 6 : 9;
-            double d = 0.0;
-            for (int a = a_lo; a <= a_hi; a++) if (k - a >= 0 && k - a <= (int) nz) d += c[k - a];
-            if (i == 11) d /= 10.0;
-            const double slop = (d < 0 ? -d : d) * 1.2e-15;                              // (the double sum / quotient above is not the real number)
-            g1[i][k] = dh_f16_bits((float) d);
-            const double r = d - (double) dh_f16_value(g1[i][k]);
-            g2[i][k] = dh_f16_bits((float) (r * 2048.0));
-            const double v2 = (double) dh_f16_value(g2[i][k]);
-            const double delta = r - v2 / 2048.0;
-            dl1 += d < 0 ? -d : d; dg1 += __builtin_fabs((double) dh_f16_value(g1[i][k])); dg2 += __builtin_fabs(v2);
-            dd += __builtin_fabs(delta) + slop;
-        }
-        const double prod = 41.0 * ks * dg1 * (1.0 + 1.0 / 2048.0) + 82.0 * ks / 2048.0 * (dg2 + 0.5 * dg1)
-                          + 2.0 * (0.5 * dg2 / 4194304.0 + dd * (1.0 + 1.0 / 4096.0) + u * dl1) / u + 3.1 * dl1;
-        const double radius = i < 10 ? r1 + prod : i == 10 ? (4.0 * r1 + 9.0 * l1 + prod) / 4.0 : (10.0 * r1 + 54.0 * l1) / 10.0 + 1.0001 * l1 + prod;
-        if (radius > worst) worst = radius;
-    }
-    const double coef = 1.44 * worst * u / (gain < 0 ? -gain : gain) * 1.0001;
-    F.coef = (float) coef;
-    if ((double) F.coef < coef) { union { float f; uint32_t u; } b; b.f = F.coef; b.u++; F.coef = b.f; }
-    for (int par = 0; par < 2; par++) for (int f = 0; f < 6; f++) for (int lane = 0; lane < DH_WAVE; lane++) for (int d = 0; d < 4; d++) {
-        const int i = lane & 15, q = lane >> 4, s = f % 3;
-        uint32_t w = 0;
-        for (int hh = 0; hh < 2; hh++) {
-            const int k = 32 * s + 8 * q + 2 * d + hh - par;
-            const uint16_t v = (i < DH_SYM_FUNCS && k >= 0 && k < DH_SYM_K) ? (f < 3 ? g1[i][k] : g2[i][k]) : 0;
-            w |= (uint32_t) v << (16 * hh);
-        }
-        F.frag[par][f][lane][d] = w;
-    }
-}
-
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 typedef _Float16 dh_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 dh_h4 __attribute__((ext_vector_type(4)));
@@ -876,133 +799,6 @@ __device__ __forceinline__ void dh_fir_f16(const float* hw, const dh_u4 (&G)[2 *
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * DH_F16_KSTEPS, 0);
     }
 }
-// ---- the symbol-major product of one run (see DhF16SymTaps): 100 symbols on the grid `wb` + 10 j halves of the staged window.
-// Run index j is ring slot j + 1; j = 99 is symbol 0 of the NEXT variance block ("z": its volume goes to slot 0 of vol_new, its ten
-// samples stay in registers -- `z` of the lanes that hold column 3 of the last tile -- until the block's timing decision has read
-// slot 0 of the ring).
-//   var_rb[(4 g + r) 100 + slot]   ring samples        vol_new[slot]   volumes        sum[j]   mid-window sums (stored last: `sum` lies
-//   inside the window block, which is being read until then)
-// Which symbol a column holds: tiles 2 c and 2 c + 1 share the 32 symbols 32 c .. 32 c + 31 -- column n of the even tile is symbol
-// 32 c + 8 (n >> 2) + {0, 2, 5, 7}[n & 3], of the odd tile + {1, 3, 4, 6}[n & 3]: symbols are five words apart, and with these two sets
-// the 32 lanes of a read pass (two K quarters, four words apart) touch 32 different banks; in natural order half of every pass ran
-// into a two-way conflict.  The last tile holds symbols 96..99 in columns 0..3 (columns 4..15 re-read them and store nothing).
-// A window fragment is sixteen bytes from a FOUR-byte aligned address.  The LDS takes a ds_read_b128 or a ds_read_b64 that is not
-// aligned to its own size apart (measured: the run three and six times as long, profiles/r06_c_ab_logs.txt); two ds_read2_b32 -- four
-// aligned words -- run at the full 128 bytes per cycle.  The fragments of tile t + 1 are requested before the MFMAs of tile t.
-// The stores of a tile go out under exec masks (lanes g = 3 hold the zero rows; g = 2 holds samples 8, 9, the sum and the volume).
-// `bad`: some volume is not finite (a NaN / infinity among the samples of the run: every sample lies under some symbol's volume).
-template <int OFF_BYTES> __device__ __forceinline__ dh_h8 dh_sym_read_at(uint32_t addr) {
-    static_assert(OFF_BYTES % 4 == 0 && OFF_BYTES / 4 + 3 < 256, "ds_read2_b32 offsets are 8-bit counts of words");
-    dh_f2 lo, hi;
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(lo) : "v"(addr), "n"(OFF_BYTES / 4), "n"(OFF_BYTES / 4 + 1) : "memory");
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(hi) : "v"(addr), "n"(OFF_BYTES / 4 + 2), "n"(OFF_BYTES / 4 + 3) : "memory");
-    dh_v4f v; v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
-    return __builtin_bit_cast(dh_h8, v);
-}
-struct DhSymFrags { dh_h8 x1[3], x2[3]; };
-// the six fragments of one tile: K steps 0..2 of the first and of the second array of halves (twelve LDS instructions)
-__device__ __forceinline__ void dh_sym_request(DhSymFrags& F, uint32_t base, uint32_t base2) {
-    F.x1[0] = dh_sym_read_at<0>(base); F.x1[1] = dh_sym_read_at<64>(base); F.x1[2] = dh_sym_read_at<128>(base);
-    F.x2[0] = dh_sym_read_at<0>(base2); F.x2[1] = dh_sym_read_at<64>(base2); F.x2[2] = dh_sym_read_at<128>(base2);
-}
-// everything requested before the twelve most recent LDS instructions has arrived (the LDS answers in order)
-__device__ __forceinline__ void dh_sym_arrived(DhSymFrags& F, bool last) {
-    if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F.x1[0]), "+v"(F.x1[1]), "+v"(F.x1[2]), "+v"(F.x2[0]), "+v"(F.x2[1]), "+v"(F.x2[2]) :: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(F.x1[0]), "+v"(F.x1[1]), "+v"(F.x1[2]), "+v"(F.x2[0]), "+v"(F.x2[1]), "+v"(F.x2[2]) :: "memory");
-}
-// r = 0, 1: lanes g < 3 (rows 4 g + r of the ring); r = 2: lanes g < 2 (g = 2 holds the mid-window sum: kept); r = 3: g < 2 ring, g = 2 volume
-template <int OFF> __device__ __forceinline__ void dh_sym_tile_store(uint32_t a0, uint32_t a3, float y0, float y1, float y2, float y3) {
-    asm volatile("s_mov_b32 exec_hi, 0xffff\n\t"
-                 "ds_write_b32 %0, %2 offset:%6\n\t"
-                 "ds_write_b32 %0, %3 offset:%7\n\t"
-                 "ds_write_b32 %1, %5 offset:%6\n\t"
-                 "s_mov_b32 exec_hi, 0\n\t"
-                 "ds_write_b32 %0, %4 offset:%8\n\t"
-                 "s_mov_b32 exec_hi, -1"
-                 :: "v"(a0), "v"(a3), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "n"(OFF), "n"(OFF + 400), "n"(OFF + 800) : "memory");
-}
-// the last tile: run indices 96..99 in columns 0..3 -- ring slots 97, 98, 99 and z (column 3: only its volume is stored, to slot 0)
-// (z's twelve values -- lanes 3, 19, 35 -- go to zst[4 g + r]: four words per lane at `azs`; its volume also to slot 0 of vol_new)
-__device__ __forceinline__ void dh_sym_tile6_store(uint32_t a0, uint32_t a3, uint32_t az, uint32_t azs, float y0, float y1, float y2, float y3) {
-    asm volatile("s_mov_b32 exec_lo, 0x00070007\n\ts_mov_b32 exec_hi, 7\n\t"
-                 "ds_write_b32 %0, %4 offset:384\n\t"
-                 "ds_write_b32 %0, %5 offset:784\n\t"
-                 "ds_write_b32 %1, %7 offset:384\n\t"
-                 "s_mov_b32 exec_hi, 0\n\t"
-                 "ds_write_b32 %0, %6 offset:1184\n\t"
-                 "s_mov_b32 exec_lo, 0x00080008\n\ts_mov_b32 exec_hi, 8\n\t"
-                 "ds_write_b32 %3, %4\n\tds_write_b32 %3, %5 offset:4\n\tds_write_b32 %3, %6 offset:8\n\tds_write_b32 %3, %7 offset:12\n\t"
-                 "s_mov_b32 exec_lo, 0\n\t"
-                 "ds_write_b32 %2, %7\n\t"
-                 "s_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, -1"
-                 :: "v"(a0), "v"(a3), "v"(az), "v"(azs), "v"(y0), "v"(y1), "v"(y2), "v"(y3) : "memory");
-}
-// the nine MFMAs of a tile (two chains: the main sum, three deep, and the second sum, six deep) and the combine
-__device__ __forceinline__ void dh_sym_mfma(const DhSymFrags& F, const dh_h8 (&t1)[3], const dh_h8 (&t2)[3], float k1, float k2, float (&y)[4]) {
-    dh_f32x4 mn = { 0.0f, 0.0f, 0.0f, 0.0f }, sc = { 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2[s], F.x1[s], sc, 0, 0, 0);
-        mn = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1[s], F.x1[s], mn, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; s++) sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1[s], F.x2[s], sc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; r++) y[r] = __builtin_fmaf(sc[r], k2, mn[r] * k1);
-}
-__device__ __forceinline__ void dh_fir_f16_sym(const float* hw, uint32_t wb_bytes, const dh_u4 (&G)[6], float k1, float k2,
-                                               float* var_rb, float* vol_new, float* sum, float* zst, bool& bad) {
-    constexpr uint32_t H2B = 4u * DH_F16_H2_OFFSET_OF(80);
-    const int lane = dh_fresh_lane_id_();
-    const uint32_t n = (uint32_t) lane & 15u, g = (uint32_t) lane >> 4;
-    // the lane's column in an even / odd tile, as a symbol index inside the tile pair's 32 symbols
-    const uint32_t c0 = 8u * (n >> 2) + ((0x07050200u >> (8u * (n & 3u))) & 255u), c1 = 8u * (n >> 2) + ((0x06040301u >> (8u * (n & 3u))) & 255u);
-    const uint32_t hwa = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) hw + wb_bytes + 16u * g;
-    const uint32_t w0 = hwa + 20u * c0, w1 = hwa + 20u * c1, w6 = hwa + 20u * (96u + (n & 3u));
-    const uint32_t ring = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) var_rb + 4u * (400u * g + 1u);
-    const uint32_t vola = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) vol_new;
-    const uint32_t a00 = ring + 4u * c0, a01 = ring + 4u * c1, a06 = ring + 4u * n;                          // (the last tile's stores carry the offset of slot 96)
-    const uint32_t a30 = g == 2u ? vola + 4u * (c0 + 1u) : a00 + 1200u, a31 = g == 2u ? vola + 4u * (c1 + 1u) : a01 + 1200u, a36 = g == 2u ? vola + 4u * (n + 1u) : a06 + 1200u;
-    dh_h8 t1[3], t2[3];
-#pragma unroll
-    for (int s = 0; s < 3; s++) { t1[s] = __builtin_bit_cast(dh_h8, G[s]); t2[s] = __builtin_bit_cast(dh_h8, G[3 + s]); }
-    float mid[DH_SYM_TILES];
-    float nonfinite = 0.0f;
-    DhSymFrags FA, FB;
-    float y[4];
-    dh_sym_request(FA, w0, w0 + H2B);
-#define DH_SYM_STEP(T, CUR, NXT, NBASE, A0, A3)                                                                          \
-    { const uint32_t nb_ = (NBASE); dh_sym_request(NXT, nb_, nb_ + H2B); }                                                 \
-    dh_sym_arrived(CUR, false);                                                                                            \
-    dh_sym_mfma(CUR, t1, t2, k1, k2, y);                                                                                   \
-    nonfinite = __builtin_fmaf(y[3], 0.0f, nonfinite); mid[T] = y[2];                                                      \
-    dh_sym_tile_store<128 * ((T) >> 1)>(A0, A3, y[0], y[1], y[2], y[3]);
-    DH_SYM_STEP(0, FA, FB, w1, a00, a30)
-    DH_SYM_STEP(1, FB, FA, w0 + 640u, a01, a31)
-    DH_SYM_STEP(2, FA, FB, w1 + 640u, a00, a30)
-    DH_SYM_STEP(3, FB, FA, w0 + 1280u, a01, a31)
-    DH_SYM_STEP(4, FA, FB, w1 + 1280u, a00, a30)
-    DH_SYM_STEP(5, FB, FA, w6, a01, a31)
-#undef DH_SYM_STEP
-    dh_sym_arrived(FA, true);
-    dh_sym_mfma(FA, t1, t2, k1, k2, y);
-    nonfinite = __builtin_fmaf(y[3], 0.0f, nonfinite); mid[6] = y[2];
-    dh_sym_tile6_store(a06, a36, vola, (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) zst + 16u * g, y[0], y[1], y[2], y[3]);
-    // the mid-window sums: every read of the window block has returned, `sum` may be written
-    {
-        const uint32_t sb = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) sum;
-        const uint32_t s0 = sb + 4u * c0, s1 = sb + 4u * c1, s6 = sb + 4u * (96u + n);
-        asm volatile("s_mov_b32 exec_lo, 0\n\ts_mov_b32 exec_hi, 0xffff\n\t"
-                     "ds_write_b32 %0, %3\n\tds_write_b32 %1, %4\n\tds_write_b32 %0, %5 offset:128\n\tds_write_b32 %1, %6 offset:128\n\t"
-                     "ds_write_b32 %0, %7 offset:256\n\tds_write_b32 %1, %8 offset:256\n\t"
-                     "s_mov_b32 exec_hi, 0xf\n\t"
-                     "ds_write_b32 %2, %9\n\t"
-                     "s_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, -1\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     :: "v"(s0), "v"(s1), "v"(s6), "v"(mid[0]), "v"(mid[1]), "v"(mid[2]), "v"(mid[3]), "v"(mid[4]), "v"(mid[5]), "v"(mid[6]) : "memory");
-    }
-    bad = __builtin_amdgcn_ballot_w64(!(nonfinite == 0.0f)) != 0;
-}
 #else
 // harness: the same split and the same sums as plain f32 chains (products of halves are exact in f32; a sequential chain of
 // 96 rounded additions stays inside what (H1) allows the hardware, so the decisions downstream are the same)
@@ -1034,34 +830,6 @@ inline void dh_fir_f16(const float* hw, const uint32_t (*G)[DH_WAVE][4], int lan
             }
         out16[4 * T + r] = __builtin_fmaf(sc, k2, mn * k1);
     }
-}
-#endif
-
-#if !(DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__))
-// harness: the symbol-major product as plain f32 chains over the same halves and the same tap fragments (see dh_fir_f16 above);
-// z[i] = sample i of run index 99 (the device keeps them in the registers of the lanes n = 3)
-inline void dh_fir_f16_sym(const float* hw, uint32_t wb_bytes, const uint32_t (*G)[DH_WAVE][4], float k1, float k2,
-                           float* var_rb, float* vol_new, float* sum, float* z, bool& bad) {
-    const uint16_t* h1 = reinterpret_cast<const uint16_t*>(hw) + wb_bytes / 2u;
-    const uint16_t* h2 = reinterpret_cast<const uint16_t*>(hw + DH_F16_H2_OFFSET_OF(80)) + wb_bytes / 2u;
-    bad = false;
-    float mids[100];                                           // (`sum` lies inside the window block: written when nothing reads it any more)
-    for (uint32_t j = 0; j < 100u; j++) for (int i = 0; i < DH_SYM_FUNCS; i++) {
-        float mn = 0.0f, sc = 0.0f;
-        for (int pass = 0; pass < 3; pass++)
-            for (int s = 0; s < 3; s++) for (int q = 0; q < 4; q++) for (int e = 0; e < 8; e++) {
-                const uint32_t w = G[(pass == 1 ? 3 : 0) + s][16 * q + i][e >> 1];
-                const float tap = dh_f16_value((uint16_t) (w >> (16 * (e & 1))));
-                const uint16_t hv = (pass == 2 ? h2 : h1)[10u * j + 32u * (uint32_t) s + 8u * (uint32_t) q + (uint32_t) e];
-                if (pass == 0) mn = __builtin_fmaf(dh_f16_value(hv), tap, mn); else sc = __builtin_fmaf(dh_f16_value(hv), tap, sc);
-            }
-        const float y = __builtin_fmaf(sc, k2, mn * k1);
-        if (i == 11) { vol_new[(j + 1u) % 100u] = y; if (!(y * 0.0f == 0.0f)) bad = true; }
-        else if (i == 10) mids[j] = y;
-        else if (j < 99u) var_rb[(uint32_t) i * DH_VARIANCE_SYMBOLS + j + 1u] = y;
-        else z[i] = y;
-    }
-    for (uint32_t j = 0; j < 100u; j++) sum[j] = mids[j];
 }
 #endif
 
@@ -1182,26 +950,20 @@ __device__ __forceinline__ float dh_wave_prev(float v, float first) {
 // backwards (lane l takes slots 126-2l and 127-2l), handed back to the owning lanes -- lane 63 - l -- by four ds_bpermute
 // (until round 5 through S.mn / S.mx: four stores, a barrier, four loads, a barrier -- one LDS round trip more).  The lane's
 // results (slots 2l and 2l+1) are also returned: the slicing phase of a run that starts its block takes them from there.
-// ROT (a symbol-major run: one hundred symbols from ring slot 1 round to slot 0, k0 = 0, k1 = 100): element e of the scan is ring slot
-// DH_ROT_SLOT(e) = (e + 1) mod 100 -- the arrays in LDS stay indexed by slot, the scan and its results (lane l: elements 2 l, 2 l + 1)
-// run in symbol order.
-#define DH_ROT_SLOT(e) ((e) < 99u ? (e) + 1u : (e) == 99u ? 0u : (e))
 struct DhAgcPair { float mn0, mx0, mn1, mx1; };
-template <bool ROT = false>
 __device__ __forceinline__ DhAgcPair dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
     const int lane = dh_fresh_lane_id_();
     const uint32_t e0 = 2u * (uint32_t) lane, e1 = e0 + 1u;
-    const uint32_t i0 = ROT ? DH_ROT_SLOT(e0) : e0, i1 = ROT ? DH_ROT_SLOT(e1) : e1;
     // prefix source: old below k0, new in [k0, k1), identity above
-    const float c0 = e0 < k0 ? S.vol_old[i0] : S.vol_new[i0];
-    const float c1 = e1 < k0 ? S.vol_old[i1] : S.vol_new[i1];
+    const float c0 = e0 < k0 ? S.vol_old[e0] : S.vol_new[e0];
+    const float c1 = e1 < k0 ? S.vol_old[e1] : S.vol_new[e1];
     const bool v0 = e0 < k1, v1 = e1 < k1;
     const float pmn0 = v0 ? c0 : DH_FLT_MAX, pmn1 = v1 ? c1 : DH_FLT_MAX;
     const float pmx0 = v0 ? c0 : DH_FLT_MIN, pmx1 = v1 ? c1 : DH_FLT_MIN;
     float pmn = dh_vmin(pmn0, pmn1), pmx = dh_vmax(pmx0, pmx1);
     // suffix source: the old ring backwards (slots >= 100 hold the identity)
     const uint32_t r0 = 126u - e0, r1 = r0 + 1u;
-    const float o0 = S.vol_old[ROT ? DH_ROT_SLOT(r0) : r0], o1 = S.vol_old[ROT ? DH_ROT_SLOT(r1) : r1];
+    const float o0 = S.vol_old[r0], o1 = S.vol_old[r1];
     const float omn0 = r0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MAX, omn1 = r1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MAX;
     const float omx0 = r0 < DH_VOLUME_RB_SIZE ? o0 : DH_FLT_MIN, omx1 = r1 < DH_VOLUME_RB_SIZE ? o1 : DH_FLT_MIN;
     float smn = dh_vmin(omn0, omn1), smx = dh_vmax(omx0, omx1);
@@ -1219,25 +981,12 @@ __device__ __forceinline__ DhAgcPair dh_agc_scan(DhDspShared& S, uint32_t k0, ui
     DhAgcPair r;
     r.mn0 = dh_vmin(dh_vmin(epmn, pmn0), s0n); r.mx0 = dh_vmax(dh_vmax(epmx, pmx0), s0x);
     r.mn1 = dh_vmin(pmn, s1n); r.mx1 = dh_vmax(pmx, s1x);
-    S.mn[i0] = r.mn0; S.mx[i0] = r.mx0; S.mn[i1] = r.mn1; S.mx[i1] = r.mx1;
+    S.mn[e0] = r.mn0; S.mx[e0] = r.mx0; S.mn[e1] = r.mn1; S.mx[e1] = r.mx1;
     return r;
 }
 #else
-#define DH_ROT_SLOT(e) ((e) < 99u ? (e) + 1u : (e) == 99u ? 0u : (e))
-template <bool ROT = false>
 inline void dh_agc_scan(DhDspShared& S, uint32_t k0, uint32_t k1) {
     // plain sequential statement of the same thing (harness only)
-    if (ROT) {                                          // one hundred symbols in the order slot 1 .. 99, 0; results by slot
-        float pmn = DH_FLT_MAX, pmx = DH_FLT_MIN;
-        for (uint32_t e = 0; e < DH_VOLUME_RB_SIZE; e++) {
-            const uint32_t k = DH_ROT_SLOT(e);
-            pmn = dh_fmin_(pmn, S.vol_new[k]); pmx = dh_fmax_(pmx, S.vol_new[k]);
-            float smn = DH_FLT_MAX, smx = DH_FLT_MIN;
-            for (uint32_t f = e + 1; f < DH_VOLUME_RB_SIZE; f++) { smn = dh_fmin_(smn, S.vol_old[DH_ROT_SLOT(f)]); smx = dh_fmax_(smx, S.vol_old[DH_ROT_SLOT(f)]); }
-            S.mn[k] = dh_fmin_(pmn, smn); S.mx[k] = dh_fmax_(pmx, smx);
-        }
-        return;
-    }
     float pmn = DH_FLT_MAX, pmx = DH_FLT_MIN;
     for (uint32_t j = 0; j < k0; j++) { pmn = dh_fmin_(pmn, S.vol_old[j]); pmx = dh_fmax_(pmx, S.vol_old[j]); }
     for (uint32_t k = k0; k < k1; k++) {
@@ -1372,7 +1121,6 @@ struct DhExactCtx {
     const float* tapsf; double gain, rgain; float sps_rcp;
     int32_t cur_start, cur_off, prev_start, prev_off; uint32_t blk_flags;
     uint32_t k0;                                                        // ring slots [k0, k] hold this run's volumes (S.vol_new)
-    uint32_t all_new;                                                   // 1: every slot's volume is this run's (the last symbol of a symbol-major run, which has gone round the ring)
     float e_eff; int32_t levels, invert;
 };
 // filtered position of sample 0 of ring slot j as seen from symbol k of the current block: slots <= k belong to the
@@ -1462,7 +1210,7 @@ DH_COLD uint8_t dh_exact_symbol_staged(const DhExactCtx& C, DhDspShared& S, uint
             const uint32_t j = (uint32_t) lane + 64u * (uint32_t) h;
             bool lo = false, hi = false;
             if (j < DH_VOLUME_RB_SIZE) {
-                const float v = (C.all_new || (j >= C.k0 && j <= k)) ? S.vol_new[j] : S.vol_old[j];
+                const float v = (j >= C.k0 && j <= k) ? S.vol_new[j] : S.vol_old[j];
                 lo = v <= lo_thr; hi = v >= hi_thr;
             }
             DH_BALLOT_ACC(vlo, lo, lane); DH_BALLOT_ACC(vhi, hi, lane);
@@ -1616,13 +1364,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
     constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
-    // Symbol-major runs (DhF16SymTaps): once symbol 0 of a variance block has been taken (k0 = 1), the next hundred symbols -- 1..99 of the
-    // block and symbol 0 of the NEXT one, which sits one symbol period behind symbol 99 whatever the block's timing decision will be
-    // (gfsk_demodulator.cpp:36-38: the step is applied behind symbol 0) -- lie on ONE grid, p + 10 j.  Such a run takes ring samples,
-    // mid-window sums and volumes straight from the matrix cores (no write-back of filtered samples, no window phase) and leaves the
-    // stream at k0 = 1 again.  Everything else (the symbols up to the first k0 = 1 of a push, the last ones, exact modes, odd samples)
-    // takes the general run below.
-    constexpr bool SYMRUN = DH_SYM_RUNS && MF16 && NZ == 80 && SPS == 10 && !KEEPF;
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;
@@ -1678,10 +1419,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // raw samples behind every entry of the 100-symbol rings are still at hand when a comparison has to be settled exactly
     uint32_t p = BOUNDED ? sth[DH_ST_P0] : 0u;          // read position in the filtered stream
     bool staged = false; uint32_t staged_p = 0;         // the LDS window already holds V[staged_p ...) (prefetch)
-    uint32_t staged_woff = 0;                           // ... for a run whose first symbol sits at staged_p + staged_woff (symbol-major runs: 0..2; else 0)
-    bool no_sym = !SYMRUN || P.tapfrag_sym == nullptr || P.exact_mode != 0;      // no (more) symbol-major runs in this push
-    uint32_t n_sym_runs = 0;
-    uint32_t tf_set = 0;                                // what tapfrag_regs holds: 0 = the block-major fragments, 1 / 2 = the symbol-major ones, even / odd offset
     // the next window fetched into registers behind P3 and put into the window block in P7: the split-f16 kernels (as two arrays of
     // halves, with the constants of its run below) and the kernels without an RRC stage (as it is: they have the registers, and staged
     // from L2 at the start of the next run every run waited out an L2 round trip: POCSAG slicer 4.86 -> 4.34 ms, D-Star chain 3.94 -> 3.65,
@@ -1784,10 +1521,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // of the chip (L1 / L2 hits).  Requested one iteration ahead (here, and again at the end of every iteration, when the
     // staging registers are free), so they have landed when P2 wants them.
     dh_u4 tapfrag_regs[2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80)];
-#define DH_TAPFRAG_LOAD(set_) do { if constexpr (MF16) { tf_set = (set_); \
-        const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(tf_set ? P.tapfrag_sym + (tf_set - 1u) * (6u * DH_WAVE * 4u) : P.tapfrag) + dh_fresh_lane_id_(); \
+#define DH_TAPFRAG_LOAD() do { if constexpr (MF16) { const dh_u4* tf_ = reinterpret_cast<const dh_u4*>(P.tapfrag) + dh_fresh_lane_id_(); \
         _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) tapfrag_regs[f_] = tf_[DH_WAVE * f_]; } } while (0)
-    DH_TAPFRAG_LOAD((!no_sym && k0 == 1u) ? 1u : 0u);
+    DH_TAPFRAG_LOAD();
     // Every path through P2 must leave these loads landed, also the rare ones that never look at the fragments: otherwise the
     // compiler's wait-count bookkeeping still sees them in flight further down, and the first instruction that reuses one of
     // their registers -- in the slicing phase -- gets an s_waitcnt vmcnt(0), which also waits for the NEXT window's loads,
@@ -1795,7 +1531,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
 #define DH_TAPFRAG_SETTLE() do { if constexpr (MF16) { _Pragma("unroll") for (int f_ = 0; f_ < 2 * DH_F16_KSTEPS_OF(NZ > 0 ? NZ : 80); f_++) \
         asm volatile("" :: "v"(tapfrag_regs[f_])); } } while (0)
 #else
-#define DH_TAPFRAG_LOAD(set_) ((void) (tf_set = (set_)))
+#define DH_TAPFRAG_LOAD() ((void) 0)
 #define DH_TAPFRAG_SETTLE() ((void) 0)
 #endif
     for (;;) {
@@ -1804,16 +1540,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // s_0 = p, s_q = p + q*sps + step_off for q >= 1.
         const int32_t step_off = (k0 == 0) ? off : 0;   // applied after the first symbol of a block
         uint32_t m = 0;
-        // symbol-major run: symbols 1..99 of the block and symbol 0 of the next (at p + 990: produced iff nf - (p + 990) > 11) all fit
-        bool sym_run = SYMRUN && DH_LIKELY(!no_sym && k0 == 1u && fast_p_end >= 0 && (int32_t) p <= fast_p_end + 1 && (int32_t) nsym <= fast_sym_end);
-        // (the symbol-major run IS the hot path of these kernels: the weights keep the allocator's spill code in the general run)
-#define DH_IS_SYM (SYMRUN && DH_LIKELY(sym_run))
-        if (DH_IS_SYM) {
-            m = DH_VARIANCE_SYMBOLS;
-        } else if (SYMRUN && !no_sym && k0 == 0u && fast_p_end >= 10 && (int32_t) p <= fast_p_end - 10 && (int32_t) nsym + 1 <= fast_sym_end) {
-            // symbol 0 alone, so that the run behind it can be a symbol-major one (p + 10 + off + 1002 <= nf, 101 symbols of room)
-            m = 1;
-        } else
         if (DH_PLAN_FAST && SPS == 10 && DH_LIKELY(k0 == 0 && (int32_t) p <= fast_p_end && (int32_t) nsym <= fast_sym_end)) {
             // the usual run: it starts a variance block and holds all of it -- the stream has the samples whatever the pending step
             // is (nf - p >= 1003 >= 1002 + step_off) and the symbol buffer the room: what the general form below comes to, in three
@@ -1858,9 +1584,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // 16 B per LDS store (a group of four never straddles a pad slot: pads sit every 16 elements).
         // From the second run on, the window was already put there by the previous iteration's prefetch (the kernels that fetch it into
         // registers: PF_REG; the others have had it pulled into L2).
-        uint32_t woff = 0;                              // symbol-major run: its first symbol sits this many halves into the staged window
-        if (DH_LIKELY(staged && staged_p + staged_woff == p && (sym_run || staged_woff == 0u))) {
-            if (PF_REG && MF16) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; woff = staged_woff; }      // (put there by P7 of the previous run)
+        if (DH_LIKELY(staged && staged_p == p)) {
+            if (PF_REG && MF16) { f16_staged = true; xmax_done = true; e_run = st_e_run; k1 = st_k1; k2 = st_k2; }      // (put there by P7 of the previous run)
         } else if (p >= tc && in + (p - tc) + (DH_FTILE + NZ) <= in_end) {
             // whole window inside the input buffer: unconditional loads (all in flight together, see the prefetch
             // below for why that matters), samples past the end of the stream zeroed afterwards
@@ -1990,37 +1715,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else use_exact = true;                      // tiny, huge or infinite samples: outside the bound's assumptions
         }
         DH_CLK(0);
-        if (SYMRUN && sym_run && DH_UNLIKELY(!f16_staged || use_exact)) {
-            // samples the bound does not cover (or an exact mode): no symbol-major runs for the rest of this push; the window is staged again
-            no_sym = true; staged = false;
-            continue;
-        }
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
         // The filtered samples go back UNPADDED (element n at word n, four 16-byte stores per lane): the symbol
         // windows of P3 then sit at compile-time offsets from one per-lane base, which saves two address
         // instructions per sample on the VALU; the bank conflicts of the 16-words-apart stores cost LDS cycles
         // only, and the LDS pipe has slack.  Without an RRC stage the staged (padded) samples are used as they are.
-        // symbol-major run: P2 and P3 in one -- ring samples (slots 1..99), volumes (slots 1..99, 0) and mid-window sums (by run index) straight
-        // from the matrix cores; the ten samples of the run's last symbol (slot 0 of the NEXT block) wait in `zs` (LDS) until P6 has read this block's slot 0
-        float* const zs = S.vol_old + 112;              // (sixteen words of the ring's padding: nothing reads slots >= 100)
-        if (DH_IS_SYM) {
-            bool bad = false;
-            const uint32_t want = 1u + (woff & 1u);
-            if (DH_UNLIKELY(tf_set != want)) DH_TAPFRAG_LOAD(want);
-            DH_COMPILER_FENCE();
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (SYMRUN) dh_fir_f16_sym(S.xf, 2u * (woff & ~1u), reinterpret_cast<const dh_u4 (&)[6]>(tapfrag_regs), k1, k2, S.var_rb, S.vol_new, S.sum, zs, bad);
-#else
-            dh_fir_f16_sym(S.xf, 2u * (woff & ~1u), reinterpret_cast<const uint32_t (*)[DH_WAVE][4]>(P.tapfrag_sym + (want - 1u) * (6u * DH_WAVE * 4u)), k1, k2, S.var_rb, S.vol_new, S.sum, zs, bad);
-#endif
-            if (DH_UNLIKELY(bad)) {                     // a NaN / infinity among the samples: the general run, with the reference's arithmetic (nothing has been committed)
-                no_sym = true; staged = false;
-                DH_TAPFRAG_SETTLE();
-                continue;
-            }
-            DH_BARRIER();
-        } else
         if (NZ > 0 && DH_STOP_AFTER >= 2) {
             DH_LANE_ARRAY(float, fo, DH_FIR_L);
             DH_COMPILER_FENCE();                        // forces the tap loads below to stay inside this pass
@@ -2033,7 +1733,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 if (DH_LIKELY(!use_exact)) {
                     if constexpr (MF16) {
                         // (f16_staged holds: every staging path that does not fill the two arrays of halves sets use_exact)
-                        if (SYMRUN && DH_UNLIKELY(tf_set != 0u)) DH_TAPFRAG_LOAD(0u);      // (the registers hold a symbol-major set: predicted wrong)
                         DH_FOR_LANES_FRESH(lane) {
                             float t = 0.0f;
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
@@ -2142,16 +1841,13 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // iteration, and P4-P6 are latency-bound with few live registers: the HBM latency of these loads hides
         // behind them.  Five 16-byte loads per lane, parked in registers until P7.
         const uint32_t p_next = last_start + sps + ((k0 == 0 && m == 1) ? (uint32_t) step_off : 0u);
-        // (a symbol-major run: the next run starts at p + 1000 + the step P6 is yet to decide -- its window is fetched from one sample
-        // earlier, so that all three outcomes lie inside it: first symbol at 0, 1 or 2 halves, staged_woff)
-        const uint32_t pf_origin = (SYMRUN && sym_run) ? p + 999u : p_next;
-        const bool pf_ok = pf_origin >= tc && pf_origin < nv;
-        const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - pf_origin) : 0u;
+        const bool pf_ok = p_next >= tc && p_next < nv;
+        const uint32_t pf_have = pf_ok ? dh_min<uint32_t>(DH_FTILE + NZ, nv - p_next) : 0u;
         DH_LANE_ARRAY(dh_f4, pfr, PF_REG ? DH_PF_N : 1);  // split-f16 kernels: the next window, parked in registers through P4 - P6
         // Only when the whole window lies inside the input buffer (every run but the last ones of the last
         // channel): the loads are then unconditional, there is nothing to merge, and all five are in flight
         // together; samples past pf_have are zeroed in P7.  Otherwise the next iteration stages in P1.
-        const bool pf_plain = pf_ok && (in + (pf_origin - tc) + (DH_FTILE + NZ) <= in_end);
+        const bool pf_plain = pf_ok && (in + (p_next - tc) + (DH_FTILE + NZ) <= in_end);
         const bool pf_reg = PF_REG && pf_plain && P.exact_mode != 2;
         if constexpr (KEEPF) {
             // This run's filtered samples [p, p_next) leave as they stand in LDS (each store instruction a run of 64 consecutive
@@ -2171,7 +1867,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             // per lane are issued here, straight from HBM, land while P4 - P6 run, and P7 turns them into the two arrays of
             // halves -- the next iteration starts at the matrix cores.
             constexpr uint32_t LAST_LANES = (DH_FTILE + NZ - 4u * DH_WAVE * (DH_PF_N - 1)) / 4u;
-            const float* src = in + (pf_origin - tc);
+            const float* src = in + (p_next - tc);
             DH_FOR_LANES_FRESH(lane) {
                 const float* lsrc = src + 4u * (uint32_t) lane;
                 const bool in_last = (uint32_t) lane < LAST_LANES;
@@ -2190,7 +1886,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         if (pf_plain) {
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
             const uint32_t pf_lane = (uint32_t) dh_fresh_lane_id_();       // not loop-invariant: a hoisted address is spilled
-            const float* line = in + (pf_origin - tc) + 32u * pf_lane;
+            const float* line = in + (p_next - tc) + 32u * pf_lane;
             const uint32_t sink = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float*) (S.xf + DH_PF_SINK);
             uint32_t keep_m0;
             if (32u * pf_lane < DH_FTILE + NZ)
@@ -2230,7 +1926,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // SQ_LDS_BANK_CONFLICT 4.75e8 -> 1.74e8 per launch, SQ_LDS_IDX_ACTIVE -21 %, chain -2 % (profiles/r05_a_ab_logs.txt).  Each
         // symbol's sums run in sample order, as the reference's do.  Lanes beyond the run read words of the window block that nothing will
         // look at and store nothing.
-        if (SPS == 10 && DH_STOP_AFTER >= 3 && !DH_IS_SYM) DH_FOR_LANES_FRESH(lane) {
+        if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
             const uint32_t l = (uint32_t) lane;
             const uint32_t qa = l + 1u, qb = l < 35u ? l + 65u : 0u;
             const bool va = qa < m, vb = l < 35u ? qb < m : l == 35u;
@@ -2377,9 +2073,9 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // ---- P4: sliding AGC min/max as two wave scans
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
         DhAgcPair agc = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (DH_STOP_AFTER >= 4) { if (DH_IS_SYM) agc = dh_agc_scan<true>(S, 0u, DH_VOLUME_RB_SIZE); else agc = dh_agc_scan<false>(S, k0, k0 + m); }
+        if (DH_STOP_AFTER >= 4) agc = dh_agc_scan(S, k0, k0 + m);
 #else
-        if (DH_STOP_AFTER >= 4) { if (DH_IS_SYM) dh_agc_scan<true>(S, 0u, DH_VOLUME_RB_SIZE); else dh_agc_scan<false>(S, k0, k0 + m); }
+        if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
 #endif
         DH_BARRIER();
         DH_CLK(3);
@@ -2395,15 +2091,14 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_FOR_LANES_FRESH(lane) {
             const uint32_t qa = 2u * (uint32_t) lane;
             const bool va = qa < m, vb = qa + 1u < m;
-            const uint32_t qq = va ? qa : 0u;                                         // (lanes beyond the run recompute symbols 0 / 1: in-range reads, no store)
-            const uint32_t k = (SYMRUN && sym_run) ? DH_ROT_SLOT(qq) : k0 + qq, kn = (SYMRUN && sym_run) ? DH_ROT_SLOT(qq + 1u) : k + 1u;      // their ring slots
+            const uint32_t qq = va ? qa : 0u, k = k0 + qq;                            // (lanes beyond the run recompute symbols 0 / 1: in-range reads, no store)
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            // (a run that starts its block, or a symbol-major one: the lane's symbols 2 l, 2 l + 1 are what the AGC scan left in its registers)
+            // (a run that starts its block: the lane's symbols 2 l, 2 l + 1 are the ring slots the AGC scan left in its registers)
             dh_f2 mn, mx;
-            if (DH_IS_SYM || k0 == 0u) { mn = dh_f2_make(agc.mn0, agc.mn1); mx = dh_f2_make(agc.mx0, agc.mx1); }
-            else { mn = dh_f2_make(S.mn[k], S.mn[kn]); mx = dh_f2_make(S.mx[k], S.mx[kn]); }
+            if (k0 == 0u) { mn = dh_f2_make(agc.mn0, agc.mn1); mx = dh_f2_make(agc.mx0, agc.mx1); }
+            else { mn = dh_f2_make(S.mn[k], S.mn[k + 1u]); mx = dh_f2_make(S.mx[k], S.mx[k + 1u]); }
 #else
-            const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[kn]), mx = dh_f2_make(S.mx[k], S.mx[kn]);
+            const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[k + 1u]), mx = dh_f2_make(S.mx[k], S.mx[k + 1u]);
 #endif
             const dh_f2 sumq = dh_f2_make(S.sum[qq], S.sum[qq + 1u]);
             const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);                // (max + min) / 2.0f: the division by two is exact
@@ -2446,7 +2141,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
             C.prev_start = (int32_t) dh_uniform((uint32_t) BS->prev_start); C.prev_off = (int32_t) dh_uniform((uint32_t) BS->prev_off);
             C.blk_flags = dh_uniform(BS->blk_flags);
-            C.k0 = k0; C.all_new = 0; C.e_eff = e_eff; C.levels = P.levels; C.invert = P.invert;
+            C.k0 = k0; C.e_eff = e_eff; C.levels = P.levels; C.invert = P.invert;
             // one evaluation at a time, the even symbols' votes first (the evaluations do not depend on one another); ONE call site:
             // the evaluation is a thousand instructions of text
             uint64_t ta = vote_a, tb = vote_b;
@@ -2455,15 +2150,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 if (ta) { q = 2u * (uint32_t) dh_ffs64(ta); ta &= ta - 1; } else { q = 2u * (uint32_t) dh_ffs64(tb) + 1u; tb &= tb - 1; }
                 // (the raw samples behind each evaluation are staged through the dead part of the window block: fetched one by one from
                 // HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
-                uint32_t kq = k0 + q;
-                if (SYMRUN && sym_run && q == DH_VARIANCE_SYMBOLS - 1u) {
-                    // the last symbol of a symbol-major run (always the last one evaluated) is symbol 0 of the NEXT block, at p + 990; every other
-                    // slot holds this run's volumes and lies on the block that is still the current one
-                    kq = 0; C.k0 = 0; C.all_new = 1;
-                    C.prev_start = C.cur_start; C.prev_off = C.cur_off; C.blk_flags = (C.blk_flags & 1u) ? 3u : 1u;
-                    C.cur_start = (int32_t) p + 990; C.cur_off = 0;
-                }
-                const uint8_t sym = dh_exact_symbol_staged<NZ>(C, S, kq, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi);
+                const uint8_t sym = dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi);
                 DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
                 BS->n_uncertain++;
             }
@@ -2487,7 +2174,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         // from 0 and from 5e6, the reference's decision is known; an all-zero phase gives vmin = 0 exactly.
         // Anything else (ties, constant input, non-finite or huge samples) is decided by the ordered chain.
         int32_t new_off = 0;
-        const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS) || (SYMRUN && sym_run);
+        const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done && DH_STOP_AFTER >= 6) {
             bool ordered = true;
             // Phases that can still be the reference's arg-min once an estimate has been taken and could not decide: those whose
@@ -2794,7 +2481,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                         C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
                         C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
                         C.prev_start = 0; C.prev_off = 0; C.blk_flags = dh_uniform(BS->blk_flags);
-                        C.k0 = k0; C.all_new = 0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
+                        C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
                         // (the window block is dead here except words 512..575, where the L2 touch of the next window may
                         // still be dropping its dwords: the staged variant uses the words behind them)
                         dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, chain_rows);
@@ -2885,20 +2572,14 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_FOR_LANES_FRESH(lane) {
             // a run has at most 100 symbols: two predicated copies per lane, both loads in flight together (as a loop this was
             // two trips of exec-mask bookkeeping with a wait in each)
-            // (a symbol-major run has written every slot: 1..99 and, last, 0)
-            const uint32_t kf = (SYMRUN && sym_run) ? 0u : k0, ke = (SYMRUN && sym_run) ? (uint32_t) DH_VOLUME_RB_SIZE : k0 + m;
-            const uint32_t ka = kf + (uint32_t) lane, kb = ka + DH_WAVE;
-            const float va_ = S.vol_new[ka < ke ? ka : kf], vb_ = S.vol_new[kb < ke ? kb : kf];
+            const uint32_t ka = k0 + (uint32_t) lane, kb = ka + DH_WAVE, ke = k0 + m;
+            const float va_ = S.vol_new[ka < ke ? ka : k0], vb_ = S.vol_new[kb < ke ? kb : k0];
             if (ka < ke) S.vol_old[ka] = va_;
             if (kb < ke) S.vol_old[kb] = vb_;
-            if (DH_IS_SYM) {
-                // slot 0 of the ring now belongs to the next block: the ten samples of the run's last symbol
-                if (lane < 10) S.var_rb[(uint32_t) lane * DH_VARIANCE_SYMBOLS] = zs[lane];
-            }
         }
         staged = false;
         if (DH_LIKELY(pf_reg)) {
-            if constexpr (PF_REG && MF16) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = pf_origin; staged_woff = (SYMRUN && sym_run) ? (uint32_t) (1 + new_off) : 0u; }
+            if constexpr (PF_REG && MF16) { staged = stage_f16(pfr, pf_have, st_e_run, st_k1, st_k2); staged_p = p_next; }
             else if constexpr (PF_PLAIN) {
                 // no RRC stage: the window is the 1 024 samples themselves (four groups of four per lane, unpadded), zeros beyond the stream's end
                 static_assert(!PF_PLAIN || (DH_FTILE == 4u * DH_WAVE * (DH_PF_N - 1)), "four full groups cover the window");
@@ -2920,13 +2601,11 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         DH_BARRIER();
-        const uint32_t p_run = p;
-        p = (SYMRUN && sym_run) ? p + 1000u + (uint32_t) new_off : p_next;      // (symbol-major: behind symbol 0 of the next block, the step applied)
+        p = p_next;
         nsym += m;
         if (k0 == 0) off = 0;                           // the pending step has been consumed (:36-38)
         k0 += m;
         if (block_done) { k0 = 0; off = new_off; }
-        if (DH_IS_SYM) { k0 = 1; off = 0; n_sym_runs++; }     // symbol 0 of the next block is done and its step consumed
         if (BOUNDED) {
             // radii of the ring entries: the last 100 symbols always lie inside the current bucket + the one before it
             const float ec = __builtin_fmaxf(BS->e_cur, e_run);
@@ -2934,12 +2613,8 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             if (cnt >= DH_VOLUME_RB_SIZE) { BS->e_prev = ec; BS->e_cur = 0.0f; BS->e_count = 0; }
             else { BS->e_cur = ec; BS->e_count = cnt; }
             if (block_done) { BS->prev_start = BS->cur_start; BS->prev_off = BS->cur_off; BS->blk_flags = (BS->blk_flags & 1u) ? 2u : 0u; }
-            if (DH_IS_SYM) {                    // ... and the next block has begun: its symbol 0 sat at p_run + 990, with this run's radius
-                BS->cur_start = (int32_t) p_run + 990; BS->cur_off = new_off; BS->blk_flags = (BS->blk_flags & 3u) | 1u; BS->e_blk = e_run;
-            }
         }
-        // the tap fragments of the next run: a symbol-major one if the stream stands behind a symbol 0 with a whole run ahead
-        DH_TAPFRAG_LOAD((SYMRUN && !no_sym && k0 == 1u && fast_p_end >= 0 && (int32_t) p <= fast_p_end + 1) ? 1u + ((staged ? staged_woff : 0u) & 1u) : 0u);
+        DH_TAPFRAG_LOAD();                              // for the next run
         DH_CLK(6);
     }
 
@@ -2998,7 +2673,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
                 sth[DH_ST_UNCERTAIN] += BS->n_uncertain; sth[DH_ST_EXACT_RUNS] += BS->n_exact_runs; sth[DH_ST_EXACT_BLOCKS] += BS->n_exact_blocks;
             }
 
-            if (SYMRUN) sth[DH_ST_SYM_RUNS] += n_sym_runs;
             sth[DH_ST_ORDERED] += S.stats[1];
             P.sym_count[ch] = nsym;
             if ((overflow || new_tc > tail_max) && P.overflow) *P.overflow = 1u;

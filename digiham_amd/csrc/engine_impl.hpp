@@ -132,7 +132,6 @@ struct Engine {
     DhDspParams dsp{}; DhRrcParams rrcp{}; DhDecParams dec{};
     float* custom_taps = nullptr; double custom_gain = 0.0;      // DH_RRC_CUSTOM: device copy of the caller's table
     uint32_t* tapfrag = nullptr; float err_coef_f16 = 0.0f;      // split-f16 FIR of the wide filter: per-lane tap fragments (dh_f16_tap_fragments)
-    uint32_t* tapfrag_sym = nullptr;                             // ... and their symbol-major form (dh_f16_sym_fragments; wide filter at sps 10)
 
     int init(const dh_engine_config& c) {
         int rc = make_layout(c, L);
@@ -180,18 +179,6 @@ struct Engine {
             if (!rc) rc = be.sync();
             delete F;
             if (rc) return rc == DH_ENOMEM ? rc : DH_EDEVICE;
-            if (DH_SYM_RUNS && L.nz == 80 && L.sps == 10 && !L.fused_keep) {
-                // symbol-major runs (dsp_core.hpp, DhF16SymTaps): a run's radius covers whichever of the two products made it
-                DhF16SymTaps* G = new (std::nothrow) DhF16SymTaps;
-                if (!G) return DH_ENOMEM;
-                dh_f16_sym_fragments(half, L.nz, gain, *G);
-                if (G->coef > err_coef_f16) err_coef_f16 = G->coef;
-                tapfrag_sym = (uint32_t*) be.alloc(sizeof(G->frag));
-                rc = tapfrag_sym ? be.upload(tapfrag_sym, G->frag, sizeof(G->frag)) : DH_ENOMEM;
-                if (!rc) rc = be.sync();
-                delete G;
-                if (rc) return rc == DH_ENOMEM ? rc : DH_EDEVICE;
-            }
         }
 #undef DH_ALLOC
         return reset();
@@ -199,7 +186,7 @@ struct Engine {
 
     void destroy() {
         void* ptrs[] = { dsp_state, syms, sym_count, sym_carry, dec_state, frames, frame_count, events, ev_count,
-                         overflow, filtered, rrc_hist, staging, staging_counts, counts_copy, tables, custom_taps, tapfrag, tapfrag_sym };
+                         overflow, filtered, rrc_hist, staging, staging_counts, counts_copy, tables, custom_taps, tapfrag };
         for (void* p : ptrs) if (p) be.free(p);
     }
 
@@ -305,7 +292,7 @@ struct Engine {
             if (L.fused) {
                 fill_taps(L.rrc, dsp.taps, &dsp.gain); dsp.rgain = 1.0 / dsp.gain; dsp.inv_gain = (float) dsp.rgain;
                 dsp.err_coef = dh_fir_error_coefficient(dsp.taps, L.nz, dsp.gain);
-                dsp.tapfrag = tapfrag; dsp.tapfrag_sym = tapfrag_sym; dsp.err_coef_f16 = err_coef_f16;
+                dsp.tapfrag = tapfrag; dsp.err_coef_f16 = err_coef_f16;
             }
             dsp.filt_out = L.fused_keep ? filtered : nullptr; dsp.filt_stride = L.max_samples;
             // slicer and decoder of a channel in one wavefront where the backend has that kernel (sps 10, wide or

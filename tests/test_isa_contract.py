@@ -143,18 +143,11 @@ def test_exact_kernels_keep_their_two_firs_apart_and_the_hot_one_in_registers(ke
         ref_fir = max(blocks, key=lambda b: sum(i.startswith("v_pk_mul_f32") for i in b))
         assert sum(i.startswith("v_pk_mul_f32") for i in ref_fir) >= 600 and sum(i.startswith("v_pk_add_f32") for i in ref_fir) >= 600     # 81 (161) taps x 8 pairs
         assert not [i for i in ref_fir if i.startswith(("v_pk_fma_f32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32", "v_mfma"))], name + " fuses inside the reference FIR"
-        n_mfma = lambda b: sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in b)
-        hot = max(blocks, key=n_mfma)
-        # narrow: 4 tiles x 6 K-steps x 3 products.  Wide (round 6): the symbol-major product of a 100-symbol run -- 7 tiles of 16 symbols x
-        # 3 K-steps x 3 products = 63 -- is the hot block; the block-major product (4 tiles x 3 x 3 = 36) serves the runs at the ends of a push
-        assert n_mfma(hot) == (72 if narrow else 63) and hot is not ref_fir
+        hot = max(blocks, key=lambda b: sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in b))
+        assert sum(i.startswith("v_mfma_f32_16x16x32_f16") for i in hot) == (72 if narrow else 36) and hot is not ref_fir      # 4 tiles x 3 K-steps x 3 products (6 K-steps narrow)
         assert sum(i.startswith(("v_pk_fma_f32", "v_pk_mul_f32")) for i in hot) <= 40, name + ": f32 FIR arithmetic beside the MFMAs"
         assert not [i for b in blocks for i in b if i.startswith("v_mfma_f32_16x16x4_f32")]
         hot_spills = [i for i in hot if "scratch_" in i]
-        if not narrow:
-            general = [b for b in blocks if n_mfma(b) == 36]
-            assert len(general) == 1 and not [i for i in general[0] if "scratch_" in i], name + ": the block-major product spills"
-            assert sum(i.startswith("ds_read_b128") for i in hot) == 42 and sum(i.startswith("ds_write_b32") for i in hot) >= 36     # window fragments; ring / volume / sum stores
         runtime_sps = "ELi3ELi0E" in name                    # the narrow filter at a run-time sps (no pipe of the reference uses it): a few 16-byte spill pairs tolerated
         assert len(hot_spills) <= (8 if runtime_sps else 0), name + " spills inside the hot FIR"
         spills = [i for b in blocks for i in b if "scratch_" in i]
