@@ -79,7 +79,7 @@ struct DhDspParams {
     uint32_t split_n0, split_n1, split_pad, part_epoch;
     // split_fixup = 1: the launch BEHIND a split launch, one workgroup per channel -- a channel whose later parts did not get
     // their hand-over (flag never came, or came from another XCD) is finished here, unsplit, from where its last completed part
-    // stopped; every other workgroup leaves at once.  split_force_fail = k > 0 (tests: DH_TAIL_SPLIT_FORCE_FAIL): the later parts
+    // stopped; every other workgroup leaves at once.  split_force_fail = k > 0 (tests: DH_TAIL_SPLIT_FORCE_FAIL): the SECOND parts
     // of the channels with ch % k == 1 give up without looking.
     uint32_t split_fixup, split_force_fail;
     // DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH on the wide filter at sps 10 (without DH_FLAG_FAST_FIR): the error-bounded slicer also delivers
@@ -163,16 +163,15 @@ DH_HD DhDspShared dh_dsp_carve(void* base, uint32_t sps, uint32_t nz = 0) {     
     return S;
 }
 
-// Diagnostic build (-DDH_PHASE_CLOCKS, tools/build_variant.sh): per-phase shader-clock totals of each channel's
-// wavefront, accumulated in LDS and added to header words 6.. of the channel state (units of 64 cycles);
-// read them with dh_engine_debug_header().  Not compiled into the product library.
+// Phase markers: with -DDH_ASM_MARKERS (tools/asm_census.py) every phase boundary of the slicer leaves a comment in the assembly; nothing otherwise.
+// (Round 2-4's per-phase shader-clock builds used the same places; they went with round 5's prune.)
 #if defined(DH_ASM_MARKERS) && DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
 // (static census of the phases in the assembly: tools/asm_census.py counts the instructions between these comments)
-#define DH_CLK_BEGIN() asm volatile("; DH_PHASE begin" ::: "memory")
-#define DH_CLK(i) asm volatile("; DH_PHASE " #i ::: "memory")
+#define DH_PHASE_MARK_BEGIN() asm volatile("; DH_PHASE begin" ::: "memory")
+#define DH_PHASE_MARK(i) asm volatile("; DH_PHASE " #i ::: "memory")
 #else
-#define DH_CLK_BEGIN() ((void) 0)
-#define DH_CLK(i) ((void) 0)
+#define DH_PHASE_MARK_BEGIN() ((void) 0)
+#define DH_PHASE_MARK(i) ((void) 0)
 #endif
 
 // (Wave priorities -- s_setprio around the FIR and in the decoder half -- were worth 2 % in round 2 and nothing since the FIR moved to
@@ -1378,7 +1377,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     // raw-sample window layout: padded one word per 16 for the FIR's lane-strided reads; plain without an RRC stage
     // (the samples are then used where they were staged, and the window sums sit right behind them)
 #define DH_XP(e) (NZ > 0 ? DH_XPAD(e) : (e))
-    DH_CLK_BEGIN();
+    DH_PHASE_MARK_BEGIN();
     // ---- load carried state
     uint32_t k0 = sth[DH_ST_K];
     int32_t off = (int32_t) sth[DH_ST_OFF];
@@ -1515,7 +1514,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
     const int32_t fast_p_end = (nf >= 1003u && nf < 0x40000000u) ? (int32_t) (nf - 1003u) : -1;
     const int32_t fast_sym_end = (P.sym_cap >= (uint32_t) DH_VARIANCE_SYMBOLS && P.sym_cap < 0x40000000u) ? (int32_t) (P.sym_cap - DH_VARIANCE_SYMBOLS) : -1;
 
-    DH_CLK(7);
+    DH_PHASE_MARK(7);
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
     // split-f16 FIR: this lane's six tap fragments -- 16-byte loads, 1 KiB per instruction, the same 6 KiB for every wavefront
     // of the chip (L1 / L2 hits).  Requested one iteration ahead (here, and again at the end of every iteration, when the
@@ -1714,7 +1713,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             else if (xmax >= DH_BOUND_XMAX_LO && xmax <= DH_BOUND_XMAX_HI) e_run = P.err_coef * xmax;
             else use_exact = true;                      // tiny, huge or infinite samples: outside the bound's assumptions
         }
-        DH_CLK(0);
+        DH_PHASE_MARK(0);
 
         // ---- P2: FIR into registers, then (after every lane has read its window) back into the window block.
         // The filtered samples go back UNPADDED (element n at word n, four 16-byte stores per lane): the symbol
@@ -1832,7 +1831,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             DH_BARRIER();
         }
         DH_TAPFRAG_SETTLE();
-        DH_CLK(1);
+        DH_PHASE_MARK(1);
         const float* fbuf = S.xf;
 #define DH_FB(n) fbuf[n]
 
@@ -2066,7 +2065,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
         DH_BARRIER();
-        DH_CLK(2);
+        DH_PHASE_MARK(2);
 
         issue_next_window();
 
@@ -2078,7 +2077,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
 #endif
         DH_BARRIER();
-        DH_CLK(3);
+        DH_PHASE_MARK(3);
 
         // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
         // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
@@ -2156,7 +2155,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
 
-        DH_CLK(4);
+        DH_PHASE_MARK(4);
         // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
         // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
         // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
@@ -2567,7 +2566,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             }
         }
 
-        DH_CLK(5);
+        DH_PHASE_MARK(5);
         // ---- P7: commit the run (wave-uniform bookkeeping) and fold new volumes into the ring
         DH_FOR_LANES_FRESH(lane) {
             // a run has at most 100 symbols: two predicated copies per lane, both loads in flight together (as a loop this was
@@ -2615,7 +2614,7 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
             if (block_done) { BS->prev_start = BS->cur_start; BS->prev_off = BS->cur_off; BS->blk_flags = (BS->blk_flags & 1u) ? 2u : 0u; }
         }
         DH_TAPFRAG_LOAD();                              // for the next run
-        DH_CLK(6);
+        DH_PHASE_MARK(6);
     }
 
 #if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)

@@ -11,6 +11,7 @@
 // reference's x86-64 SSE2 build does; the FAST FIR asks for fmaf explicitly).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -99,12 +100,12 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
         if (part) sym_base = dh_uniform(__hip_atomic_load(P.sym_count + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     } else if (part) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;      // HW_REG_XCC_ID
-        bool ok = false;
-        const bool forced = P.split_force_fail && ch % P.split_force_fail == 1u;     // (tests: this hand-over "fails")
+        bool ok = false, told = false;
+        const bool forced = P.split_force_fail && part == 1u && ch % P.split_force_fail == 1u;     // (tests: this hand-over "fails"; a third part then has to notice)
         for (uint32_t spin = 0; spin < (1u << 16) && !forced; spin++) {                 // (a first part takes ~1.5 ms; 2^16 x ~2 us)
             const uint32_t v = dh_uniform(__hip_atomic_load(part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if ((v & 0x00FFFFFFu) == P.part_epoch) {
-                if (v & (1u << 26)) break;                                               // the part in front of this one gave up
+                if (v & (1u << 26)) { told = true; break; }                              // the part in front of this one gave up
                 if (((v >> 24) & 3u) >= part) { ok = (v >> 28) == xcc; break; }
             }
             __builtin_amdgcn_s_sleep(64);
@@ -115,8 +116,16 @@ __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_c
             // No hand-over (never seen on an MI355X in SPX mode, where the probe of HipBackend::open holds): nothing of this
             // channel has been touched by this workgroup, the fix-up launch behind this one finishes the row.
             if (threadIdx.x == 0) {
-                __hip_atomic_fetch_or(part_flag, 1u << 26, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // "gave up" is published as a word of THIS push: when the part in front has not published yet the word still carries an older
+                // epoch, and a bit set on that would be dropped by that part's compare-and-swap below (it only keeps the bit of a word of its
+                // own push) -- the part behind this one would then spin through its whole patience instead of leaving at once
+                uint32_t seen = __hip_atomic_load(part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    const uint32_t want = ((seen & 0x00FFFFFFu) == P.part_epoch ? seen : P.part_epoch) | (1u << 26);
+                    if (__hip_atomic_compare_exchange_strong(part_flag, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                }
                 if (P.overflow) __hip_atomic_fetch_add(P.overflow + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a statistic: dh_engine_debug_header(202))
+                if (P.overflow && told) __hip_atomic_fetch_add(P.overflow + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... of which: told so by the part in front (203)
             }
             return;
         }
@@ -522,7 +531,12 @@ struct HipBackend {
         if (hip_fail(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) return DH_ENODEV;
         if (dev < 0 || dev >= count) return DH_EINVAL;
         device = dev; stream = (hipStream_t) s;
-        if (!lds_unaligned_probe()) { g_last_error = "the device does not return unaligned 8 / 16-byte LDS reads whole (LDS alignment mode): the slicer kernels need it"; return DH_EDEVICE; }
+        // (the first open on a device runs a one-wavefront probe kernel on a stream of its own and waits for it: it synchronises with the
+        // host once, and must not happen inside a global-mode stream capture; later opens take the cached verdict)
+        const char* why = nullptr;
+        const int lds = lds_unaligned_probe(&why);
+        if (lds < 0) { g_last_error = "the device does not return unaligned 8 / 16-byte LDS reads whole (LDS alignment mode): the slicer kernels need it"; return DH_EDEVICE; }
+        if (lds == 0) { g_last_error = why ? why : "the LDS alignment probe could not run"; return DH_EDEVICE; }
         if (!tail_split_probe()) tail_split_pct = 0;              // workgroup i does not run on XCD i mod 8 here (another part, a partitioned one): one workgroup per channel
         if (const char* e = std::getenv("DH_TAIL_SPLIT_FORCE_FAIL")) tail_split_force_fail = (uint32_t) std::strtoul(e, nullptr, 10);     // tests: see DhDspParams
         if (const char* e = std::getenv("DH_TAIL_SPLIT")) {       // "80" or "75,93" (percent of a push where the second / third workgroup of a channel starts), "0" = off
@@ -592,28 +606,39 @@ struct HipBackend {
         verdict[device] = ok ? 1 : -1;
         return ok;
     }
-    // see k_lds_unaligned_probe; a probe that could not run (allocation / launch failure) is an error of its own, reported by the caller's next HIP call
-    bool lds_unaligned_probe() {
+    // see k_lds_unaligned_probe.  1 = unaligned reads come back whole, -1 = they do not (measured), 0 = the probe could not run (`why` says
+    // which HIP call failed: an out-of-memory or a launch failure is not an alignment finding, and is not cached)
+    int lds_unaligned_probe(const char** why) {
         static std::mutex m; static int verdict[64] = { 0 };         // 0 unknown, 1 holds, -1 does not
-        if (device < 0 || device >= 64) return false;
+        if (device < 0 || device >= 64) { *why = "the LDS alignment probe keeps verdicts for device indices below 64"; return 0; }
         std::lock_guard<std::mutex> lock(m);
-        if (std::getenv("DH_LDS_PROBE_FORCE_FAIL")) return false;     // tests: what an engine on a device without unaligned LDS reads is told
-        if (verdict[device]) return verdict[device] > 0;
+        if (std::getenv("DH_LDS_PROBE_FORCE_FAIL")) return -1;        // tests: what an engine on a device without unaligned LDS reads is told
+        if (verdict[device]) return verdict[device];
         Scope on_device(device);
         uint32_t* d = nullptr; uint32_t h = 0;
         hipStream_t probe = nullptr;
-        if (hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return false; }
-        if (hipMalloc((void**) &d, sizeof(uint32_t)) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamDestroy(probe); return false; }
-        bool ran = hipMemsetAsync(d, 0, sizeof(uint32_t), probe) == hipSuccess;
-        if (ran) {
+        static thread_local char msg[160];
+        auto failed = [&](hipError_t e, const char* call) {
+            if (e == hipSuccess) return false;
+            std::snprintf(msg, sizeof(msg), "the LDS alignment probe could not run: %s: %s", call, hipGetErrorString(e));
+            (void) hipGetLastError();
+            *why = msg;
+            return true;
+        };
+        if (failed(hipStreamCreateWithFlags(&probe, hipStreamNonBlocking), "hipStreamCreateWithFlags")) return 0;
+        bool bad = failed(hipMalloc((void**) &d, sizeof(uint32_t)), "hipMalloc");
+        if (!bad) bad = failed(hipMemsetAsync(d, 0, sizeof(uint32_t), probe), "hipMemsetAsync");
+        if (!bad) {
             hipLaunchKernelGGL(k_lds_unaligned_probe, dim3(1), dim3(DH_WAVE), 0, probe, d);
-            ran = hipGetLastError() == hipSuccess && hipStreamSynchronize(probe) == hipSuccess && hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+            bad = failed(hipGetLastError(), "launch of k_lds_unaligned_probe") || failed(hipStreamSynchronize(probe), "hipStreamSynchronize") ||
+                  failed(hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy");
         }
-        (void) hipFree(d);
+        if (d) (void) hipFree(d);
         (void) hipStreamDestroy(probe);
-        if (!ran || h == 0u) { (void) hipGetLastError(); return false; }
+        if (bad) return 0;
+        if (h == 0u) { *why = "the LDS alignment probe could not run: the probe kernel left no result"; return 0; }
         verdict[device] = h == 1u ? 1 : -1;
-        return h == 1u;
+        return verdict[device];
     }
     hipStream_t side = nullptr, side_lo = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_lo = nullptr;
@@ -776,7 +801,7 @@ struct HipBackend {
         }
         if constexpr (MAY_SPLIT) {
             // Tail split (see k_chain): a launch of one workgroup per channel ends with a drain of about one workgroup's
-            // duration during which the chip runs half empty (tools/wave_timeline.py: 0.65 ms of a 6.2 ms step).  With the
+            // duration during which the chip runs half empty (start / end stamps of every wavefront, profiles/r03_d_*: 0.65 ms of a 6.2 ms step).  With the
             // last quarter of every row handed to a second workgroup of the same launch the drain consists of workgroups a
             // third as long.  Only for launches that fill the chip several times over and pushes long enough to be worth
             // two prologues.

@@ -3,6 +3,8 @@
 Each test runs twice: on the CPU wave emulation of the kernel bodies (CPU tier) and, with -m gpu,
 through libdigiham_amd.so on the MI355X.  Bit-exact is the bar.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -141,6 +143,54 @@ def test_trellis_single_dibit_repair_vs_reference(ctx, oracle):
                     w[pos // 4] ^= int(rng.integers(1, 4)) << (6 - 2 * (pos % 4))
                     w[(pos + gap) // 4] ^= int(rng.integers(1, 4)) << (6 - 2 * ((pos + gap) % 4))
                     words.append(w)
+    x = np.stack(words)
+    o1, m1 = ctx.trellis(x, nd)
+    o2, m2 = oracle.trellis(x, nd, which)
+    assert (m1 == m2).all()
+    assert (o1 == o2).all()
+
+
+def test_trellis_repair_window_is_inside_the_proven_margin():
+    """DH_YSF_REPAIR_LO / _HI (decoder_core.hpp) against the margin tools/trellis_margin.py derives from the code itself (free distance, the
+    weights a difference path must have to stay active from the block's start / to its end): an edit of the bounds that leaves the proven
+    range fails here, not in some rare frame."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("trellis_margin", os.path.join(root, "tools", "trellis_margin.py"))
+    tm = importlib.util.module_from_spec(spec); spec.loader.exec_module(tm)
+    assert tm.d_free() == 7                                       # a single wrong dibit (weight <= 2) is closer to its codeword than to any detour: 2 * 2 + 1 = 5 <= 7
+    # a path from another start state must weigh >= 5 while it is still unmerged at step p: f_start(p + 1); a divergence at or before p that
+    # is still open at the end of the 100 steps: f_end(100 - p).  Both grow with the distance from the block's end they guard.
+    lo_min = next(p for p in range(100) if all(tm.f_start(q + 1) >= 5 for q in range(p, min(p + 24, 100))))
+    hi_max = next(p for p in range(99, -1, -1) if all(tm.f_end(100 - q) >= 5 for q in range(max(p - 24, 0), p + 1)))
+    src = open(os.path.join(root, "digiham_amd", "csrc", "decoder_core.hpp")).read()
+    lo = int(re.search(r"#define DH_YSF_REPAIR_LO (\d+)", src).group(1)); hi = int(re.search(r"#define DH_YSF_REPAIR_HI (\d+)", src).group(1))
+    assert (lo_min, hi_max) == (14, 91)                           # (what the comment above dh_ysf_clean100 quotes)
+    assert lo_min <= lo <= hi <= hi_max, (lo_min, lo, hi, hi_max)
+
+
+def test_trellis_error_clusters_at_the_edges_of_the_repair_window_vs_reference(ctx, oracle):
+    """Two and three wrong dibits close together around the ends of the repair window (positions 12..20 and 84..96): whatever the lane-local
+    shortcut makes of them -- clean, one repairable dibit, or hand over to the Viterbi decoder -- outputs and metrics are the reference's
+    (its tie rules included: equal metrics keep predecessor 0 and the lowest end state, trellis.c:68-99)."""
+    which = "ref" if oracle.ref() is not None else "oracle"
+    rng = np.random.default_rng(2024)
+    nd = 100
+    words = []
+    for _ in range(40):
+        base = _encode_from_state(rng.integers(0, 2, nd), int(rng.integers(0, 16)))
+        for lo, hi in ((12, 20), (84, 96)):
+            for _ in range(60):
+                w = base.copy()
+                k = int(rng.integers(2, 4))
+                first = int(rng.integers(lo, hi + 1))
+                pos = {first}
+                while len(pos) < k:
+                    pos.add(int(np.clip(first + rng.integers(-6, 7), 0, nd - 1)))
+                for q in pos:
+                    w[q // 4] ^= int(rng.integers(1, 4)) << (6 - 2 * (q % 4))
+                words.append(w)
     x = np.stack(words)
     o1, m1 = ctx.trellis(x, nd)
     o2, m2 = oracle.trellis(x, nd, which)

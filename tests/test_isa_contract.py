@@ -154,4 +154,5 @@ def test_exact_kernels_keep_their_two_firs_apart_and_the_hot_one_in_registers(ke
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
         # (static counts: with the branch weights of the hot loop the allocator puts its spill code into the rare paths --
         # the reference-order FIR, the exact evaluations, the ordered timing chain -- where there is more of it than before)
-        assert len(spills) <= (144 if narrow else 128) and vgprs <= (168 if narrow else 128), (name, len(spills), vgprs)      # (static count over the whole kernel text, decoder half included: round 5's YSF decode-ahead has 114; what matters is hot_spills above and tools/asm_census.py)
+        ysf = "ELi2ELi10E" in name                           # (template arguments NZ, FAST, PROTO, SPS: protocol 2 = YSF)
+        assert len(spills) <= (144 if narrow else 128 if ysf else 112) and vgprs <= (168 if narrow else 128), (name, len(spills), vgprs)      # (static count over the whole kernel text, decoder half included: round 5's YSF decode-ahead has 114; what matters is hot_spills above and tools/asm_census.py)

@@ -105,6 +105,11 @@ def test_split_launch_equals_whole_launch_and_oracle(gpu_ctx, oracle, monkeypatc
         _collect(eng, B, acc)
         gave_up = int(eng.debug_header(202)[0])                 # hand-overs that did not come (finished by the fix-up launch)
         assert (gave_up > 0) == pct.endswith(":fail"), (pct, gave_up)
+        if pct == "70,92:fail":
+            # three parts: the forced failure is the SECOND part's; the third must leave because it is told so (the give-up bit in a word
+            # of this push), not because its patience (2^16 naps, ~130 ms per channel) ran out -- every one of them
+            told = int(eng.debug_header(203)[0])
+            assert told > 0 and 2 * told == gave_up, (told, gave_up)
         eng.close()
         results[pct] = [[hashlib.sha256(np.concatenate(acc[k][b]).tobytes()).hexdigest() for b in range(B)] for k in range(3)]
         if pct == "0":
