@@ -1358,11 +1358,14 @@ DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t ne
 // LV = 4 / 2: the number of levels is known where the kernel is instantiated (the chain kernels: 4 for DMR / YSF / NXDN, 2 for
 // D-Star; engine.hip checks P.levels against it) and the other slicer's selects, its invert mask and two scalar register
 // pairs drop out of the slicing phase; 0 = taken from P.levels.
-template <int NZ, bool FAST, int SPS, int LV = 0, bool KEEPF = false>
+// KEEPF (DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH): the run's filtered samples also leave, from where they stand in LDS -- 1: those of the
+// split-f16 product (2.5e-6 of the reference's); 2 (with DH_FLAG_FAST_FIR): the error-bounded kernel filters with the f32 FMA chain instead
+// (v_mfma_f32_16x16x4_f32: the arithmetic of DH_FLAG_FAST_FIR, 1e-6 -- BASELINE configs[1] in ONE launch, dibits still the reference's).
+template <int NZ, bool FAST, int SPS, int LV = 0, int KEEPF = 0>
 DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& S, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu, uint32_t sym_base = 0) {
     static_assert(SPS == 0 || SPS == 10 || SPS == 20 || SPS == 40, "0 = run-time samples per symbol; 10 has its own window and timing code, 20 / 40 are the generic code with the constant folded in");
     constexpr bool BOUNDED = DhIsBounded<NZ, FAST, SPS>::value;                      // see "Error-bounded FIR" above
-    constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160);                         // its fused FIR as a split-f16 product on the matrix cores
+    constexpr bool MF16 = DH_FIR_F16 && BOUNDED && (NZ == 80 || NZ == 160) && KEEPF != 2;           // its fused FIR as a split-f16 product on the matrix cores
     DhBoundState* const BS = DH_BOUND_STATE(S);
     float* st = P.state + (size_t) ch * P.state_stride;
     uint32_t* sth = (uint32_t*) st;

@@ -47,7 +47,7 @@ int hip_fail(hipError_t e, const char* what) {
 // ---------------------------------------------------------------------------------- kernels
 // second launch-bounds argument = minimum waves per SIMD: caps the VGPR budget at 128 (wide) / 256 (narrow)
 // KEEPF: the launch also delivers the filtered samples (DhDspParams::filt_out; BASELINE configs[1] in one kernel)
-template <int NZ, bool FAST, int SPS, bool KEEPF = false>
+template <int NZ, bool FAST, int SPS, int KEEPF = 0>
 __global__ __launch_bounds__(DH_WAVE, (NZ > 80 ? DH_LB_NARROW : DH_LB)) void k_rrc_demod(const DhDspParams P) {
     extern __shared__ __attribute__((aligned(16))) char dh_smem[];
     DhDspShared S = dh_dsp_carve(dh_smem, SPS ? (uint32_t) SPS : P.sps, NZ);
@@ -749,7 +749,7 @@ struct HipBackend {
         return DH_OK;
     }
 
-    template <int NZ, bool FAST, int SPS, bool KEEPF = false> int go_rrc_demod(const DhDspParams& P) {
+    template <int NZ, bool FAST, int SPS, int KEEPF = 0> int go_rrc_demod(const DhDspParams& P) {
         const size_t lds = dh_dsp_shared_bytes(P.sps, NZ);
         if (lds > 48 * 1024) {
             if (hip_fail(hipFuncSetAttribute((const void*) k_rrc_demod<NZ, FAST, SPS, KEEPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds),
@@ -759,7 +759,8 @@ struct HipBackend {
         return launched("k_rrc_demod");
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
-        if (P.filt_out) return (P.sps == 10 && nz == 80 && !fast) ? go_rrc_demod<80, false, 10, true>(P) : -1;      // (engine_impl.hpp: only this pipe asks for it)
+        // (engine_impl.hpp: only this pipe asks for it; `fast` here = the floats of the f32 FMA chain, dsp_core.hpp KEEPF = 2)
+        if (P.filt_out) return (P.sps == 10 && nz == 80) ? (fast ? go_rrc_demod<80, false, 10, 2>(P) : go_rrc_demod<80, false, 10, 1>(P)) : -1;
         if (P.sps == 10) {                      // DMR / YSF: specialised symbol loops
             if (nz == 0) return go_rrc_demod<0, false, 10>(P);
             if (nz == 80) return fast ? go_rrc_demod<80, true, 10>(P) : go_rrc_demod<80, false, 10>(P);

@@ -33,7 +33,7 @@ struct Layout {
     uint32_t sym_cap, out_cap, ev_cap;
     size_t sym_stride, state_words;
     bool fused;          // RRC folded into the slicer kernel (no filtered signal in HBM)
-    bool fused_keep;     // ... which also delivers the filtered samples (DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH, wide filter, sps 10): one launch
+    int fused_keep;      // ... which also delivers the filtered samples (DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH, wide filter, sps 10): one launch; 2 = with DH_FLAG_FAST_FIR
 };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -59,10 +59,11 @@ inline int make_layout(const dh_engine_config& c, Layout& L) {
     // DH_FLAG_ONE_LAUNCH: the error-bounded slicer kernel filters on the matrix cores, decides every dibit as the reference does and
     // stores the filtered samples it holds in LDS -- one kernel instead of RRC tiles + slicer (8.1 instead of 12.1 bytes per sample
     // through HBM).  Its floats are the split-f16 FIR's: 1.1e-6 of max(|ref|, rms) measured, outside the 1e-6 of BASELINE configs[1].
-    // (DH_FLAG_FAST_FIR asks for floats within 1e-6: it takes precedence over DH_FLAG_ONE_LAUNCH, whose floats are only within 2.5e-6 -- the two-kernel
-    // FMA pair then runs, as without DH_FLAG_ONE_LAUNCH)
-    L.fused_keep = (L.flags & DH_FLAG_KEEP_FILTERED) && (L.flags & DH_FLAG_ONE_LAUNCH) && !(L.flags & DH_FLAG_FAST_FIR) && L.rrc == DH_RRC_WIDE && L.demod != DH_DEMOD_NONE && L.sps == 10
-                   && !(L.flags & DH_FLAG_EXACT_FIR);
+    // With DH_FLAG_FAST_FIR (floats within 1e-6 asked for) the same kernel filters with the f32 FMA chain on the matrix cores instead
+    // (v_mfma_f32_16x16x4_f32, the arithmetic of the two-kernel FMA pair: 5e-7 measured) and still decides every dibit as the reference does:
+    // BASELINE configs[1] in one launch (round 6; before, the flag fell back to the two-kernel pair).
+    L.fused_keep = ((L.flags & DH_FLAG_KEEP_FILTERED) && (L.flags & DH_FLAG_ONE_LAUNCH) && L.rrc == DH_RRC_WIDE && L.demod != DH_DEMOD_NONE && L.sps == 10
+                    && !(L.flags & DH_FLAG_EXACT_FIR)) ? ((L.flags & DH_FLAG_FAST_FIR) ? 2 : 1) : 0;
     L.fused = L.rrc != DH_RRC_NONE && L.rrc != DH_RRC_CUSTOM && L.demod != DH_DEMOD_NONE && (!(L.flags & DH_FLAG_KEEP_FILTERED) || L.fused_keep);
     // a symbol consumes at least sps-1 samples
     L.sym_cap = L.demod ? (L.max_samples + dh_tail_max(L.sps)) / (L.sps - 1) + 4 : L.max_samples;
@@ -260,7 +261,7 @@ struct Engine {
         last_n = (uint32_t) n;
         int rc = 0;
         const float* demod_in = d_in; size_t demod_stride = stride;
-        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;                        // (never together with fused_keep: layout_for)
+        const bool fast = (L.flags & DH_FLAG_FAST_FIR) != 0;                        // (with fused_keep: which floats the one launch delivers)
         bool decoder_done = false;
         be.timing_mark(0);
         if (L.rrc == DH_RRC_CUSTOM) {
@@ -286,7 +287,7 @@ struct Engine {
             dsp.sym_count = sym_count; dsp.sym_cap = L.sym_cap; dsp.overflow = overflow; dsp.n_channels = L.B;
             dsp.sps = L.sps; dsp.lo = L.lo; dsp.hi = L.hi;
             dsp.levels = L.demod; dsp.invert = (L.flags & DH_FLAG_FSK_INVERT) ? 1 : 0;
-            dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast;
+            dsp.nz = L.fused ? L.nz : 0; dsp.fast = fast && !L.fused_keep;       // (fused_keep = 2 is an error-bounded kernel: exact dibits)
             dsp.ordered_timing = (L.flags & DH_FLAG_ORDERED_TIMING) ? 1 : 0;
             dsp.exact_mode = (L.flags & DH_FLAG_EXACT_FIR) ? 2 : (L.flags & DH_FLAG_EXACT_SYMBOLS) ? 1 : 0;
             if (L.fused) {

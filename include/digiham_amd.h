@@ -112,9 +112,11 @@ enum { DH_PROTO_NONE = 0, DH_PROTO_DMR = 1, DH_PROTO_YSF = 2, DH_PROTO_NXDN = 3,
 #define DH_FLAG_ONE_LAUNCH      0x200 /* with DH_FLAG_KEEP_FILTERED on the wide filter at 10 samples per symbol: `rrc_filter | gfsk_demodulator` as ONE kernel per push -- the
                                          error-bounded slicer kernel (dibits bit-exact, as without the flag) also stores the filtered samples it holds in LDS.  They come from
                                          its split-f16 matrix-core FIR: within 2.5e-6 of the reference's floats relative to max(|ref|, rms(ref)) (measured 1.0e-6), which is
-                                         NOT the 1e-6 of DH_FLAG_FAST_FIR and not bit-exact; with DH_FLAG_FAST_FIR set as well, that flag's contract wins and the push runs
-                                         as two kernels (FMA FIR + slicer), as without this flag.  (The reference's own 81-term float chain is 8e-7 away from the exact
-                                         convolution and this FIR 1.3e-7: most of the distance is the reference's rounding, which only its own order of operations reproduces.) */
+                                         NOT the 1e-6 of DH_FLAG_FAST_FIR and not bit-exact.  With DH_FLAG_FAST_FIR set as well the one kernel filters with the f32 FMA chain
+                                         instead (on the matrix cores, v_mfma_f32_16x16x4_f32: the floats of DH_FLAG_FAST_FIR, within 1e-6, measured 5e-7) and -- unlike
+                                         DH_FLAG_FAST_FIR alone -- still delivers the reference's dibits bit for bit (error radius + exact re-evaluation of what it leaves in
+                                         doubt): BASELINE configs[1] in one launch.  (The reference's own 81-term float chain is 8e-7 away from the exact
+                                         convolution and the split-f16 FIR 1.3e-7: most of the distance is the reference's rounding, which only its own order of operations reproduces.) */
 #define DH_FLAG_OVERLAP_PUSHES  0x100 /* engines of >= 8192 channels on the one-launch chains (DMR, YSF, NXDN, D-Star): a push goes out as two launches on two streams of the engine's
                                          own (three quarters of the channels at high priority, the rest at normal priority) which are ordered
                                          after the caller's stream at the moment of the push and joined with it again only when results are

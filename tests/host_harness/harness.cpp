@@ -49,13 +49,13 @@ struct HostBackend {
     int timing_read_split(float*, uint32_t*, uint32_t* n) { *n = 0; return 0; }
     bool overlap_pushes = false;                     // (a property of the GPU dispatcher; nothing to emulate)
 
-    template <int NZ, bool FAST, int SPS, bool KEEPF = false> static void run_rrc_demod(const DhDspParams& P) {
+    template <int NZ, bool FAST, int SPS, int KEEPF = 0> static void run_rrc_demod(const DhDspParams& P) {
         std::vector<float> lds(dh_dsp_shared_bytes(P.sps, NZ) / sizeof(float));     // exactly the device allocation
         DhDspShared S = dh_dsp_carve(lds.data(), P.sps, NZ);
         for (uint32_t ch = 0; ch < P.n_channels; ch++) dh_rrc_demod_channel<NZ, FAST, SPS, 0, KEEPF>(P, ch, S);
     }
     int launch_rrc_demod(const DhDspParams& P, uint32_t nz, bool fast) {
-        if (P.filt_out) { if (P.sps == 10 && nz == 80 && !fast) { run_rrc_demod<80, false, 10, true>(P); return 0; } return -1; }
+        if (P.filt_out) { if (P.sps == 10 && nz == 80) { if (fast) run_rrc_demod<80, false, 10, 2>(P); else run_rrc_demod<80, false, 10, 1>(P); return 0; } return -1; }
         if (P.sps == 10 && nz == 0) run_rrc_demod<0, false, 10>(P);
         else if (P.sps == 10 && nz == 80) { if (fast) run_rrc_demod<80, true, 10>(P); else run_rrc_demod<80, false, 10>(P); }
         else if (nz == 0 && P.sps == 40) run_rrc_demod<0, false, 40>(P);                 // the same instantiations as engine.hip

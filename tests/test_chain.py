@@ -72,6 +72,21 @@ def test_rrc_and_gfsk_in_one_launch(ctx, oracle, chunks):
         assert rel_err(res["filtered"], ref["filtered"]).max() <= 2.5e-6
 
 
+@pytest.mark.parametrize("chunks", [[10 ** 9], [3000, 17, 9000, 1, 4096]])
+def test_rrc_and_gfsk_in_one_launch_within_1e6(ctx, oracle, chunks):
+    """DH_FLAG_KEEP_FILTERED | DH_FLAG_ONE_LAUNCH | DH_FLAG_FAST_FIR: BASELINE configs[1] in ONE kernel per push.  The error-bounded slicer
+    filters with the f32 FMA chain (rrc_filter.cpp:22-34 with fused multiply-adds and the reciprocal gain: every filtered sample within
+    1e-6 of the reference's relative to max(|ref|, rms)) and still decides every dibit as the reference does (gfsk_demodulator.cpp:24-107):
+    the radius of the FMA chain + exact re-evaluation of what it leaves in doubt."""
+    x = make_channels("dmr", [7, 8, 9], 12)
+    ref = oracle.chain(x, proto=0, keep_filtered=True)
+    chunks = [min(c, x.shape[1]) for c in chunks]
+    res = run_engine(ctx, x, "none", chunks, keep_filtered=True, one_launch=True, fast_fir=True)
+    assert res["filtered"].shape == ref["filtered"].shape
+    assert rel_err(res["filtered"], ref["filtered"]).max() <= 1e-6
+    assert_matches_oracle(res, {"syms": ref["syms"], "sym_count": ref["sym_count"]}, x.shape[0], "one launch, FMA floats %s" % chunks[:2])
+
+
 def test_fast_fir_within_1e6(ctx, oracle):
     """FAST_FIR (FMA) is the float-path variant: 1e-6 relative to max(|ref|, rms(ref))."""
     x = make_channels("dmr", [7, 8], 12)
