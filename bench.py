@@ -952,6 +952,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
+        try:                                                        # RCCL's own lines ("Hostname", "Librccl path") sit in the C library's stdout buffer
+            import ctypes                                           # until exit: out with them now, so that the JSON line is the LAST line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         detail = None
         for cand in (os.environ.get("DH_BENCH_DETAIL"), os.path.join(ROOT, "bench_detail.json")):
             if not cand:

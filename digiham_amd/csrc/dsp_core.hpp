@@ -1348,6 +1348,424 @@ DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t ne
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
+// The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
+// vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
+// 100-long dependent chain on `sps` lanes.  For sps = 10 a float estimate V' with a proven error bound is
+// taken first: 50 lanes = 10 phases x 5 groups of 20 symbols, partials combined through LDS.  With
+// u = 2^-24, mu / sigma^2 the exact mean / variance of the phase, A = mean |x|, F(m) = sum (m - x)^2 / 100
+// = sigma^2 + (m - mu)^2:
+//   |mean_ref - mu| <= 100.1 u A,  |mean' - mu| <= 25.2 u A   =>  |F(mean') - F(mean_ref)| <= (100.1 u A)^2
+//   (the estimate's sums run as two interleaved chains of ten per lane -- packed adds / FMAs -- plus one add, so
+//   they are shorter than the 20-long chains these constants were derived for: 16 u A and 18 u below)
+//   A^2 <= mean x^2 = sigma^2 + mu^2 <= 1.01 (F(mean') + 2 mean'^2)   =>  that difference < 1e-10 (V' + mean'^2)
+//   V_ref = F(mean_ref)(1 + 1.2e-14);  V' = F(mean')(1 + 28 u) up to 25 subnormal roundings (< 1e-42)
+// so |V' - V_ref| <= tol = 4e-6 V' + 1.2e-10 (V' + mean'^2) + 1e-42, provided nothing overflows (max |x|
+// < 1e16 is checked).  If the intervals [V' - tol, V' + tol] separate the smallest phase from all others,
+// from 0 and from 5e6, the reference's decision is known; an all-zero phase gives vmin = 0 exactly.
+// Anything else (ties, constant input, non-finite or huge samples) is decided by the ordered chain.
+// `V`: the virtual stream of the push (for the exact recomputation of the ring); k0: the run's first slot (for the exact context only).
+// Returns the step the reference would take: +1, -1 or 0.
+struct DhStreamView { const float* tail; uint32_t tc; const float* in; uint32_t nv; float sps_rcp; };
+template <int NZ, int SPS, bool BOUNDED>
+DH_HD int32_t dh_timing_decision(const DhDspParams& P, DhDspShared& S, DhBoundState* const BS, const DhStreamView& V, uint32_t sps, uint32_t k0, float e_blk) {
+    const float* const tail = V.tail; const uint32_t tc = V.tc; const float* const in = V.in; const uint32_t nv = V.nv; const float sps_rcp = V.sps_rcp;
+    int32_t new_off = 0;
+    {
+        bool ordered = true;
+        // Phases that can still be the reference's arg-min once an estimate has been taken and could not decide: those whose
+        // interval [V' - tol, V' + tol] reaches below the smallest upper end.  Every other phase has V_ref > that upper end
+        // >= the smallest V_ref, strictly, so neither the minimum nor a tie: the ordered chain (and, in the error-bounded
+        // kernels, the exact recomputation of the ring in front of it) only has to look at these rows.  All rows when no
+        // valid set of intervals exists (no estimate, NaN / overflow, an estimate of exactly 0).
+        uint64_t chain_rows = ~0ull;
+        bool est_done = false;
+        // The same estimate without its LDS exchange and with two votes instead of six.  Lane 16 r + 5 j + g takes piece g (20
+        // symbols) of phase i = 3 r + j -- three phases per DPP row, so that the five partial sums of a phase are five neighbouring
+        // lanes of one row and meet through row_shr (lane g = 4 of each group: ((s4 + s3) + (s2 + s1)) + s0, three roundings
+        // where the exchange form has four: the tolerance derived below covers it).  The ten lanes that then hold a phase form
+        // its interval; `above` (ruled out by the smallest upper end) and `fine` (guard holds, estimate not exactly 0, and the
+        // lane is either ruled out or positive and below 5e6) are the only votes: one candidate and every lane fine is the case
+        // decided here -- everything else (an estimate of exactly 0, NaN / overflow, ties) is left to the full form below, which
+        // starts over.  ~100 instructions instead of ~260 per block.
+        if (SPS == 10 && !P.ordered_timing) {
+            DH_LANE_ARRAY(float, gs, 1); DH_LANE_ARRAY(float, gq, 1);
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
+                const uint32_t j = (c * 205u) >> 10, g = c - 5u * j, i = 3u * r + j;      // c / 5, c % 5
+                const bool act = c < 15u && i < 10u;
+                const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + (act ? i * DH_VARIANCE_SYMBOLS + g * 20u : 0u));
+                dh_f2 s2 = dh_f2_make(0.0f, 0.0f), q2 = dh_f2_make(0.0f, 0.0f);
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const dh_f4a v = row[q];
+                    const dh_f2 a = dh_f2_make(v.x, v.y), b = dh_f2_make(v.z, v.w);
+                    s2 = dh_f2_add(s2, a); s2 = dh_f2_add(s2, b);
+                    q2 = dh_f2_fma(a, a, q2); q2 = dh_f2_fma(b, b, q2);
+                }
+                DH_LA(gs, lane)[0] = act ? s2.x + s2.y : 0.0f; DH_LA(gq, lane)[0] = act ? q2.x + q2.y : 0.0f;
+            }
+            DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
+            uint64_t vote_above = 0, vote_fine = 0;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            {
+                float s = gs[0], q = gq[0], t1, t2, u1, u2;
+                // (row_shr with bound_ctrl: lanes without a source read 0 -- only lanes 4, 9, 14 of a row are looked at, and theirs exist)
+                asm volatile("s_nop 4\n\t"               // (a VALU write of EXEC just before would need 5 wait states ahead of a DPP op)
+                             "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                             "v_add_f32_dpp %2, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                             "s_nop 0\n\t"                // (a DPP read needs two wait states after the write of its source: the other stream's add + this)
+                             "v_add_f32_dpp %1, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                             "v_add_f32_dpp %3, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                             "v_add_f32_dpp %1, %4, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                             "v_add_f32_dpp %3, %5, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                             : "=&v"(t1), "=&v"(t2), "=&v"(u1), "=&v"(u2) : "v"(s), "v"(q));
+                gs[0] = t2; gq[0] = u2;
+            }
+#else
+            {
+                float ts[DH_WAVE], tq[DH_WAVE];
+                for (int l = 0; l < DH_WAVE; l++) {
+                    const int c = l & 15;
+                    auto at = [&](float (*arr)[1], int d) { return c - d >= 0 ? arr[l - d][0] : 0.0f; };
+                    ts[l] = ((at(gs, 0) + at(gs, 1)) + (at(gs, 2) + at(gs, 3))) + at(gs, 4);
+                    tq[l] = ((at(gq, 0) + at(gq, 1)) + (at(gq, 2) + at(gq, 3))) + at(gq, 4);
+                }
+                for (int l = 0; l < DH_WAVE; l++) { gs[l][0] = ts[l]; gq[l][0] = tq[l]; }
+            }
+#endif
+            DH_FOR_LANES_FRESH(lane) {
+                const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
+                const bool own = (((r == 3u ? 0x0010u : 0x4210u) >> c) & 1u) != 0u;      // this lane holds a phase: lane 4, 9 or 14 of its row (row 3: phase 9 only)
+                const float total = DH_LA(gs, lane)[0], e = DH_LA(gq, lane)[0] * 0.01f;      // e = mean x^2
+                const float mean = total * 0.01f;
+                const float v = __builtin_fmaf(-mean, mean, e);
+                float tol = __builtin_fmaf(e, 4e-6f, 1e-42f);
+                if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;      // (see the full form below)
+                const float l = own ? v - tol : DH_FLT_MAX, h = own ? v + tol : DH_FLT_MAX;
+                DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
+                DH_LA(gs, lane)[0] = own ? ((e < 1e30f && v != 0.0f && l > 0.0f && h < 4999999.0f) ? 1.0f : 0.0f) : 1.0f;      // fine as a candidate
+                DH_LA(gq, lane)[0] = own ? ((e < 1e30f && v != 0.0f) ? 1.0f : 0.0f) : 1.0f;                                      // fine when ruled out
+            }
+            float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            hmin = -dh_wave_max(-hi[0]);
+#else
+            hmin = DH_FLT_MAX;
+            for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, hi[q][0]);
+#endif
+            DH_FOR_LANES_FRESH(lane) {
+                const bool above = DH_LA(lo, lane)[0] > hmin;
+                DH_BALLOT_ACC(vote_above, above, lane);
+                DH_BALLOT_ACC(vote_fine, (above ? DH_LA(gq, lane)[0] : DH_LA(gs, lane)[0]) != 0.0f, lane);
+            }
+            const uint64_t cand = ~vote_above;
+            if (DH_LIKELY(vote_fine == ~0ull && cand != 0 && (cand & (cand - 1)) == 0)) {
+                est_done = true; ordered = false;
+                const uint32_t b = (uint32_t) dh_ffs64(cand), vmin_pos = 3u * (b >> 4) + ((b & 15u) - 4u) / 5u;
+                if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
+                else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
+            }
+        }
+        if (SPS == 10 && !P.ordered_timing && !est_done) {
+            DH_BARRIER();                                   // mn / mx are dead from here: scratch
+            float* psum = S.mn; float* pd = S.mx;
+            // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
+            // V' = Q' / 100 - mean'^2 loses more to cancellation than the reference's two passes, and its tolerance says
+            // so: with S', Q' the float sums (chains of 10 + 1 + 4 roundings: 15 u), 0.01f for 1 / 100 (0.4 u) and m2 =
+            // mean x^2 = sigma^2 + mu^2 >= A^2:
+            //   |Q' 0.01f - m2| <= 16.4 u m2,  |mean' - mu| <= 16.4 u A  =>  |mean'^2 - mu^2| <= 32.8 u m2,  the final fma 1 u m2
+            //   |V' - sigma^2| <= 50.2 u m2 = 3.0e-6 m2;  V_ref within (100.1 u A)^2 + 1.2e-14 V of sigma^2: 3.6e-11 m2
+            // so tol = 4e-6 m2' + 1e-42 (m2' = Q' 0.01f, within 1e-6 of m2; 1e-42 for up to ~120 subnormal roundings).
+            // A strong DC component (mu^2 >> sigma^2) widens the intervals; what they cannot separate goes to the ordered
+            // chain as before.
+            DH_FOR_LANES_FRESH(lane) {
+                if (lane < 50) {
+                    // lane = 5 i + g: eight consecutive lanes then read 16-byte pieces 20 or 40 words apart, which fall into
+                    // eight different groups of four banks (with lane = 10 g + i two of every eight collided: 50 LDS cycles
+                    // per block, all of this phase's bank conflicts)
+                    const uint32_t i = ((uint32_t) lane * 205u) >> 10, g = (uint32_t) lane - 5u * i;      // lane / 5, lane % 5
+                    const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
+                    const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
+                    dh_f2 s2 = dh_f2_make(0.0f, 0.0f), q2 = dh_f2_make(0.0f, 0.0f);
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        const dh_f4a v = row[q];
+                        const dh_f2 a = dh_f2_make(v.x, v.y), b = dh_f2_make(v.z, v.w);
+                        s2 = dh_f2_add(s2, a); s2 = dh_f2_add(s2, b);
+                        q2 = dh_f2_fma(a, a, q2); q2 = dh_f2_fma(b, b, q2);
+                    }
+                    psum[lane] = s2.x + s2.y; pd[lane] = q2.x + q2.y;
+                }
+            }
+            DH_BARRIER();
+            // lanes 0..9 hold one phase each; the others hold neutral values
+            DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
+            uint64_t vote_guard = 0, vote_vzero = 0, vote_zero = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
+            DH_FOR_LANES_FRESH(lane) {
+                float l = DH_FLT_MAX, h = DH_FLT_MAX;
+                bool guard = true, vzero = false;
+                if (lane < 10) {
+                    const int i = lane;
+                    const float total = (((psum[5 * i] + psum[5 * i + 1]) + psum[5 * i + 2]) + psum[5 * i + 3]) + psum[5 * i + 4];
+                    const float e = ((((pd[5 * i] + pd[5 * i + 1]) + pd[5 * i + 2]) + pd[5 * i + 3]) + pd[5 * i + 4]) * 0.01f;      // mean x^2
+                    const float mean = total * 0.01f;
+                    const float v = __builtin_fmaf(-mean, mean, e);
+                    float tol = __builtin_fmaf(e, 4e-6f, 1e-42f);
+                    // error-bounded mode: the ring holds values within e_blk of the reference's; moving every sample by
+                    // up to e_blk moves the mean by <= e_blk, every deviation by <= 2 e_blk and the variance by
+                    // <= 4 e_blk sqrt(V) + 4 e_blk^2 (Cauchy-Schwarz); taken twice over for the float mean's own rounding
+                    if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
+                    guard = e < 1e30f;                           // false for NaN, and for samples beyond ~1e15 (e overflows first)
+                    vzero = v == 0.0f;
+                    l = v - tol; h = v + tol;
+                }
+                DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
+                DH_BALLOT_ACC(vote_guard, guard, lane);
+                DH_BALLOT_ACC(vote_vzero, vzero, lane);
+                DH_BALLOT_ACC(vote_pos, l > 0.0f, lane);
+                DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
+            }
+            const uint32_t ten = 0x3FFu;
+            if (((uint32_t) vote_vzero & ten) && !(BOUNDED && e_blk > 0.0f)) {       // (approximate samples prove nothing about exact zeros)
+                // an estimate of exactly 0: only a phase whose hundred samples are all (+-)0 has vmin == 0 for sure (tiny
+                // samples square to 0 in float, not in the reference's double) -- look at the bits
+                uint64_t vote_nz = 0;
+                DH_FOR_LANES_FRESH(lane) {
+                    uint32_t any = 0;
+                    if (lane < 50) {
+                        const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;
+                        const uint32_t* row = reinterpret_cast<const uint32_t*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20u);
+#pragma unroll
+                        for (int q = 0; q < 20; q++) any |= row[q];
+                    }
+                    DH_BALLOT_ACC(vote_nz, (any << 1) != 0u, lane);
+                }
+                const uint32_t nz = (uint32_t) (vote_nz | (vote_nz >> 10) | (vote_nz >> 20) | (vote_nz >> 30) | (vote_nz >> 40));
+                vote_zero = ~nz & ten;
+            }
+            float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            hmin = dh_row_min_to_lane15(hi[0]);
+#else
+            hmin = DH_FLT_MAX;
+            for (int q = 0; q < 10; q++) hmin = dh_fmin_(hmin, hi[q][0]);
+#endif
+            DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
+            const uint32_t above = (uint32_t) vote_above & ten;
+            const uint32_t cand = ~above & ten;                 // phases whose interval reaches below hmin
+            if (((uint32_t) vote_guard & ten) != ten) {
+            } else if ((uint32_t) vote_zero & ten) {
+                ordered = false;                                // vmin == 0 exactly: no step
+            } else if (dh_popc32(cand) == 1 && ((uint32_t) vote_pos & cand) && ((uint32_t) vote_small & cand)) {
+                ordered = false;
+                const uint32_t vmin_pos = (uint32_t) dh_ffs64((uint64_t) cand);
+                if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
+                else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
+            }
+            // (the candidates are not handed on here: one more live value costs the 81-tap kernels four scratch accesses in
+            // their hot loop, and they reach this point in 0.02 % of the blocks -- the 161-tap, sps-20 kernel in 1.3 %)
+        }
+        if (ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
+            // (sps 33 .. 64, e.g. POCSAG's 40: one lane per phase, chains of 100 + 1 fused terms -- (1 + u)^102 - 1 < 6.1e-6, still
+            // inside the 8e-6 V' below; the float mean is then the reference's own chain, within 100.1 u A of the true one.  The
+            // in-order double chain cost that slicer a fifth of its time, every block.)
+            // Run-time sps with at least one lane per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
+            // per phase, lane g sps + i takes a contiguous piece of row i -- `seg` = 4 ceil(25 / G) ring entries, read 16
+            // bytes at a time -- and the partial sums meet in LDS.  The bound of the sps-10 estimate holds with 8e-6 V'
+            // for 4e-6 V' (chains of up to 52 fused terms + G partials); in the error-bounded kernels the ring holds
+            // values within e_blk of the reference's, which moves a variance by |2 cov(x, d) + var(d)| <= 2 e sigma +
+            // e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken as 2.5 e sqrt(V) + 4 e^2).  An estimate
+            // of exactly 0, a NaN or an overflow is left to the chain below.
+            DH_BARRIER();                                   // mn / mx are dead from here: scratch
+            float* psum = S.mn; float* pd = S.mx; float* pmean = S.mn + 64;
+            const uint32_t G = DH_WAVE / sps, active = G * sps, quads = (25u + G - 1u) / G;
+            for (int pass = 0; pass < 2; pass++) {
+                DH_FOR_LANES_FRESH(lane) {
+                    if ((uint32_t) lane < active) {
+                        const uint32_t g = (uint32_t) lane / sps, i = (uint32_t) lane - g * sps;
+                        const uint32_t q0 = g * quads;                                 // first 16-byte piece of this lane
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS);
+                        float mean = 0.0f;
+                        if (pass == 1) {
+                            float total = 0.0f;
+                            for (uint32_t gg = 0; gg < G; gg++) total += psum[gg * sps + i];
+                            mean = total * 0.01f;
+                            if (g == 0) pmean[i] = mean;
+                        }
+                        float acc = 0.0f;
+                        for (uint32_t q = 0; q < quads; q += 3u) {                     // three pieces in flight
+                            dh_f4a v[3];
+#pragma unroll
+                            for (uint32_t j = 0; j < 3u; j++) v[j] = row[dh_min<uint32_t>(q0 + q + j, 24u)];
+#pragma unroll
+                            for (uint32_t j = 0; j < 3u; j++) {
+                                if (q + j < quads && q0 + q + j < 25u) {
+                                    if (pass == 0) { acc += v[j].x; acc += v[j].y; acc += v[j].z; acc += v[j].w; }
+                                    else {
+                                        const float d0 = mean - v[j].x, d1 = mean - v[j].y, d2 = mean - v[j].z, d3 = mean - v[j].w;
+                                        acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
+                                        acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
+                                    }
+                                }
+                            }
+                        }
+                        if (pass == 0) psum[lane] = acc; else pd[lane] = acc;
+                    }
+                }
+                DH_BARRIER();
+            }
+            DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1);
+            uint64_t v_ok = 0, v_pos = 0, v_small = 0, v_big = 0, v_above = 0;
+            DH_FOR_LANES_FRESH(lane) {
+                float l = DH_FLT_MAX, h = DH_FLT_MAX;
+                bool ok = true;
+                if ((uint32_t) lane < sps) {
+                    float v = 0.0f;
+                    for (uint32_t gg = 0; gg < G; gg++) v += pd[gg * sps + (uint32_t) lane];
+                    v *= 0.01f;
+                    const float mean = pmean[lane];
+                    const float e = __builtin_fmaf(mean, mean, v);
+                    float tol = __builtin_fmaf(v, 8e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
+                    if (BOUNDED && e_blk > 0.0f) tol += 2.5f * e_blk * __builtin_sqrtf(v) + 4.0f * e_blk * e_blk;
+                    ok = e < 1e30f && v != 0.0f;
+                    l = v - tol; h = v + tol;
+                }
+                DH_LA(iv_lo, lane)[0] = l; DH_LA(iv_hi, lane)[0] = h;
+                DH_BALLOT_ACC(v_ok, ok, lane);
+                DH_BALLOT_ACC(v_pos, l > 0.0f, lane);
+                DH_BALLOT_ACC(v_small, h < 4999999.0f, lane);
+                DH_BALLOT_ACC(v_big, l > 5000001.0f, lane);
+            }
+            float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+            hmin = -dh_wave_max(-iv_hi[0]);
+#else
+            hmin = DH_FLT_MAX;
+            for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
+#endif
+            DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(v_above, DH_LA(iv_lo, lane)[0] > hmin, lane); }
+            const uint64_t phases = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
+            const uint64_t cand = ~v_above & phases;                          // phases whose interval reaches below the smallest upper end
+            const bool one = cand != 0 && (cand & (cand - 1)) == 0;
+            if (one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand))) {
+                ordered = false;
+                const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
+                if (v_big & cand) {
+                } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+            } else if (cand != 0 && (v_ok & phases) == phases) {
+                chain_rows = cand;
+            }
+        }
+        if (DH_UNLIKELY(ordered)) {
+            // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
+            // ring and fetched 16 bytes at a time.
+            // Error-bounded kernels: the ring holds values within e_blk of the reference's.  At sps 10 the estimate above
+            // has already failed, so the chain runs on the reference's samples -- all thousand of this block, recomputed
+            // exactly.  At a run-time sps there is no estimate: the chain first runs on the ring as it is (attempt 0) and
+            // its result stands if the intervals [V - tol, V + tol] separate the smallest phase from all others, from 0 and
+            // from 5e6; otherwise attempt 1 recomputes the ring exactly.  tol: samples moved by <= e move the variance
+            // by |2 cov(x, d) + var(d)| <= 2 e sigma + e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken
+            // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
+            // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
+            const bool approx_ring = BOUNDED && e_blk > 0.0f;
+            for (int attempt = (approx_ring && SPS != 10 && sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
+                DH_BARRIER();
+                if (approx_ring && attempt == 1) {
+                    DhExactCtx C;
+                    C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
+                    C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
+                    C.prev_start = 0; C.prev_off = 0; C.blk_flags = dh_uniform(BS->blk_flags);
+                    C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
+                    // (the window block is dead here except words 512..575, where the L2 touch of the next window may
+                    // still be dropping its dwords: the staged variant uses the words behind them)
+                    dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, chain_rows);
+                    BS->n_exact_blocks++;
+                    DH_BARRIER();
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+#endif
+                }
+                DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1); DH_LANE_ARRAY(uint32_t, iv_ok, 1);
+                DH_FOR_LANES_FRESH(lane) {
+                    if ((uint32_t) lane < sps && !((chain_rows >> (uint32_t) lane) & 1ull)) {
+                        S.variance[lane] = DH_DBL_MAX;               // ruled out by its interval: never the smallest
+                        if (BOUNDED && SPS != 10 && attempt == 0) { DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u; }
+                    } else if ((uint32_t) lane < sps) {
+                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
+                        float total = 0.0f;
+#pragma unroll 5
+                        for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                            const dh_f4a v = row[q];
+                            total += v.x; total += v.y; total += v.z; total += v.w;
+                        }
+                        const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
+                        double dsum = 0.0;
+#pragma unroll 5
+                        for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
+                            const dh_f4a v = row[q];
+                            const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
+                            const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+                            dsum += s0; dsum += s1; dsum += s2; dsum += s3;
+                        }
+                        const double var = dsum / (double) DH_VARIANCE_SYMBOLS;
+                        S.variance[lane] = var;
+                        if (BOUNDED && SPS != 10 && attempt == 0) {
+                            // this phase's interval, as floats rounded outwards (2e-7 V covers the two conversions)
+                            const double eb = (double) e_blk;
+                            const double tol = 2.5 * eb * __builtin_sqrt(var) + 4.0 * eb * eb + 2e-10 * (var + mean * mean) + 2e-7 * var + 1e-40;
+                            DH_LA(iv_lo, lane)[0] = (float) (var - tol); DH_LA(iv_hi, lane)[0] = (float) (var + tol);
+                            DH_LA(iv_ok, lane)[0] = (var + mean * mean < 1e30) ? 1u : 0u;      // false for NaN / overflow, as in the estimate
+                        }
+                    } else if (BOUNDED && SPS != 10 && attempt == 0) {
+                        DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u;
+                    }
+                }
+                DH_BARRIER();
+                if (BOUNDED && SPS != 10 && attempt == 0) {
+                    // is the reference's (arg-min, vmin <= 0, vmin > 5e6) beyond doubt?  One vote per question.
+                    float hmin;
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+                    hmin = -dh_wave_max(-iv_hi[0]);
+#else
+                    hmin = DH_FLT_MAX;
+                    for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
+#endif
+                    uint64_t v_above = 0, v_ok = 0, v_pos = 0, v_small = 0, v_big = 0;
+                    DH_FOR_LANES_FRESH(lane) {
+                        const float l = DH_LA(iv_lo, lane)[0], h = DH_LA(iv_hi, lane)[0];
+                        DH_BALLOT_ACC(v_above, l > hmin, lane);
+                        DH_BALLOT_ACC(v_ok, DH_LA(iv_ok, lane)[0] != 0u, lane);
+                        DH_BALLOT_ACC(v_pos, l > 0.0f, lane);
+                        DH_BALLOT_ACC(v_small, h < 4999999.0f, lane);
+                        DH_BALLOT_ACC(v_big, l > 5000001.0f, lane);
+                    }
+                    const uint64_t phases = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
+                    const uint64_t cand = ~v_above & phases;                  // phases whose interval reaches below the smallest upper end
+                    const bool one = cand != 0 && (cand & (cand - 1)) == 0;
+                    const bool sure = one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand));
+                    if (!sure) continue;                                      // attempt 1: the exact ring
+                    DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+                    const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
+                    if (v_big & cand) {
+                    } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                    else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+                    break;
+                }
+                double vmin = S.variance[0]; uint32_t vmin_pos = 0;
+                for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
+                DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
+                if (vmin <= 0 || vmin > 5000000) {
+                } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
+                else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
+                break;
+            }
+        }
+    }
+    return new_off;
+}
+
+// ---------------------------------------------------------------------------------------------
 // One channel, one push.  `S` is this wavefront's LDS block.  Called by all 64 lanes (device) or
 // once (host harness; the DH_FOR_LANES loops then iterate the lanes).
 // SPS = 10 bakes the DMR / YSF samples-per-symbol (and its evaluation window 3..6) into the code so the
@@ -2159,414 +2577,12 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         }
 
         DH_PHASE_MARK(4);
-        // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
-        // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
-        // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
-        // 100-long dependent chain on `sps` lanes.  For sps = 10 a float estimate V' with a proven error bound is
-        // taken first: 50 lanes = 10 phases x 5 groups of 20 symbols, partials combined through LDS.  With
-        // u = 2^-24, mu / sigma^2 the exact mean / variance of the phase, A = mean |x|, F(m) = sum (m - x)^2 / 100
-        // = sigma^2 + (m - mu)^2:
-        //   |mean_ref - mu| <= 100.1 u A,  |mean' - mu| <= 25.2 u A   =>  |F(mean') - F(mean_ref)| <= (100.1 u A)^2
-        //   (the estimate's sums run as two interleaved chains of ten per lane -- packed adds / FMAs -- plus one add, so
-        //   they are shorter than the 20-long chains these constants were derived for: 16 u A and 18 u below)
-        //   A^2 <= mean x^2 = sigma^2 + mu^2 <= 1.01 (F(mean') + 2 mean'^2)   =>  that difference < 1e-10 (V' + mean'^2)
-        //   V_ref = F(mean_ref)(1 + 1.2e-14);  V' = F(mean')(1 + 28 u) up to 25 subnormal roundings (< 1e-42)
-        // so |V' - V_ref| <= tol = 4e-6 V' + 1.2e-10 (V' + mean'^2) + 1e-42, provided nothing overflows (max |x|
-        // < 1e16 is checked).  If the intervals [V' - tol, V' + tol] separate the smallest phase from all others,
-        // from 0 and from 5e6, the reference's decision is known; an all-zero phase gives vmin = 0 exactly.
-        // Anything else (ties, constant input, non-finite or huge samples) is decided by the ordered chain.
+        // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80): dh_timing_decision
         int32_t new_off = 0;
         const bool block_done = (k0 + m == DH_VARIANCE_SYMBOLS);
         if (block_done && DH_STOP_AFTER >= 6) {
-            bool ordered = true;
-            // Phases that can still be the reference's arg-min once an estimate has been taken and could not decide: those whose
-            // interval [V' - tol, V' + tol] reaches below the smallest upper end.  Every other phase has V_ref > that upper end
-            // >= the smallest V_ref, strictly, so neither the minimum nor a tie: the ordered chain (and, in the error-bounded
-            // kernels, the exact recomputation of the ring in front of it) only has to look at these rows.  All rows when no
-            // valid set of intervals exists (no estimate, NaN / overflow, an estimate of exactly 0).
-            uint64_t chain_rows = ~0ull;
-            bool est_done = false;
-            // The same estimate without its LDS exchange and with two votes instead of six.  Lane 16 r + 5 j + g takes piece g (20
-            // symbols) of phase i = 3 r + j -- three phases per DPP row, so that the five partial sums of a phase are five neighbouring
-            // lanes of one row and meet through row_shr (lane g = 4 of each group: ((s4 + s3) + (s2 + s1)) + s0, three roundings
-            // where the exchange form has four: the tolerance derived below covers it).  The ten lanes that then hold a phase form
-            // its interval; `above` (ruled out by the smallest upper end) and `fine` (guard holds, estimate not exactly 0, and the
-            // lane is either ruled out or positive and below 5e6) are the only votes: one candidate and every lane fine is the case
-            // decided here -- everything else (an estimate of exactly 0, NaN / overflow, ties) is left to the full form below, which
-            // starts over.  ~100 instructions instead of ~260 per block.
-            if (SPS == 10 && !P.ordered_timing) {
-                DH_LANE_ARRAY(float, gs, 1); DH_LANE_ARRAY(float, gq, 1);
-                DH_FOR_LANES_FRESH(lane) {
-                    const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
-                    const uint32_t j = (c * 205u) >> 10, g = c - 5u * j, i = 3u * r + j;      // c / 5, c % 5
-                    const bool act = c < 15u && i < 10u;
-                    const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + (act ? i * DH_VARIANCE_SYMBOLS + g * 20u : 0u));
-                    dh_f2 s2 = dh_f2_make(0.0f, 0.0f), q2 = dh_f2_make(0.0f, 0.0f);
-#pragma unroll
-                    for (int q = 0; q < 5; q++) {
-                        const dh_f4a v = row[q];
-                        const dh_f2 a = dh_f2_make(v.x, v.y), b = dh_f2_make(v.z, v.w);
-                        s2 = dh_f2_add(s2, a); s2 = dh_f2_add(s2, b);
-                        q2 = dh_f2_fma(a, a, q2); q2 = dh_f2_fma(b, b, q2);
-                    }
-                    DH_LA(gs, lane)[0] = act ? s2.x + s2.y : 0.0f; DH_LA(gq, lane)[0] = act ? q2.x + q2.y : 0.0f;
-                }
-                DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
-                uint64_t vote_above = 0, vote_fine = 0;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                {
-                    float s = gs[0], q = gq[0], t1, t2, u1, u2;
-                    // (row_shr with bound_ctrl: lanes without a source read 0 -- only lanes 4, 9, 14 of a row are looked at, and theirs exist)
-                    asm volatile("s_nop 4\n\t"               // (a VALU write of EXEC just before would need 5 wait states ahead of a DPP op)
-                                 "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                 "v_add_f32_dpp %2, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                 "s_nop 0\n\t"                // (a DPP read needs two wait states after the write of its source: the other stream's add + this)
-                                 "v_add_f32_dpp %1, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                 "v_add_f32_dpp %3, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                 "v_add_f32_dpp %1, %4, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                 "v_add_f32_dpp %3, %5, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                                 : "=&v"(t1), "=&v"(t2), "=&v"(u1), "=&v"(u2) : "v"(s), "v"(q));
-                    gs[0] = t2; gq[0] = u2;
-                }
-#else
-                {
-                    float ts[DH_WAVE], tq[DH_WAVE];
-                    for (int l = 0; l < DH_WAVE; l++) {
-                        const int c = l & 15;
-                        auto at = [&](float (*arr)[1], int d) { return c - d >= 0 ? arr[l - d][0] : 0.0f; };
-                        ts[l] = ((at(gs, 0) + at(gs, 1)) + (at(gs, 2) + at(gs, 3))) + at(gs, 4);
-                        tq[l] = ((at(gq, 0) + at(gq, 1)) + (at(gq, 2) + at(gq, 3))) + at(gq, 4);
-                    }
-                    for (int l = 0; l < DH_WAVE; l++) { gs[l][0] = ts[l]; gq[l][0] = tq[l]; }
-                }
-#endif
-                DH_FOR_LANES_FRESH(lane) {
-                    const uint32_t r = (uint32_t) lane >> 4, c = (uint32_t) lane & 15u;
-                    const bool own = (((r == 3u ? 0x0010u : 0x4210u) >> c) & 1u) != 0u;      // this lane holds a phase: lane 4, 9 or 14 of its row (row 3: phase 9 only)
-                    const float total = DH_LA(gs, lane)[0], e = DH_LA(gq, lane)[0] * 0.01f;      // e = mean x^2
-                    const float mean = total * 0.01f;
-                    const float v = __builtin_fmaf(-mean, mean, e);
-                    float tol = __builtin_fmaf(e, 4e-6f, 1e-42f);
-                    if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;      // (see the full form below)
-                    const float l = own ? v - tol : DH_FLT_MAX, h = own ? v + tol : DH_FLT_MAX;
-                    DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
-                    DH_LA(gs, lane)[0] = own ? ((e < 1e30f && v != 0.0f && l > 0.0f && h < 4999999.0f) ? 1.0f : 0.0f) : 1.0f;      // fine as a candidate
-                    DH_LA(gq, lane)[0] = own ? ((e < 1e30f && v != 0.0f) ? 1.0f : 0.0f) : 1.0f;                                      // fine when ruled out
-                }
-                float hmin;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                hmin = -dh_wave_max(-hi[0]);
-#else
-                hmin = DH_FLT_MAX;
-                for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, hi[q][0]);
-#endif
-                DH_FOR_LANES_FRESH(lane) {
-                    const bool above = DH_LA(lo, lane)[0] > hmin;
-                    DH_BALLOT_ACC(vote_above, above, lane);
-                    DH_BALLOT_ACC(vote_fine, (above ? DH_LA(gq, lane)[0] : DH_LA(gs, lane)[0]) != 0.0f, lane);
-                }
-                const uint64_t cand = ~vote_above;
-                if (DH_LIKELY(vote_fine == ~0ull && cand != 0 && (cand & (cand - 1)) == 0)) {
-                    est_done = true; ordered = false;
-                    const uint32_t b = (uint32_t) dh_ffs64(cand), vmin_pos = 3u * (b >> 4) + ((b & 15u) - 4u) / 5u;
-                    if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
-                    else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
-                }
-            }
-            if (SPS == 10 && !P.ordered_timing && !est_done) {
-                DH_BARRIER();                                   // mn / mx are dead from here: scratch
-                float* psum = S.mn; float* pd = S.mx;
-                // ONE pass over the ring: sum and sum of squares together, two interleaved chains per lane (packed adds / FMAs).
-                // V' = Q' / 100 - mean'^2 loses more to cancellation than the reference's two passes, and its tolerance says
-                // so: with S', Q' the float sums (chains of 10 + 1 + 4 roundings: 15 u), 0.01f for 1 / 100 (0.4 u) and m2 =
-                // mean x^2 = sigma^2 + mu^2 >= A^2:
-                //   |Q' 0.01f - m2| <= 16.4 u m2,  |mean' - mu| <= 16.4 u A  =>  |mean'^2 - mu^2| <= 32.8 u m2,  the final fma 1 u m2
-                //   |V' - sigma^2| <= 50.2 u m2 = 3.0e-6 m2;  V_ref within (100.1 u A)^2 + 1.2e-14 V of sigma^2: 3.6e-11 m2
-                // so tol = 4e-6 m2' + 1e-42 (m2' = Q' 0.01f, within 1e-6 of m2; 1e-42 for up to ~120 subnormal roundings).
-                // A strong DC component (mu^2 >> sigma^2) widens the intervals; what they cannot separate goes to the ordered
-                // chain as before.
-                DH_FOR_LANES_FRESH(lane) {
-                    if (lane < 50) {
-                        // lane = 5 i + g: eight consecutive lanes then read 16-byte pieces 20 or 40 words apart, which fall into
-                        // eight different groups of four banks (with lane = 10 g + i two of every eight collided: 50 LDS cycles
-                        // per block, all of this phase's bank conflicts)
-                        const uint32_t i = ((uint32_t) lane * 205u) >> 10, g = (uint32_t) lane - 5u * i;      // lane / 5, lane % 5
-                        const uint32_t ro = i * DH_VARIANCE_SYMBOLS + g * 20u;
-                        const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + ro);
-                        dh_f2 s2 = dh_f2_make(0.0f, 0.0f), q2 = dh_f2_make(0.0f, 0.0f);
-#pragma unroll
-                        for (int q = 0; q < 5; q++) {
-                            const dh_f4a v = row[q];
-                            const dh_f2 a = dh_f2_make(v.x, v.y), b = dh_f2_make(v.z, v.w);
-                            s2 = dh_f2_add(s2, a); s2 = dh_f2_add(s2, b);
-                            q2 = dh_f2_fma(a, a, q2); q2 = dh_f2_fma(b, b, q2);
-                        }
-                        psum[lane] = s2.x + s2.y; pd[lane] = q2.x + q2.y;
-                    }
-                }
-                DH_BARRIER();
-                // lanes 0..9 hold one phase each; the others hold neutral values
-                DH_LANE_ARRAY(float, lo, 1); DH_LANE_ARRAY(float, hi, 1);
-                uint64_t vote_guard = 0, vote_vzero = 0, vote_zero = 0, vote_pos = 0, vote_small = 0, vote_above = 0;
-                DH_FOR_LANES_FRESH(lane) {
-                    float l = DH_FLT_MAX, h = DH_FLT_MAX;
-                    bool guard = true, vzero = false;
-                    if (lane < 10) {
-                        const int i = lane;
-                        const float total = (((psum[5 * i] + psum[5 * i + 1]) + psum[5 * i + 2]) + psum[5 * i + 3]) + psum[5 * i + 4];
-                        const float e = ((((pd[5 * i] + pd[5 * i + 1]) + pd[5 * i + 2]) + pd[5 * i + 3]) + pd[5 * i + 4]) * 0.01f;      // mean x^2
-                        const float mean = total * 0.01f;
-                        const float v = __builtin_fmaf(-mean, mean, e);
-                        float tol = __builtin_fmaf(e, 4e-6f, 1e-42f);
-                        // error-bounded mode: the ring holds values within e_blk of the reference's; moving every sample by
-                        // up to e_blk moves the mean by <= e_blk, every deviation by <= 2 e_blk and the variance by
-                        // <= 4 e_blk sqrt(V) + 4 e_blk^2 (Cauchy-Schwarz); taken twice over for the float mean's own rounding
-                        if (BOUNDED && e_blk > 0.0f) tol += 8.0f * e_blk * dh_sqrt_upper(__builtin_fmaxf(v, 0.0f) + 4.0f * e_blk * e_blk) + 8.0f * e_blk * e_blk;
-                        guard = e < 1e30f;                           // false for NaN, and for samples beyond ~1e15 (e overflows first)
-                        vzero = v == 0.0f;
-                        l = v - tol; h = v + tol;
-                    }
-                    DH_LA(lo, lane)[0] = l; DH_LA(hi, lane)[0] = h;
-                    DH_BALLOT_ACC(vote_guard, guard, lane);
-                    DH_BALLOT_ACC(vote_vzero, vzero, lane);
-                    DH_BALLOT_ACC(vote_pos, l > 0.0f, lane);
-                    DH_BALLOT_ACC(vote_small, h < 4999999.0f, lane);
-                }
-                const uint32_t ten = 0x3FFu;
-                if (((uint32_t) vote_vzero & ten) && !(BOUNDED && e_blk > 0.0f)) {       // (approximate samples prove nothing about exact zeros)
-                    // an estimate of exactly 0: only a phase whose hundred samples are all (+-)0 has vmin == 0 for sure (tiny
-                    // samples square to 0 in float, not in the reference's double) -- look at the bits
-                    uint64_t vote_nz = 0;
-                    DH_FOR_LANES_FRESH(lane) {
-                        uint32_t any = 0;
-                        if (lane < 50) {
-                            const uint32_t g = ((uint32_t) lane * 205u) >> 11, i = (uint32_t) lane - 10u * g;
-                            const uint32_t* row = reinterpret_cast<const uint32_t*>(S.var_rb + i * DH_VARIANCE_SYMBOLS + g * 20u);
-#pragma unroll
-                            for (int q = 0; q < 20; q++) any |= row[q];
-                        }
-                        DH_BALLOT_ACC(vote_nz, (any << 1) != 0u, lane);
-                    }
-                    const uint32_t nz = (uint32_t) (vote_nz | (vote_nz >> 10) | (vote_nz >> 20) | (vote_nz >> 30) | (vote_nz >> 40));
-                    vote_zero = ~nz & ten;
-                }
-                float hmin;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                hmin = dh_row_min_to_lane15(hi[0]);
-#else
-                hmin = DH_FLT_MAX;
-                for (int q = 0; q < 10; q++) hmin = dh_fmin_(hmin, hi[q][0]);
-#endif
-                DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(vote_above, DH_LA(lo, lane)[0] > hmin, lane); }
-                const uint32_t above = (uint32_t) vote_above & ten;
-                const uint32_t cand = ~above & ten;                 // phases whose interval reaches below hmin
-                if (((uint32_t) vote_guard & ten) != ten) {
-                } else if ((uint32_t) vote_zero & ten) {
-                    ordered = false;                                // vmin == 0 exactly: no step
-                } else if (dh_popc32(cand) == 1 && ((uint32_t) vote_pos & cand) && ((uint32_t) vote_small & cand)) {
-                    ordered = false;
-                    const uint32_t vmin_pos = (uint32_t) dh_ffs64((uint64_t) cand);
-                    if (vmin_pos > 0 && vmin_pos < 5) new_off = +1;
-                    else if (vmin_pos >= 5 && vmin_pos < 9) new_off = -1;
-                }
-                // (the candidates are not handed on here: one more live value costs the 81-tap kernels four scratch accesses in
-                // their hot loop, and they reach this point in 0.02 % of the blocks -- the 161-tap, sps-20 kernel in 1.3 %)
-            }
-            if (ordered && SPS != 10 && sps <= DH_WAVE && !P.ordered_timing && (!BOUNDED || P.exact_mode == 0)) {
-                // (sps 33 .. 64, e.g. POCSAG's 40: one lane per phase, chains of 100 + 1 fused terms -- (1 + u)^102 - 1 < 6.1e-6, still
-                // inside the 8e-6 V' below; the float mean is then the reference's own chain, within 100.1 u A of the true one.  The
-                // in-order double chain cost that slicer a fifth of its time, every block.)
-                // Run-time sps with at least one lane per phase: a float estimate like the sps-10 one.  G = 64 / sps groups
-                // per phase, lane g sps + i takes a contiguous piece of row i -- `seg` = 4 ceil(25 / G) ring entries, read 16
-                // bytes at a time -- and the partial sums meet in LDS.  The bound of the sps-10 estimate holds with 8e-6 V'
-                // for 4e-6 V' (chains of up to 52 fused terms + G partials); in the error-bounded kernels the ring holds
-                // values within e_blk of the reference's, which moves a variance by |2 cov(x, d) + var(d)| <= 2 e sigma +
-                // e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken as 2.5 e sqrt(V) + 4 e^2).  An estimate
-                // of exactly 0, a NaN or an overflow is left to the chain below.
-                DH_BARRIER();                                   // mn / mx are dead from here: scratch
-                float* psum = S.mn; float* pd = S.mx; float* pmean = S.mn + 64;
-                const uint32_t G = DH_WAVE / sps, active = G * sps, quads = (25u + G - 1u) / G;
-                for (int pass = 0; pass < 2; pass++) {
-                    DH_FOR_LANES_FRESH(lane) {
-                        if ((uint32_t) lane < active) {
-                            const uint32_t g = (uint32_t) lane / sps, i = (uint32_t) lane - g * sps;
-                            const uint32_t q0 = g * quads;                                 // first 16-byte piece of this lane
-                            const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + i * DH_VARIANCE_SYMBOLS);
-                            float mean = 0.0f;
-                            if (pass == 1) {
-                                float total = 0.0f;
-                                for (uint32_t gg = 0; gg < G; gg++) total += psum[gg * sps + i];
-                                mean = total * 0.01f;
-                                if (g == 0) pmean[i] = mean;
-                            }
-                            float acc = 0.0f;
-                            for (uint32_t q = 0; q < quads; q += 3u) {                     // three pieces in flight
-                                dh_f4a v[3];
-#pragma unroll
-                                for (uint32_t j = 0; j < 3u; j++) v[j] = row[dh_min<uint32_t>(q0 + q + j, 24u)];
-#pragma unroll
-                                for (uint32_t j = 0; j < 3u; j++) {
-                                    if (q + j < quads && q0 + q + j < 25u) {
-                                        if (pass == 0) { acc += v[j].x; acc += v[j].y; acc += v[j].z; acc += v[j].w; }
-                                        else {
-                                            const float d0 = mean - v[j].x, d1 = mean - v[j].y, d2 = mean - v[j].z, d3 = mean - v[j].w;
-                                            acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
-                                            acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
-                                        }
-                                    }
-                                }
-                            }
-                            if (pass == 0) psum[lane] = acc; else pd[lane] = acc;
-                        }
-                    }
-                    DH_BARRIER();
-                }
-                DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1);
-                uint64_t v_ok = 0, v_pos = 0, v_small = 0, v_big = 0, v_above = 0;
-                DH_FOR_LANES_FRESH(lane) {
-                    float l = DH_FLT_MAX, h = DH_FLT_MAX;
-                    bool ok = true;
-                    if ((uint32_t) lane < sps) {
-                        float v = 0.0f;
-                        for (uint32_t gg = 0; gg < G; gg++) v += pd[gg * sps + (uint32_t) lane];
-                        v *= 0.01f;
-                        const float mean = pmean[lane];
-                        const float e = __builtin_fmaf(mean, mean, v);
-                        float tol = __builtin_fmaf(v, 8e-6f, __builtin_fmaf(e, 1.2e-10f, 1e-42f));
-                        if (BOUNDED && e_blk > 0.0f) tol += 2.5f * e_blk * __builtin_sqrtf(v) + 4.0f * e_blk * e_blk;
-                        ok = e < 1e30f && v != 0.0f;
-                        l = v - tol; h = v + tol;
-                    }
-                    DH_LA(iv_lo, lane)[0] = l; DH_LA(iv_hi, lane)[0] = h;
-                    DH_BALLOT_ACC(v_ok, ok, lane);
-                    DH_BALLOT_ACC(v_pos, l > 0.0f, lane);
-                    DH_BALLOT_ACC(v_small, h < 4999999.0f, lane);
-                    DH_BALLOT_ACC(v_big, l > 5000001.0f, lane);
-                }
-                float hmin;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                hmin = -dh_wave_max(-iv_hi[0]);
-#else
-                hmin = DH_FLT_MAX;
-                for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
-#endif
-                DH_FOR_LANES_FRESH(lane) { DH_BALLOT_ACC(v_above, DH_LA(iv_lo, lane)[0] > hmin, lane); }
-                const uint64_t phases = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
-                const uint64_t cand = ~v_above & phases;                          // phases whose interval reaches below the smallest upper end
-                const bool one = cand != 0 && (cand & (cand - 1)) == 0;
-                if (one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand))) {
-                    ordered = false;
-                    const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
-                    if (v_big & cand) {
-                    } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
-                    else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
-                } else if (cand != 0 && (v_ok & phases) == phases) {
-                    chain_rows = cand;
-                }
-            }
-            if (DH_UNLIKELY(ordered)) {
-                // both sums of a phase in symbol order: one phase per lane, its 100 samples contiguous in the transposed
-                // ring and fetched 16 bytes at a time.
-                // Error-bounded kernels: the ring holds values within e_blk of the reference's.  At sps 10 the estimate above
-                // has already failed, so the chain runs on the reference's samples -- all thousand of this block, recomputed
-                // exactly.  At a run-time sps there is no estimate: the chain first runs on the ring as it is (attempt 0) and
-                // its result stands if the intervals [V - tol, V + tol] separate the smallest phase from all others, from 0 and
-                // from 5e6; otherwise attempt 1 recomputes the ring exactly.  tol: samples moved by <= e move the variance
-                // by |2 cov(x, d) + var(d)| <= 2 e sigma + e^2 with sigma <= sqrt(V) + e, i.e. <= 2 e sqrt(V) + 3 e^2 (taken
-                // as 2.5 e sqrt(V) + 4 e^2); each chain's float mean is within 100.1 u A of the true one, which moves its
-                // sum of squared deviations by (that)^2 <= 1e-10 (V + mean^2); the double arithmetic adds 1e-14 V.
-                const bool approx_ring = BOUNDED && e_blk > 0.0f;
-                for (int attempt = (approx_ring && SPS != 10 && sps > DH_WAVE && !P.ordered_timing && P.exact_mode == 0) ? 0 : 1; attempt < 2; attempt++) {      // (attempt 0 only where the estimate above does not run)
-                    DH_BARRIER();
-                    if (approx_ring && attempt == 1) {
-                        DhExactCtx C;
-                        C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
-                        C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
-                        C.prev_start = 0; C.prev_off = 0; C.blk_flags = dh_uniform(BS->blk_flags);
-                        C.k0 = k0; C.e_eff = 0.0f; C.levels = P.levels; C.invert = P.invert;
-                        // (the window block is dead here except words 512..575, where the L2 touch of the next window may
-                        // still be dropping its dwords: the staged variant uses the words behind them)
-                        dh_exact_var_ring_staged<NZ>(C, S, sps, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, chain_rows);
-                        BS->n_exact_blocks++;
-                        DH_BARRIER();
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-#endif
-                    }
-                    DH_LANE_ARRAY(float, iv_lo, 1); DH_LANE_ARRAY(float, iv_hi, 1); DH_LANE_ARRAY(uint32_t, iv_ok, 1);
-                    DH_FOR_LANES_FRESH(lane) {
-                        if ((uint32_t) lane < sps && !((chain_rows >> (uint32_t) lane) & 1ull)) {
-                            S.variance[lane] = DH_DBL_MAX;               // ruled out by its interval: never the smallest
-                            if (BOUNDED && SPS != 10 && attempt == 0) { DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u; }
-                        } else if ((uint32_t) lane < sps) {
-                            const dh_f4a* row = reinterpret_cast<const dh_f4a*>(S.var_rb + lane * DH_VARIANCE_SYMBOLS);
-                            float total = 0.0f;
-#pragma unroll 5
-                            for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
-                                const dh_f4a v = row[q];
-                                total += v.x; total += v.y; total += v.z; total += v.w;
-                            }
-                            const double mean = (double) (total / (float) DH_VARIANCE_SYMBOLS);
-                            double dsum = 0.0;
-#pragma unroll 5
-                            for (int q = 0; q < DH_VARIANCE_SYMBOLS / 4; q++) {
-                                const dh_f4a v = row[q];
-                                const double d0 = mean - (double) v.x, d1 = mean - (double) v.y, d2 = mean - (double) v.z, d3 = mean - (double) v.w;
-                                const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
-                                dsum += s0; dsum += s1; dsum += s2; dsum += s3;
-                            }
-                            const double var = dsum / (double) DH_VARIANCE_SYMBOLS;
-                            S.variance[lane] = var;
-                            if (BOUNDED && SPS != 10 && attempt == 0) {
-                                // this phase's interval, as floats rounded outwards (2e-7 V covers the two conversions)
-                                const double eb = (double) e_blk;
-                                const double tol = 2.5 * eb * __builtin_sqrt(var) + 4.0 * eb * eb + 2e-10 * (var + mean * mean) + 2e-7 * var + 1e-40;
-                                DH_LA(iv_lo, lane)[0] = (float) (var - tol); DH_LA(iv_hi, lane)[0] = (float) (var + tol);
-                                DH_LA(iv_ok, lane)[0] = (var + mean * mean < 1e30) ? 1u : 0u;      // false for NaN / overflow, as in the estimate
-                            }
-                        } else if (BOUNDED && SPS != 10 && attempt == 0) {
-                            DH_LA(iv_lo, lane)[0] = DH_FLT_MAX; DH_LA(iv_hi, lane)[0] = DH_FLT_MAX; DH_LA(iv_ok, lane)[0] = 1u;
-                        }
-                    }
-                    DH_BARRIER();
-                    if (BOUNDED && SPS != 10 && attempt == 0) {
-                        // is the reference's (arg-min, vmin <= 0, vmin > 5e6) beyond doubt?  One vote per question.
-                        float hmin;
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-                        hmin = -dh_wave_max(-iv_hi[0]);
-#else
-                        hmin = DH_FLT_MAX;
-                        for (int q = 0; q < DH_WAVE; q++) hmin = dh_fmin_(hmin, iv_hi[q][0]);
-#endif
-                        uint64_t v_above = 0, v_ok = 0, v_pos = 0, v_small = 0, v_big = 0;
-                        DH_FOR_LANES_FRESH(lane) {
-                            const float l = DH_LA(iv_lo, lane)[0], h = DH_LA(iv_hi, lane)[0];
-                            DH_BALLOT_ACC(v_above, l > hmin, lane);
-                            DH_BALLOT_ACC(v_ok, DH_LA(iv_ok, lane)[0] != 0u, lane);
-                            DH_BALLOT_ACC(v_pos, l > 0.0f, lane);
-                            DH_BALLOT_ACC(v_small, h < 4999999.0f, lane);
-                            DH_BALLOT_ACC(v_big, l > 5000001.0f, lane);
-                        }
-                        const uint64_t phases = sps >= 64u ? ~0ull : ((1ull << sps) - 1ull);
-                        const uint64_t cand = ~v_above & phases;                  // phases whose interval reaches below the smallest upper end
-                        const bool one = cand != 0 && (cand & (cand - 1)) == 0;
-                        const bool sure = one && (v_ok & phases) == phases && (((v_pos & cand) && (v_small & cand)) || (v_big & cand));
-                        if (!sure) continue;                                      // attempt 1: the exact ring
-                        DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
-                        const uint32_t vmin_pos = (uint32_t) dh_ffs64(cand);
-                        if (v_big & cand) {
-                        } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
-                        else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
-                        break;
-                    }
-                    double vmin = S.variance[0]; uint32_t vmin_pos = 0;
-                    for (uint32_t i = 1; i < sps; i++) if (S.variance[i] < vmin) { vmin = S.variance[i]; vmin_pos = i; }
-                    DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) S.stats[1]++; }
-                    if (vmin <= 0 || vmin > 5000000) {
-                    } else if (vmin_pos > 0 && vmin_pos < sps / 2) new_off = +1;
-                    else if (vmin_pos >= sps / 2 && vmin_pos < sps - 1) new_off = -1;
-                    break;
-                }
-            }
+            const DhStreamView V = { tail, tc, in, nv, sps_rcp };
+            new_off = dh_timing_decision<NZ, SPS, BOUNDED>(P, S, BS, V, sps, k0, e_blk);
         }
 
         DH_PHASE_MARK(5);
