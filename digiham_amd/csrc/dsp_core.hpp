@@ -1348,6 +1348,164 @@ DH_COLD void dh_exact_fir_pass(const DhDspParams& P, DhDspShared& S, uint32_t ne
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
+// sps 10: two symbols per lane -- q = lane + 1 and (lanes 0..34) q = lane + 65, lane 35: symbol 0, the only one in front of the pending
+// timing step -- each read as five ds_read_b64 at compile-time offsets from one per-lane base (eight bytes from a four-byte aligned
+// address: the symbols start 40 bytes apart and a timing step moves them by four).  Ten words per lane, read in pairs, touch every
+// bank twice per 32 lanes: conflict-free.  Until the end of round 5 the two symbols of a lane were 24 symbols apart and a
+// ds_read2_b32 delivered sample i of both as a register pair for packed additions (16 vector instructions less per run): a
+// ten-word lane stride read ONE word at a time only ever reaches the sixteen banks of its parity, every read was a two-way conflict --
+// SQ_LDS_BANK_CONFLICT 4.75e8 -> 1.74e8 per launch, SQ_LDS_IDX_ACTIVE -21 %, chain -2 % (profiles/r05_a_ab_logs.txt).  Each
+// symbol's sums run in sample order, as the reference's do.  Lanes beyond the run read words of the window block that nothing will
+// look at and store nothing.
+// `fbuf`: the run's filtered samples (the window block); symbol q of the run (ring slot k0 + q) starts at q sps (+ step_off behind symbol 0).
+// Leaves S.sum[q], S.vol_new[k0 + q] and column k0 + q of the transposed ring; the caller's barrier publishes them.
+template <int SPS>
+DH_HD void dh_symbol_windows(DhDspShared& S, const float* fbuf, uint32_t k0, uint32_t m, int32_t step_off, uint32_t sps, uint32_t ev_lo, uint32_t ev_hi, float sps_rcp) {
+#define DH_FB(n) fbuf[n]
+    if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        const uint32_t l = (uint32_t) lane;
+        const uint32_t qa = l + 1u, qb = l < 35u ? l + 65u : 0u;
+        const bool va = qa < m, vb = l < 35u ? qb < m : l == 35u;
+        const float* srca = fbuf + (int32_t) (qa * 10u) + step_off;
+        const float* srcb = l < 35u ? srca + 640 : fbuf;
+        float v[10], w[10];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        {
+            const uint32_t aa = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) srca;
+            const uint32_t ab = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) srcb;
+            dh_f2 x0 = dh_lds_read_b64<0>(aa), x1 = dh_lds_read_b64<8>(aa), x2 = dh_lds_read_b64<16>(aa), x3 = dh_lds_read_b64<24>(aa), x4 = dh_lds_read_b64<32>(aa);
+            dh_f2 y0 = dh_lds_read_b64<0>(ab), y1 = dh_lds_read_b64<8>(ab), y2 = dh_lds_read_b64<16>(ab), y3 = dh_lds_read_b64<24>(ab), y4 = dh_lds_read_b64<32>(ab);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4) :: "memory");
+            v[0] = x0.x; v[1] = x0.y; v[2] = x1.x; v[3] = x1.y; v[4] = x2.x; v[5] = x2.y; v[6] = x3.x; v[7] = x3.y; v[8] = x4.x; v[9] = x4.y;
+            w[0] = y0.x; w[1] = y0.y; w[2] = y1.x; w[3] = y1.y; w[4] = y2.x; w[5] = y2.y; w[6] = y3.x; w[7] = y3.y; w[8] = y4.x; w[9] = y4.y;
+        }
+#else
+        for (int i = 0; i < 10; i++) { v[i] = srca[i]; w[i] = srcb[i]; }
+#endif
+        float vola = v[0], volb = w[0];
+#pragma unroll
+        for (int i = 1; i < 10; i++) { vola += v[i]; volb += w[i]; }
+        const float mida = ((v[3] + v[4]) + v[5]) + v[6], midb = ((w[3] + w[4]) + w[5]) + w[6];          // samples ev_lo .. ev_hi - 1 = 3 .. 6
+        const float volume_a = dh_div_const(vola, 10.0f, sps_rcp), volume_b = dh_div_const(volb, 10.0f, sps_rcp);
+        if (va) {
+            const uint32_t ka = k0 + qa;
+            dh_lds_store_row10<0>(S.var_rb + ka, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
+            S.sum[qa] = mida; S.vol_new[ka] = volume_a;
+        }
+        if (vb) {
+            const uint32_t kb = k0 + qb;
+            dh_lds_store_row10<0>(S.var_rb + kb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9]);
+            S.sum[qb] = midb; S.vol_new[kb] = volume_b;
+        }
+        dh_lds_stores_done();
+    }
+    // sps 20 (a FIR pass holds at most 51 symbols): one symbol per lane, q = lane + 1, lane 63: symbol 0; its twenty samples as five
+    // ds_read_b128 (sixteen bytes from a four-byte aligned address).  Twenty words per lane read in fours touch every bank once per
+    // eight lanes; read one word at a time (the general form below) every read was a four-way conflict.
+    if (SPS == 20 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        const uint32_t l = (uint32_t) lane;
+        const uint32_t q = l < 63u ? l + 1u : 0u;
+        const bool valid = q < m;
+        const float* src = valid && q > 0u ? fbuf + (int32_t) (q * 20u) + step_off : fbuf;       // (lanes beyond the run read symbol 0 and store nothing)
+        float v[20];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        {
+            const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
+            dh_v4f x0 = dh_lds_read_b128<0>(a), x1 = dh_lds_read_b128<16>(a), x2 = dh_lds_read_b128<32>(a), x3 = dh_lds_read_b128<48>(a), x4 = dh_lds_read_b128<64>(a);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4) :: "memory");
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w; v[8] = x2.x; v[9] = x2.y;
+            v[10] = x2.z; v[11] = x2.w; v[12] = x3.x; v[13] = x3.y; v[14] = x3.z; v[15] = x3.w; v[16] = x4.x; v[17] = x4.y; v[18] = x4.z; v[19] = x4.w;
+        }
+#else
+        for (int i = 0; i < 20; i++) v[i] = src[i];
+#endif
+        float vol = v[0];
+#pragma unroll
+        for (int i = 1; i < 20; i++) vol += v[i];
+        const float mid = ((((v[7] + v[8]) + v[9]) + v[10]) + v[11]) + v[12];                    // samples ev_lo .. ev_hi - 1 = 7 .. 12
+        const float volume = dh_div_const(vol, 20.0f, sps_rcp);
+        if (valid) {
+            const uint32_t k = k0 + q;
+            dh_lds_store_row10<0>(S.var_rb + k, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
+            dh_lds_store_row10<1000>(S.var_rb + k, v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
+            S.sum[q] = mid; S.vol_new[k] = volume;
+        }
+        dh_lds_stores_done();
+    }
+    // sps 40 (a pass holds at most 25 symbols): the same with ten ds_read_b128 per symbol (a forty-word lane stride read one word at a
+    // time reaches four banks: eight-way conflicts in the general loop)
+    if (SPS == 40 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        const uint32_t l = (uint32_t) lane;
+        const uint32_t q = l < 63u ? l + 1u : 0u;
+        const bool valid = q < m;
+        const float* src = valid && q > 0u ? fbuf + (int32_t) (q * 40u) + step_off : fbuf;       // (lanes beyond the run read symbol 0 and store nothing)
+        float v[40];
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        {
+            const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
+            dh_v4f x0 = dh_lds_read_b128<0>(a), x1 = dh_lds_read_b128<16>(a), x2 = dh_lds_read_b128<32>(a), x3 = dh_lds_read_b128<48>(a), x4 = dh_lds_read_b128<64>(a);
+            dh_v4f x5 = dh_lds_read_b128<80>(a), x6 = dh_lds_read_b128<96>(a), x7 = dh_lds_read_b128<112>(a), x8 = dh_lds_read_b128<128>(a), x9 = dh_lds_read_b128<144>(a);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9) :: "memory");
+            const dh_v4f x[10] = { x0, x1, x2, x3, x4, x5, x6, x7, x8, x9 };
+#pragma unroll
+            for (int i = 0; i < 10; i++) { v[4 * i] = x[i].x; v[4 * i + 1] = x[i].y; v[4 * i + 2] = x[i].z; v[4 * i + 3] = x[i].w; }
+        }
+#else
+        for (int i = 0; i < 40; i++) v[i] = src[i];
+#endif
+        float vol = v[0], mid = v[13];
+#pragma unroll
+        for (int i = 1; i < 40; i++) vol += v[i];
+#pragma unroll
+        for (int i = 14; i < 27; i++) mid += v[i];                                               // samples ev_lo .. ev_hi - 1 = 13 .. 26
+        const float volume = dh_div_const(vol, 40.0f, sps_rcp);
+        if (valid) {
+            const uint32_t k = k0 + q;
+            dh_lds_store_row10<0>(S.var_rb + k, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
+            dh_lds_store_row10<1000>(S.var_rb + k, v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
+            dh_lds_store_row10<2000>(S.var_rb + k, v[20], v[21], v[22], v[23], v[24], v[25], v[26], v[27], v[28], v[29]);
+            dh_lds_store_row10<3000>(S.var_rb + k, v[30], v[31], v[32], v[33], v[34], v[35], v[36], v[37], v[38], v[39]);
+            S.sum[q] = mid; S.vol_new[k] = volume;
+        }
+        dh_lds_stores_done();
+    }
+    if (SPS != 10 && SPS != 20 && SPS != 40 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
+        for (uint32_t q = lane; q < m; q += DH_WAVE) {
+            const uint32_t k = k0 + q;
+            const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
+            float sum = 0.0f, volume_sum = 0.0f;
+            {
+                // (the ring stores below may alias the samples as far as the compiler knows: read one by one, every sample would wait out
+                // its own LDS round trip before the next is even requested)
+                // four samples at a time, all four requested before the first is used; sums in sample order
+                uint32_t i = 0;
+                for (; i + 4u <= sps; i += 4u) {
+                    float value[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) value[j] = DH_FB(s + i + j);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        if (i + j >= ev_lo && i + j < ev_hi) sum += value[j];
+                        volume_sum += value[j];
+                        S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
+                    }
+                }
+                for (; i < sps; i++) {
+                    const float value = DH_FB(s + i);
+                    if (i >= ev_lo && i < ev_hi) sum += value;
+                    volume_sum += value;
+                    S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
+                }
+            }
+            S.sum[q] = sum;
+            S.vol_new[k] = dh_div_const(volume_sum, (float) sps, sps_rcp);
+        }
+    }
+#undef DH_FB
+}
+
+// ---------------------------------------------------------------------------------------------
 // ---- P6: end of a variance block -> timing decision (gfsk_demodulator.cpp:41-80)
 // The reference's result depends on the per-phase variances only through (arg-min position, vmin <= 0,
 // vmin > 5e6).  Its sums run in symbol order (float total, then double sum of squared deviations): a
@@ -1763,6 +1921,100 @@ DH_HD int32_t dh_timing_decision(const DhDspParams& P, DhDspShared& S, DhBoundSt
         }
     }
     return new_off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
+// error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
+// reference's; those symbols are not stored here but decided exactly below
+// TWO symbols per lane, q = 2 lane and 2 lane + 1 (a run has at most 100): their AGC extremes, window sums and everything
+// derived from them are pairs, so centre, average, the two thresholds and the three distances are packed operations for
+// both symbols -- one pass of ~40 vector instructions instead of two of ~37.  Every operation is the one the one-symbol
+// form performs (same operands, same order), so the dibits and the doubts are the same.
+// `out`: where symbol 0 of the run goes; `agc` (device): the scan's own results for the lane's two symbols, used when the run starts its
+// block.  Doubtful symbols are not stored; their votes come back in vote_a (symbols 2 l) and vote_b (2 l + 1).
+struct DhSliceSetup { bool four_levels, e_pos, width_pow2, pair_store; float T_eff, inv_width; };
+#if !(DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__))
+struct DhAgcPair { float mn0, mx0, mn1, mx1; };          // (harness: the scan leaves its results in S.mn / S.mx only)
+#endif
+template <int SPS, int LV, bool BOUNDED>
+DH_HD void dh_slice_symbols(const DhDspParams& P, DhDspShared& S, const DhAgcPair agc, uint8_t* out, uint32_t k0, uint32_t m, uint32_t ev_lo, uint32_t ev_hi,
+                            const DhSliceSetup& U, uint64_t& vote_a, uint64_t& vote_b) {
+    (void) agc;
+    const bool four_levels = U.four_levels, e_pos = U.e_pos, width_pow2 = U.width_pow2, pair_store = U.pair_store;
+    const float T_eff = U.T_eff, inv_width = U.inv_width;
+    DH_FOR_LANES_FRESH(lane) {
+        const uint32_t qa = 2u * (uint32_t) lane;
+        const bool va = qa < m, vb = qa + 1u < m;
+        const uint32_t qq = va ? qa : 0u, k = k0 + qq;                            // (lanes beyond the run recompute symbols 0 / 1: in-range reads, no store)
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
+        // (a run that starts its block: the lane's symbols 2 l, 2 l + 1 are the ring slots the AGC scan left in its registers)
+        dh_f2 mn, mx;
+        if (k0 == 0u) { mn = dh_f2_make(agc.mn0, agc.mn1); mx = dh_f2_make(agc.mx0, agc.mx1); }
+        else { mn = dh_f2_make(S.mn[k], S.mn[k + 1u]); mx = dh_f2_make(S.mx[k], S.mx[k + 1u]); }
+#else
+        const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[k + 1u]), mx = dh_f2_make(S.mx[k], S.mx[k + 1u]);
+#endif
+        const dh_f2 sumq = dh_f2_make(S.sum[qq], S.sum[qq + 1u]);
+        const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);                // (max + min) / 2.0f: the division by two is exact
+        // (sps 20: the division by the window's six samples as reciprocal product + exact residual + correction, dh_div_const; tests/test_numerics.py)
+        const dh_f2 average = width_pow2 ? dh_f2_scale(sumq, inv_width) : SPS == 20 ? dh_div_const2(sumq, 6.0f, inv_width)
+                                                                                    : dh_f2_make(sumq.x / (float) (ev_hi - ev_lo), sumq.y / (float) (ev_hi - ev_lo));
+        const dh_f2 c625 = dh_f2_make(0.625f, 0.625f);
+        const dh_f2 umid = dh_f2_fma(dh_f2_sub(mx, center), c625, center);        // one float FMA each: see the one-symbol form below
+        const dh_f2 lmid = dh_f2_fma(dh_f2_sub(mn, center), c625, center);
+        const bool above_a = average.x > center.x, above_b = average.y > center.y;
+        const uint8_t sym4a = above_a ? (average.x > umid.x ? 1 : 0) : (average.x < lmid.x ? 3 : 2);
+        const uint8_t sym4b = above_b ? (average.y > umid.y ? 1 : 0) : (average.y < lmid.y ? 3 : 2);
+        const uint8_t sym2a = LV == 4 ? (uint8_t) 0 : above_a ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+        const uint8_t sym2b = LV == 4 ? (uint8_t) 0 : above_b ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
+        const uint8_t sa = four_levels ? sym4a : sym2a, sb = four_levels ? sym4b : sym2b;
+        bool doubt_a = false, doubt_b = false;
+        if (BOUNDED) {
+            const dh_f2 du = dh_f2_sub(average, umid), dl = dh_f2_sub(average, lmid), dc = dh_f2_sub(average, center);
+            const float da = dh_min3_abs(four_levels ? du.x : DH_FLT_MAX, four_levels ? dl.x : DH_FLT_MAX, dc.x);
+            const float db = dh_min3_abs(four_levels ? du.y : DH_FLT_MAX, four_levels ? dl.y : DH_FLT_MAX, dc.y);
+            doubt_a = va && e_pos && !(da > T_eff);                               // (!(d > T): a NaN distance is a doubt)
+            doubt_b = vb && e_pos && !(db > T_eff);
+        }
+#ifdef DH_IGNORE_DOUBT
+        doubt_a = false; doubt_b = false;
+#endif
+        // the lane's two dibits are neighbours: one 16-bit store when the row position is even (wave-uniform) and both are decided
+        if (pair_store && va && !doubt_a && vb && !doubt_b) *reinterpret_cast<uint16_t*>(out + qa) = (uint16_t) ((uint32_t) sa | ((uint32_t) sb << 8));
+        else {
+            if (va && !doubt_a) out[qa] = sa;
+            if (vb && !doubt_b) out[qa + 1u] = sb;
+        }
+        DH_BALLOT_ACC(vote_a, doubt_a, lane);
+        DH_BALLOT_ACC(vote_b, doubt_b, lane);
+    }
+}
+
+// the doubtful symbols of a run (votes of dh_slice_symbols), one exact evaluation at a time -- the even symbols' votes first (the evaluations do
+// not depend on one another); ONE call site: the evaluation is a thousand instructions of text
+template <int NZ>
+DH_COLD void dh_settle_doubts(const DhDspParams& P, DhDspShared& S, DhBoundState* const BS, const DhStreamView& V, uint8_t* out, uint32_t k0, float e_eff,
+                              uint32_t sps, uint32_t ev_lo, uint32_t ev_hi, uint64_t vote_a, uint64_t vote_b) {
+    const float* const tail = V.tail; const uint32_t tc = V.tc; const float* const in = V.in; const uint32_t nv = V.nv; const float sps_rcp = V.sps_rcp;
+        DhExactCtx C;
+        C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
+        C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
+        C.prev_start = (int32_t) dh_uniform((uint32_t) BS->prev_start); C.prev_off = (int32_t) dh_uniform((uint32_t) BS->prev_off);
+        C.blk_flags = dh_uniform(BS->blk_flags);
+        C.k0 = k0; C.e_eff = e_eff; C.levels = P.levels; C.invert = P.invert;
+        // one evaluation at a time, the even symbols' votes first (the evaluations do not depend on one another); ONE call site:
+        // the evaluation is a thousand instructions of text
+        uint64_t ta = vote_a, tb = vote_b;
+        while ((ta | tb) != 0) {
+            uint32_t q;
+            if (ta) { q = 2u * (uint32_t) dh_ffs64(ta); ta &= ta - 1; } else { q = 2u * (uint32_t) dh_ffs64(tb) + 1u; tb &= tb - 1; }
+            // (the raw samples behind each evaluation are staged through the dead part of the window block: fetched one by one from
+            // HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
+            const uint8_t sym = dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi);
+            DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) out[q] = sym; }
+            BS->n_uncertain++;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2254,7 +2506,6 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_TAPFRAG_SETTLE();
         DH_PHASE_MARK(1);
         const float* fbuf = S.xf;
-#define DH_FB(n) fbuf[n]
 
         // ---- prefetch: the raw window of the NEXT run.  Its start is already known (the timing decision of this
         // block only moves symbols 1.. of the next one), the window block is idle from here to the end of the
@@ -2336,163 +2587,16 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         const bool width_pow2 = ((ev_hi - ev_lo) & (ev_hi - ev_lo - 1u)) == 0u;
         const bool pair_store = ((uint32_t) (uintptr_t) syms + nsym) % 2u == 0u;      // (paired slicing phases: symbols 2 l, 2 l + 1 of the run as one 16-bit store)
 
-        // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83)
-        // sps 10: two symbols per lane -- q = lane + 1 and (lanes 0..34) q = lane + 65, lane 35: symbol 0, the only one in front of the pending
-        // timing step -- each read as five ds_read_b64 at compile-time offsets from one per-lane base (eight bytes from a four-byte aligned
-        // address: the symbols start 40 bytes apart and a timing step moves them by four).  Ten words per lane, read in pairs, touch every
-        // bank twice per 32 lanes: conflict-free.  Until the end of round 5 the two symbols of a lane were 24 symbols apart and a
-        // ds_read2_b32 delivered sample i of both as a register pair for packed additions (16 vector instructions less per run): a
-        // ten-word lane stride read ONE word at a time only ever reaches the sixteen banks of its parity, every read was a two-way conflict --
-        // SQ_LDS_BANK_CONFLICT 4.75e8 -> 1.74e8 per launch, SQ_LDS_IDX_ACTIVE -21 %, chain -2 % (profiles/r05_a_ab_logs.txt).  Each
-        // symbol's sums run in sample order, as the reference's do.  Lanes beyond the run read words of the window block that nothing will
-        // look at and store nothing.
-        if (SPS == 10 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
-            const uint32_t l = (uint32_t) lane;
-            const uint32_t qa = l + 1u, qb = l < 35u ? l + 65u : 0u;
-            const bool va = qa < m, vb = l < 35u ? qb < m : l == 35u;
-            const float* srca = fbuf + (int32_t) (qa * 10u) + step_off;
-            const float* srcb = l < 35u ? srca + 640 : fbuf;
-            float v[10], w[10];
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            {
-                const uint32_t aa = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) srca;
-                const uint32_t ab = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) srcb;
-                dh_f2 x0 = dh_lds_read_b64<0>(aa), x1 = dh_lds_read_b64<8>(aa), x2 = dh_lds_read_b64<16>(aa), x3 = dh_lds_read_b64<24>(aa), x4 = dh_lds_read_b64<32>(aa);
-                dh_f2 y0 = dh_lds_read_b64<0>(ab), y1 = dh_lds_read_b64<8>(ab), y2 = dh_lds_read_b64<16>(ab), y3 = dh_lds_read_b64<24>(ab), y4 = dh_lds_read_b64<32>(ab);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4) :: "memory");
-                v[0] = x0.x; v[1] = x0.y; v[2] = x1.x; v[3] = x1.y; v[4] = x2.x; v[5] = x2.y; v[6] = x3.x; v[7] = x3.y; v[8] = x4.x; v[9] = x4.y;
-                w[0] = y0.x; w[1] = y0.y; w[2] = y1.x; w[3] = y1.y; w[4] = y2.x; w[5] = y2.y; w[6] = y3.x; w[7] = y3.y; w[8] = y4.x; w[9] = y4.y;
-            }
-#else
-            for (int i = 0; i < 10; i++) { v[i] = srca[i]; w[i] = srcb[i]; }
-#endif
-            float vola = v[0], volb = w[0];
-#pragma unroll
-            for (int i = 1; i < 10; i++) { vola += v[i]; volb += w[i]; }
-            const float mida = ((v[3] + v[4]) + v[5]) + v[6], midb = ((w[3] + w[4]) + w[5]) + w[6];          // samples ev_lo .. ev_hi - 1 = 3 .. 6
-            const float volume_a = dh_div_const(vola, 10.0f, sps_rcp), volume_b = dh_div_const(volb, 10.0f, sps_rcp);
-            if (va) {
-                const uint32_t ka = k0 + qa;
-                dh_lds_store_row10<0>(S.var_rb + ka, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
-                S.sum[qa] = mida; S.vol_new[ka] = volume_a;
-            }
-            if (vb) {
-                const uint32_t kb = k0 + qb;
-                dh_lds_store_row10<0>(S.var_rb + kb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9]);
-                S.sum[qb] = midb; S.vol_new[kb] = volume_b;
-            }
-            dh_lds_stores_done();
-        }
-        // sps 20 (a FIR pass holds at most 51 symbols): one symbol per lane, q = lane + 1, lane 63: symbol 0; its twenty samples as five
-        // ds_read_b128 (sixteen bytes from a four-byte aligned address).  Twenty words per lane read in fours touch every bank once per
-        // eight lanes; read one word at a time (the general form below) every read was a four-way conflict.
-        if (SPS == 20 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
-            const uint32_t l = (uint32_t) lane;
-            const uint32_t q = l < 63u ? l + 1u : 0u;
-            const bool valid = q < m;
-            const float* src = valid && q > 0u ? fbuf + (int32_t) (q * 20u) + step_off : fbuf;       // (lanes beyond the run read symbol 0 and store nothing)
-            float v[20];
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            {
-                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
-                dh_v4f x0 = dh_lds_read_b128<0>(a), x1 = dh_lds_read_b128<16>(a), x2 = dh_lds_read_b128<32>(a), x3 = dh_lds_read_b128<48>(a), x4 = dh_lds_read_b128<64>(a);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4) :: "memory");
-                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w; v[8] = x2.x; v[9] = x2.y;
-                v[10] = x2.z; v[11] = x2.w; v[12] = x3.x; v[13] = x3.y; v[14] = x3.z; v[15] = x3.w; v[16] = x4.x; v[17] = x4.y; v[18] = x4.z; v[19] = x4.w;
-            }
-#else
-            for (int i = 0; i < 20; i++) v[i] = src[i];
-#endif
-            float vol = v[0];
-#pragma unroll
-            for (int i = 1; i < 20; i++) vol += v[i];
-            const float mid = ((((v[7] + v[8]) + v[9]) + v[10]) + v[11]) + v[12];                    // samples ev_lo .. ev_hi - 1 = 7 .. 12
-            const float volume = dh_div_const(vol, 20.0f, sps_rcp);
-            if (valid) {
-                const uint32_t k = k0 + q;
-                dh_lds_store_row10<0>(S.var_rb + k, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
-                dh_lds_store_row10<1000>(S.var_rb + k, v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
-                S.sum[q] = mid; S.vol_new[k] = volume;
-            }
-            dh_lds_stores_done();
-        }
-        // sps 40 (a pass holds at most 25 symbols): the same with ten ds_read_b128 per symbol (a forty-word lane stride read one word at a
-        // time reaches four banks: eight-way conflicts in the general loop)
-        if (SPS == 40 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
-            const uint32_t l = (uint32_t) lane;
-            const uint32_t q = l < 63u ? l + 1u : 0u;
-            const bool valid = q < m;
-            const float* src = valid && q > 0u ? fbuf + (int32_t) (q * 40u) + step_off : fbuf;       // (lanes beyond the run read symbol 0 and store nothing)
-            float v[40];
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            {
-                const uint32_t a = (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) float*) src;
-                dh_v4f x0 = dh_lds_read_b128<0>(a), x1 = dh_lds_read_b128<16>(a), x2 = dh_lds_read_b128<32>(a), x3 = dh_lds_read_b128<48>(a), x4 = dh_lds_read_b128<64>(a);
-                dh_v4f x5 = dh_lds_read_b128<80>(a), x6 = dh_lds_read_b128<96>(a), x7 = dh_lds_read_b128<112>(a), x8 = dh_lds_read_b128<128>(a), x9 = dh_lds_read_b128<144>(a);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9) :: "memory");
-                const dh_v4f x[10] = { x0, x1, x2, x3, x4, x5, x6, x7, x8, x9 };
-#pragma unroll
-                for (int i = 0; i < 10; i++) { v[4 * i] = x[i].x; v[4 * i + 1] = x[i].y; v[4 * i + 2] = x[i].z; v[4 * i + 3] = x[i].w; }
-            }
-#else
-            for (int i = 0; i < 40; i++) v[i] = src[i];
-#endif
-            float vol = v[0], mid = v[13];
-#pragma unroll
-            for (int i = 1; i < 40; i++) vol += v[i];
-#pragma unroll
-            for (int i = 14; i < 27; i++) mid += v[i];                                               // samples ev_lo .. ev_hi - 1 = 13 .. 26
-            const float volume = dh_div_const(vol, 40.0f, sps_rcp);
-            if (valid) {
-                const uint32_t k = k0 + q;
-                dh_lds_store_row10<0>(S.var_rb + k, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);      // transposed ring: phase-major
-                dh_lds_store_row10<1000>(S.var_rb + k, v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
-                dh_lds_store_row10<2000>(S.var_rb + k, v[20], v[21], v[22], v[23], v[24], v[25], v[26], v[27], v[28], v[29]);
-                dh_lds_store_row10<3000>(S.var_rb + k, v[30], v[31], v[32], v[33], v[34], v[35], v[36], v[37], v[38], v[39]);
-                S.sum[q] = mid; S.vol_new[k] = volume;
-            }
-            dh_lds_stores_done();
-        }
-        if (SPS != 10 && SPS != 20 && SPS != 40 && DH_STOP_AFTER >= 3) DH_FOR_LANES_FRESH(lane) {
-            for (uint32_t q = lane; q < m; q += DH_WAVE) {
-                const uint32_t k = k0 + q;
-                const uint32_t s = q * sps + (q > 0 ? (uint32_t) step_off : 0u);   // relative to p
-                float sum = 0.0f, volume_sum = 0.0f;
-                {
-                    // (the ring stores below may alias the samples as far as the compiler knows: read one by one, every sample would wait out
-                    // its own LDS round trip before the next is even requested)
-                    // four samples at a time, all four requested before the first is used; sums in sample order
-                    uint32_t i = 0;
-                    for (; i + 4u <= sps; i += 4u) {
-                        float value[4];
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++) value[j] = DH_FB(s + i + j);
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++) {
-                            if (i + j >= ev_lo && i + j < ev_hi) sum += value[j];
-                            volume_sum += value[j];
-                            S.var_rb[(i + j) * DH_VARIANCE_SYMBOLS + k] = value[j];       // transposed ring: phase-major
-                        }
-                    }
-                    for (; i < sps; i++) {
-                        const float value = DH_FB(s + i);
-                        if (i >= ev_lo && i < ev_hi) sum += value;
-                        volume_sum += value;
-                        S.var_rb[i * DH_VARIANCE_SYMBOLS + k] = value;
-                    }
-                }
-                S.sum[q] = sum;
-                S.vol_new[k] = dh_div_const(volume_sum, (float) sps, sps_rcp);
-            }
-        }
+        // ---- P3: symbol windows (gfsk_demodulator.cpp:28-35, 82-83): dh_symbol_windows
+        dh_symbol_windows<SPS>(S, fbuf, k0, m, step_off, sps, ev_lo, ev_hi, sps_rcp);
         DH_BARRIER();
         DH_PHASE_MARK(2);
 
         issue_next_window();
 
         // ---- P4: sliding AGC min/max as two wave scans
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
         DhAgcPair agc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
         if (DH_STOP_AFTER >= 4) agc = dh_agc_scan(S, k0, k0 + m);
 #else
         if (DH_STOP_AFTER >= 4) dh_agc_scan(S, k0, k0 + m);
@@ -2500,80 +2604,14 @@ DH_HD void dh_rrc_demod_channel(const DhDspParams& P, uint32_t ch, DhDspShared& 
         DH_BARRIER();
         DH_PHASE_MARK(3);
 
-        // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99)
-        // error-bounded mode: a comparison whose two sides are closer than T cannot be trusted to come out as the
-        // reference's; those symbols are not stored here but decided exactly below
-        // TWO symbols per lane, q = 2 lane and 2 lane + 1 (a run has at most 100): their AGC extremes, window sums and everything
-        // derived from them are pairs, so centre, average, the two thresholds and the three distances are packed operations for
-        // both symbols -- one pass of ~40 vector instructions instead of two of ~37.  Every operation is the one the one-symbol
-        // form performs (same operands, same order), so the dibits and the doubts are the same.
+        // ---- P5: thresholds + slice (gfsk_demodulator.cpp:88-106 / fsk_demodulator.cpp:89-99): dh_slice_symbols; what it leaves in doubt: dh_settle_doubts
         if (DH_STOP_AFTER >= 5) {
-        DH_FOR_LANES_FRESH(lane) {
-            const uint32_t qa = 2u * (uint32_t) lane;
-            const bool va = qa < m, vb = qa + 1u < m;
-            const uint32_t qq = va ? qa : 0u, k = k0 + qq;                            // (lanes beyond the run recompute symbols 0 / 1: in-range reads, no store)
-#if DH_DEVICE_BUILD && defined(__HIP_DEVICE_COMPILE__)
-            // (a run that starts its block: the lane's symbols 2 l, 2 l + 1 are the ring slots the AGC scan left in its registers)
-            dh_f2 mn, mx;
-            if (k0 == 0u) { mn = dh_f2_make(agc.mn0, agc.mn1); mx = dh_f2_make(agc.mx0, agc.mx1); }
-            else { mn = dh_f2_make(S.mn[k], S.mn[k + 1u]); mx = dh_f2_make(S.mx[k], S.mx[k + 1u]); }
-#else
-            const dh_f2 mn = dh_f2_make(S.mn[k], S.mn[k + 1u]), mx = dh_f2_make(S.mx[k], S.mx[k + 1u]);
-#endif
-            const dh_f2 sumq = dh_f2_make(S.sum[qq], S.sum[qq + 1u]);
-            const dh_f2 center = dh_f2_scale(dh_f2_add(mx, mn), 0.5f);                // (max + min) / 2.0f: the division by two is exact
-            // (sps 20: the division by the window's six samples as reciprocal product + exact residual + correction, dh_div_const; tests/test_numerics.py)
-            const dh_f2 average = width_pow2 ? dh_f2_scale(sumq, inv_width) : SPS == 20 ? dh_div_const2(sumq, 6.0f, inv_width)
-                                                                                        : dh_f2_make(sumq.x / (float) (ev_hi - ev_lo), sumq.y / (float) (ev_hi - ev_lo));
-            const dh_f2 c625 = dh_f2_make(0.625f, 0.625f);
-            const dh_f2 umid = dh_f2_fma(dh_f2_sub(mx, center), c625, center);        // one float FMA each: see the one-symbol form below
-            const dh_f2 lmid = dh_f2_fma(dh_f2_sub(mn, center), c625, center);
-            const bool above_a = average.x > center.x, above_b = average.y > center.y;
-            const uint8_t sym4a = above_a ? (average.x > umid.x ? 1 : 0) : (average.x < lmid.x ? 3 : 2);
-            const uint8_t sym4b = above_b ? (average.y > umid.y ? 1 : 0) : (average.y < lmid.y ? 3 : 2);
-            const uint8_t sym2a = LV == 4 ? (uint8_t) 0 : above_a ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
-            const uint8_t sym2b = LV == 4 ? (uint8_t) 0 : above_b ? (uint8_t) !P.invert : (uint8_t) (P.invert != 0);
-            const uint8_t sa = four_levels ? sym4a : sym2a, sb = four_levels ? sym4b : sym2b;
-            bool doubt_a = false, doubt_b = false;
-            if (BOUNDED) {
-                const dh_f2 du = dh_f2_sub(average, umid), dl = dh_f2_sub(average, lmid), dc = dh_f2_sub(average, center);
-                const float da = dh_min3_abs(four_levels ? du.x : DH_FLT_MAX, four_levels ? dl.x : DH_FLT_MAX, dc.x);
-                const float db = dh_min3_abs(four_levels ? du.y : DH_FLT_MAX, four_levels ? dl.y : DH_FLT_MAX, dc.y);
-                doubt_a = va && e_pos && !(da > T_eff);                               // (!(d > T): a NaN distance is a doubt)
-                doubt_b = vb && e_pos && !(db > T_eff);
-            }
-#ifdef DH_IGNORE_DOUBT
-            doubt_a = false; doubt_b = false;
-#endif
-            // the lane's two dibits are neighbours: one 16-bit store when the row position is even (wave-uniform) and both are decided
-            if (pair_store && va && !doubt_a && vb && !doubt_b) *reinterpret_cast<uint16_t*>(syms + nsym + qa) = (uint16_t) ((uint32_t) sa | ((uint32_t) sb << 8));
-            else {
-                if (va && !doubt_a) syms[nsym + qa] = sa;
-                if (vb && !doubt_b) syms[nsym + qa + 1u] = sb;
-            }
-            DH_BALLOT_ACC(vote_a, doubt_a, lane);
-            DH_BALLOT_ACC(vote_b, doubt_b, lane);
-        }
+            const DhSliceSetup U = { four_levels, e_pos, width_pow2, pair_store, T_eff, inv_width };
+            dh_slice_symbols<SPS, LV, BOUNDED>(P, S, agc, syms + nsym, k0, m, ev_lo, ev_hi, U, vote_a, vote_b);
         }
         if (BOUNDED && DH_UNLIKELY((vote_a | vote_b) != 0)) {
-            DhExactCtx C;
-            C.tail = tail; C.tc = tc; C.in = in; C.nv = nv; C.tapsf = S.tapsf; C.gain = P.gain; C.rgain = P.rgain; C.sps_rcp = sps_rcp;
-            C.cur_start = (int32_t) dh_uniform((uint32_t) BS->cur_start); C.cur_off = (int32_t) dh_uniform((uint32_t) BS->cur_off);
-            C.prev_start = (int32_t) dh_uniform((uint32_t) BS->prev_start); C.prev_off = (int32_t) dh_uniform((uint32_t) BS->prev_off);
-            C.blk_flags = dh_uniform(BS->blk_flags);
-            C.k0 = k0; C.e_eff = e_eff; C.levels = P.levels; C.invert = P.invert;
-            // one evaluation at a time, the even symbols' votes first (the evaluations do not depend on one another); ONE call site:
-            // the evaluation is a thousand instructions of text
-            uint64_t ta = vote_a, tb = vote_b;
-            while ((ta | tb) != 0) {
-                uint32_t q;
-                if (ta) { q = 2u * (uint32_t) dh_ffs64(ta); ta &= ta - 1; } else { q = 2u * (uint32_t) dh_ffs64(tb) + 1u; tb &= tb - 1; }
-                // (the raw samples behind each evaluation are staged through the dead part of the window block: fetched one by one from
-                // HBM / L2 by the 81-tap chains, a doubtful symbol cost as much as several whole runs)
-                const uint8_t sym = dh_exact_symbol_staged<NZ>(C, S, k0 + q, S.xf + 576, dh_dsp_xf_words(NZ) - 576u, sps, ev_lo, ev_hi);
-                DH_FOR_LANES_FRESH(lane) { if (DH_IS_LANE0(lane)) syms[nsym + q] = sym; }
-                BS->n_uncertain++;
-            }
+            const DhStreamView V = { tail, tc, in, nv, sps_rcp };
+            dh_settle_doubts<NZ>(P, S, BS, V, syms + nsym, k0, e_eff, sps, ev_lo, ev_hi, vote_a, vote_b);
         }
 
         DH_PHASE_MARK(4);
