@@ -25,4 +25,5 @@ for o in oc or []:
     print("  %-28s %-22s %7.3f ms  kernel %7.3f ms  frac %.3f  traffic/alg %-6s  ok=%s%s"
           % (o["workload"], o["config"].split(" x ")[0], o["ms_per_step"], o["avg_launch_ms"], o["frac"],
              "%.3f" % (o["traffic"] / (o.get("algorithmic_bytes_per_step") or o["algorithmic_bytes_per_launch"])) if o.get("traffic") else "-",
-             v.get("bit_exact_vs_oracle", v.get("within_1e-6_vs_oracle")), " (1e-6: %.2e)" % v["max_rel_err"] if "max_rel_err" in v else ""))
+             v.get("bit_exact_vs_oracle") or (bool(v.get("floats_within_2.5e-6_vs_oracle", v.get("within_1e-6_vs_oracle"))) and v.get("dibits_bit_exact_vs_oracle", True)),
+             " (floats: %.2e%s)" % (v["max_rel_err"], ", dibits exact" if v.get("dibits_bit_exact_vs_oracle") else "") if "max_rel_err" in v else ""))
